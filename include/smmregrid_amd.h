@@ -1,0 +1,191 @@
+/*
+ * smmregrid_amd.h -- C ABI of libsmmregrid_hip.so (MI355X / gfx950).
+ *
+ * This library replaces the third-party arithmetic that the reference
+ * (jhardenberg/smmregrid) invokes on its hot path -- the seam is
+ *
+ *   weights.py:25-44   compute_weights_matrix     sparse.COO([src,dst], w, (S,D))
+ *   weights.py:7-23    compute_weights_matrix3d   one COO per level, links[:link_length]
+ *   weights.py:47-52   mask_tensordot             (src_imask . W) < 0.5 ? 0 : 1
+ *   regrid.py:545-547  non-finite -> 1e20 fill of the source array
+ *   regrid.py:550      dask.array.tensordot(X(B,S), W(S,D), axes=1)
+ *   regrid.py:553-570  where(dst_imask) / where(frac < remap_area_min) / where(> 1e19)
+ *   regrid.py:387-418  regrid3d level loop + concat (+ transpose)
+ *
+ * The reference is pure Python: a maintainer binds this ABI with ctypes
+ * (see INTEGRATION.md for the stub). No torch / C++ types cross the boundary:
+ * plain pointers, sizes and opaque handles only.
+ *
+ * Conventions
+ *   - every function returns an int status (SMM_OK == 0); it never throws.
+ *     The message of the last failure on the calling thread is returned by
+ *     smm_last_error().
+ *   - "host" pointers are ordinary process memory, borrowed for the call only.
+ *     "device" pointers are HBM addresses (from smm_malloc or any hipMalloc).
+ *   - operator handles are immutable once their epilogue vectors are set;
+ *     smm_apply* is re-entrant on them (the reference's dask scheduler calls
+ *     one matrix from several threads, regrid.py:29-30).
+ *   - there is NO CPU fallback in this library: without a HIP device every
+ *     compute entry point fails with SMM_ERR_NO_DEVICE.
+ */
+#ifndef SMMREGRID_AMD_H
+#define SMMREGRID_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMM_ABI_VERSION 1
+
+/* status codes */
+enum {
+  SMM_OK = 0,
+  SMM_ERR_INVALID = 1,    /* bad argument (address out of range, negative size, ...) */
+  SMM_ERR_NO_DEVICE = 2,  /* no HIP device / device ordinal out of range            */
+  SMM_ERR_HIP = 3,        /* a HIP runtime call failed (message has the hipError)    */
+  SMM_ERR_ALLOC = 4,      /* host allocation failed                                  */
+  SMM_ERR_UNSUPPORTED = 5 /* dtype / flag combination not built                      */
+};
+
+/* element types of the dense field buffers */
+enum {
+  SMM_F32 = 0,
+  SMM_F64 = 1
+};
+
+/* smm_apply flags */
+enum {
+  SMM_APPLY_MASKED = 1u << 0,   /* apply dst_imask (regrid.py:553-559); per level in a group */
+  SMM_APPLY_NO_FILL = 1u << 1,  /* skip the 1e20 fill (caller guarantees finite X)           */
+  SMM_APPLY_KERNEL_SELL = 1u << 8, /* force the row-per-lane SELL-64 kernel                  */
+  SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
+};
+
+typedef struct smm_operator* smm_operator_t; /* one (S x D) weights matrix resident in HBM      */
+typedef struct smm_group* smm_group_t;       /* ordered set of operators (one per masked level) */
+
+/* ------------------------------------------------------------------ misc */
+int smm_abi_version(void);
+const char* smm_last_error(void);
+
+/* ------------------------------------------------- device / memory / time */
+int smm_device_count(int* count);
+int smm_set_device(int device);
+int smm_get_device(int* device);
+int smm_device_name(int device, char* buf, size_t buflen);
+int smm_mem_info(size_t* free_bytes, size_t* total_bytes);
+int smm_malloc(void** dptr, size_t bytes);
+int smm_free(void* dptr);
+int smm_host_alloc(void** hptr, size_t bytes); /* pinned host memory */
+int smm_host_free(void* hptr);
+int smm_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int smm_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int smm_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int smm_memset(void* dst_dev, int value, size_t bytes, void* stream);
+int smm_stream_create(void** stream);
+int smm_stream_destroy(void* stream);
+int smm_stream_sync(void* stream); /* NULL = default stream */
+int smm_device_sync(void);
+int smm_event_create(void** event);
+int smm_event_destroy(void* event);
+int smm_event_record(void* event, void* stream);
+int smm_event_sync(void* event);
+int smm_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* Synthetic field generator for benchmarks and full-size tests: fills n elements
+ * with a counter-based pseudo-normal sequence mean + sigma * N(0,1) (element i
+ * depends only on (seed, i), so shards can be filled independently). */
+int smm_fill_random(void* dst_dev, int dtype, int64_t n, uint64_t seed, double mean,
+                    double sigma, void* stream);
+
+/* ------------------------------------------------------------- operators */
+
+/*
+ * Build the operator from SCRIP/CDO links (replaces weights.py:31-42).
+ *   src_addr_1based / dst_addr_1based : int32[nnz], 1-based as in the CDO file
+ *   w                                  : double[nnz] = remap_matrix[:, 0]
+ * Links are sorted by (dst, src) with the original order as tie-break and
+ * duplicate (dst, src) pairs are summed in that order (the COO constructor's
+ * semantics).  Explicit zero weights are kept.  The handle owns a device copy
+ * on `device`; host arrays are only read during the call.
+ */
+int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz,
+                        const int32_t* src_addr_1based,
+                        const int32_t* dst_addr_1based,
+                        const double* w, int device, smm_operator_t* out);
+int smm_operator_destroy(smm_operator_t op);
+
+/* sizes after duplicate-summing; n_used_src = distinct source cells with >= 1 link (U) */
+int smm_operator_info(smm_operator_t op, int64_t* n_src, int64_t* n_dst,
+                      int64_t* nnz, int64_t* n_used_src, int64_t* max_row_nnz);
+
+/* canonical CSR (row = destination cell, 0-based, columns ascending) for parity tests.
+ * rowptr: int64[n_dst+1], col: int32[nnz], val: double[nnz] (host buffers). */
+int smm_operator_export_csr(smm_operator_t op, int64_t* rowptr, int32_t* col, double* val);
+
+/*
+ * Epilogue vectors of the weights file (host pointers, copied to HBM):
+ *   dst_imask: int32[n_dst] (regrid.py:510, used when SMM_APPLY_MASKED)
+ *   dst_frac : double[n_dst] (regrid.py:509, used when area_min > 0)
+ * Either may be NULL to clear it.  Call before any concurrent smm_apply.
+ */
+int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask,
+                              const double* dst_frac);
+
+/*
+ * Destination-mask pre-compute (weights.py:47-52):
+ *   dst_imask[d] = (sum_s src_imask[s] * W[s,d]) < 0.5 ? 0 : 1
+ * src_imask int32[n_src] host, dst_imask int32[n_dst] host (output).
+ * Runs on the device (SpMV + threshold).
+ */
+int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask);
+
+/* kernel selection the library made for this operator: 0 = SELL row-per-lane, 1 = LDS tile */
+int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
+                           int64_t* staged_src_elems);
+
+/* per-level set (replaces the list built by weights.py:7-23); borrows the operators */
+int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out);
+int smm_group_destroy(smm_group_t g);
+
+/* ----------------------------------------------------------------- apply */
+
+/*
+ * 2-D apply (regrid.py:536-570):   Y[b, :] = epilogue( fill(X[b, :]) . W ),  b in [0, n_batch)
+ *   x : device, element type x_dtype, row b starts at x + b*ldx elements (ldx >= n_src)
+ *   y : device, element type y_dtype, row b starts at y + b*ldy elements (ldy >= n_dst)
+ * The reference always produces f64 (result_type(x, f64)); y_dtype == SMM_F32 is an
+ * opt-in narrowing store.
+ */
+int smm_apply(smm_operator_t op,
+              const void* x, int x_dtype, int64_t ldx,
+              void* y, int y_dtype, int64_t ldy,
+              int64_t n_batch, double remap_area_min, unsigned flags, void* stream);
+
+/*
+ * Masked-level apply (regrid.py:387-418 in one launch).  The kept dims of the
+ * field are viewed as (n_outer, n_lev, n_inner) around the mask dimension;
+ * data level l uses group member level_index[l] (host int32[n_lev], result of
+ * the nearest-level match regrid.py:390).  Element offsets:
+ *   x row (o,l,i) at  o*xs_outer + l*xs_lev + i*xs_inner
+ *   y row (o,l,i) at  o*ys_outer + l*ys_lev + i*ys_inner
+ * so both the concat order and the transpose (regrid.py:420-427) are strides.
+ * With SMM_APPLY_MASKED, masked_levels (host uint8[n_ops], nullable = all)
+ * says per group member whether its dst_imask is applied (regrid.py:405).
+ */
+int smm_group_apply(smm_group_t g,
+                    const void* x, int x_dtype,
+                    int64_t xs_outer, int64_t xs_lev, int64_t xs_inner,
+                    void* y, int y_dtype,
+                    int64_t ys_outer, int64_t ys_lev, int64_t ys_inner,
+                    int64_t n_outer, int64_t n_lev, int64_t n_inner,
+                    const int32_t* level_index, const uint8_t* masked_levels,
+                    double remap_area_min, unsigned flags, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMMREGRID_AMD_H */

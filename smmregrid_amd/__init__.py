@@ -1,0 +1,13 @@
+"""smmregrid_amd -- MI355X-native sparse regrid engine (drop-in for the
+apply path of jhardenberg/smmregrid: Regridder(...).regrid(), CdoGenerate)."""
+from .regrid import Regridder, regrid
+from .cdogenerate import CdoGenerate, cdo_generate_weights
+from .gridtype import GridType
+from .operator import SparseOperator, OperatorGroup
+from .device import DeviceArray, to_device
+from .xrlite import DataArray, Dataset
+
+__version__ = '0.1.0'
+
+__all__ = ["Regridder", "regrid", "CdoGenerate", "cdo_generate_weights", "GridType",
+           "SparseOperator", "OperatorGroup", "DeviceArray", "to_device", "DataArray", "Dataset"]

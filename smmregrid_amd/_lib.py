@@ -1,0 +1,145 @@
+"""ctypes binding of libsmmregrid_hip.so (C ABI in include/smmregrid_amd.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is
+present every compute call raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmmregrid_hip.so")
+
+SMM_OK = 0
+SMM_ERR_INVALID = 1
+SMM_ERR_NO_DEVICE = 2
+SMM_ERR_HIP = 3
+SMM_ERR_ALLOC = 4
+SMM_ERR_UNSUPPORTED = 5
+
+SMM_F32 = 0
+SMM_F64 = 1
+
+APPLY_MASKED = 1 << 0
+APPLY_NO_FILL = 1 << 1
+APPLY_KERNEL_SELL = 1 << 8
+APPLY_KERNEL_TILE = 1 << 9
+
+
+class SmmError(RuntimeError):
+    """A libsmmregrid_hip call failed (status code in .code)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libsmmregrid_hip error {code}: {message}")
+        self.code = code
+
+
+class SmmNoDeviceError(SmmError):
+    """No usable HIP device: the HIP path is mandatory, nothing falls back to the CPU."""
+
+
+_i64 = ctypes.c_int64
+_p = ctypes.c_void_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+_uint = ctypes.c_uint
+_size = ctypes.c_size_t
+
+# name -> argtypes; every entry point returns int status except the two noted
+SIGNATURES = {
+    "smm_device_count": [ctypes.POINTER(_int)],
+    "smm_set_device": [_int],
+    "smm_get_device": [ctypes.POINTER(_int)],
+    "smm_device_name": [_int, ctypes.c_char_p, _size],
+    "smm_mem_info": [ctypes.POINTER(_size), ctypes.POINTER(_size)],
+    "smm_malloc": [_pp, _size],
+    "smm_free": [_p],
+    "smm_host_alloc": [_pp, _size],
+    "smm_host_free": [_p],
+    "smm_memcpy_h2d": [_p, _p, _size, _p],
+    "smm_memcpy_d2h": [_p, _p, _size, _p],
+    "smm_memcpy_d2d": [_p, _p, _size, _p],
+    "smm_memset": [_p, _int, _size, _p],
+    "smm_stream_create": [_pp],
+    "smm_stream_destroy": [_p],
+    "smm_stream_sync": [_p],
+    "smm_device_sync": [],
+    "smm_event_create": [_pp],
+    "smm_event_destroy": [_p],
+    "smm_event_record": [_p, _p],
+    "smm_event_sync": [_p],
+    "smm_event_elapsed_ms": [_p, _p, ctypes.POINTER(ctypes.c_float)],
+    "smm_fill_random": [_p, _int, _i64, ctypes.c_uint64, _dbl, _dbl, _p],
+    "smm_operator_create": [_i64, _i64, _i64, _p, _p, _p, _int, _pp],
+    "smm_operator_destroy": [_p],
+    "smm_operator_info": [_p] + [ctypes.POINTER(_i64)] * 5,
+    "smm_operator_export_csr": [_p, _p, _p, _p],
+    "smm_operator_set_epilogue": [_p, _p, _p],
+    "smm_operator_mask_apply": [_p, _p, _p],
+    "smm_operator_plan_info": [_p, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "smm_group_create": [_pp, _int, _pp],
+    "smm_group_destroy": [_p],
+    "smm_apply": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _p],
+    "smm_group_apply": [_p, _p, _int, _i64, _i64, _i64, _p, _int, _i64, _i64, _i64,
+                        _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
+}
+SPECIAL = {"smm_abi_version": (_int, []), "smm_last_error": (ctypes.c_char_p, [])}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the shared library in-tree with hipcc for gfx950."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once) and declare every prototype.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmmError(SMM_ERR_UNSUPPORTED,
+                       f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C smmregrid_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _int
+        fn.argtypes = argtypes
+    for name, (restype, argtypes) in SPECIAL.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status == SMM_OK:
+        return
+    msg = load().smm_last_error()
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    if status == SMM_ERR_NO_DEVICE:
+        raise SmmNoDeviceError(status, msg)
+    raise SmmError(status, msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def device_count():
+    """Number of HIP devices; 0 when none (never raises for 'no device')."""
+    n = _int(0)
+    status = load().smm_device_count(ctypes.byref(n))
+    if status == SMM_ERR_NO_DEVICE:
+        return 0
+    check(status)
+    return n.value

@@ -1,0 +1,172 @@
+// Host-side operator construction (K6 of SURVEY.md section 2): SCRIP links ->
+// canonical CSR -> SELL-64 device layout and the LDS source-tile plan.
+//
+// Replaces what the reference gets from the sparse.COO constructor
+// (weights.py:31-42): 1-based addresses become 0-based, coordinates are sorted
+// and duplicate coordinates are summed.
+#include "smm_internal.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace smm {
+
+bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
+               const int32_t* dst1, const double* w, HostCsr& out, std::string& err) {
+  if (n_src < 0 || n_dst < 0 || nnz < 0) {
+    err = "negative size";
+    return false;
+  }
+  if (n_src > INT32_MAX || n_dst > INT32_MAX || nnz > INT32_MAX) {
+    err = "sizes beyond int32 addressing (SCRIP addresses are int32)";
+    return false;
+  }
+  if (nnz > 0 && (!src1 || !dst1 || !w)) {
+    err = "null link array";
+    return false;
+  }
+  for (int64_t k = 0; k < nnz; ++k) {
+    const int64_t s = (int64_t)src1[k] - 1, d = (int64_t)dst1[k] - 1;
+    if (s < 0 || s >= n_src) {
+      err = "src_address[" + std::to_string(k) + "]=" + std::to_string(src1[k]) +
+            " outside 1.." + std::to_string(n_src);
+      return false;
+    }
+    if (d < 0 || d >= n_dst) {
+      err = "dst_address[" + std::to_string(k) + "]=" + std::to_string(dst1[k]) +
+            " outside 1.." + std::to_string(n_dst);
+      return false;
+    }
+  }
+
+  // Two stable counting sorts (LSD): by src, then by dst -> order (dst, src, original k).
+  std::vector<int32_t> by_src((size_t)nnz), order((size_t)nnz);
+  {
+    std::vector<int64_t> pos((size_t)n_src + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) pos[(size_t)src1[k]]++;  // src1-1+1
+    for (int64_t s = 0; s < n_src; ++s) pos[(size_t)s + 1] += pos[(size_t)s];
+    for (int64_t k = 0; k < nnz; ++k) by_src[(size_t)pos[(size_t)src1[k] - 1]++] = (int32_t)k;
+  }
+  std::vector<int64_t> rawptr((size_t)n_dst + 1, 0);
+  {
+    for (int64_t k = 0; k < nnz; ++k) rawptr[(size_t)dst1[k]]++;
+    for (int64_t d = 0; d < n_dst; ++d) rawptr[(size_t)d + 1] += rawptr[(size_t)d];
+    std::vector<int64_t> pos(rawptr.begin(), rawptr.end() - 1);
+    for (int64_t i = 0; i < nnz; ++i) {
+      const int32_t k = by_src[(size_t)i];
+      order[(size_t)pos[(size_t)dst1[k] - 1]++] = k;
+    }
+  }
+  by_src.clear();
+  by_src.shrink_to_fit();
+
+  out.n_src = n_src;
+  out.n_dst = n_dst;
+  out.rowptr.assign((size_t)n_dst + 1, 0);
+  out.col.clear();
+  out.val.clear();
+  out.col.reserve((size_t)nnz);
+  out.val.reserve((size_t)nnz);
+  out.max_row_nnz = 0;
+  for (int64_t d = 0; d < n_dst; ++d) {
+    const int64_t row_start = (int64_t)out.col.size();
+    for (int64_t i = rawptr[(size_t)d]; i < rawptr[(size_t)d + 1]; ++i) {
+      const int32_t k = order[(size_t)i];
+      const int32_t s = src1[k] - 1;
+      if ((int64_t)out.col.size() > row_start && out.col.back() == s) {
+        out.val.back() += w[k];  // duplicate coordinate: summed in original link order
+      } else {
+        out.col.push_back(s);
+        out.val.push_back(w[k]);
+      }
+    }
+    out.rowptr[(size_t)d + 1] = (int64_t)out.col.size();
+    out.max_row_nnz = std::max(out.max_row_nnz, (int64_t)out.col.size() - row_start);
+  }
+  out.nnz = (int64_t)out.col.size();
+
+  std::vector<uint8_t> used((size_t)n_src, 0);
+  for (int32_t c : out.col) used[(size_t)c] = 1;
+  int64_t u = 0;
+  for (uint8_t b : used) u += b;
+  out.n_used_src = u;
+  return true;
+}
+
+void build_sell(const HostCsr& csr, HostSell& out) {
+  const int64_t n_slices = (csr.n_dst + 63) / 64;
+  out.n_slices = n_slices;
+  out.slice_off.assign((size_t)n_slices + 1, 0);
+  out.rowlen.assign((size_t)n_slices * 64, 0);
+  for (int64_t d = 0; d < csr.n_dst; ++d)
+    out.rowlen[(size_t)d] = (int32_t)(csr.rowptr[(size_t)d + 1] - csr.rowptr[(size_t)d]);
+  for (int64_t s = 0; s < n_slices; ++s) {
+    int32_t m = 0;
+    for (int r = 0; r < 64; ++r) m = std::max(m, out.rowlen[(size_t)s * 64 + r]);
+    out.slice_off[(size_t)s + 1] = out.slice_off[(size_t)s] + (int64_t)m * 64;
+  }
+  out.n_slots = out.slice_off[(size_t)n_slices];
+  out.col.assign((size_t)out.n_slots, 0);
+  out.val.assign((size_t)out.n_slots, 0.0);
+  for (int64_t d = 0; d < csr.n_dst; ++d) {
+    const int64_t s = d >> 6, r = d & 63;
+    const int64_t base = out.slice_off[(size_t)s] + r;
+    const int64_t p0 = csr.rowptr[(size_t)d];
+    const int32_t len = out.rowlen[(size_t)d];
+    for (int32_t k = 0; k < len; ++k) {
+      out.col[(size_t)(base + (int64_t)k * 64)] = csr.col[(size_t)(p0 + k)];
+      out.val[(size_t)(base + (int64_t)k * 64)] = csr.val[(size_t)(p0 + k)];
+    }
+  }
+}
+
+void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_per_block,
+                     int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan) {
+  plan = HostTilePlan();
+  plan.slices_per_block = slices_per_block;
+  plan.chunk_elems = chunk_elems;
+  if (csr.n_dst == 0 || slices_per_block <= 0 || chunk_elems <= 0) return;
+  const int64_t rows_per_block = (int64_t)slices_per_block * 64;
+  const int64_t n_blocks = (csr.n_dst + rows_per_block - 1) / rows_per_block;
+  plan.n_blocks = n_blocks;
+  plan.blk_chunk_off.assign((size_t)n_blocks + 1, 0);
+  plan.lcol.assign((size_t)sell.n_slots, 0);
+
+  std::vector<int32_t> chunks;
+  for (int64_t b = 0; b < n_blocks; ++b) {
+    const int64_t d0 = b * rows_per_block;
+    const int64_t d1 = std::min(csr.n_dst, d0 + rows_per_block);
+    chunks.clear();
+    for (int64_t p = csr.rowptr[(size_t)d0]; p < csr.rowptr[(size_t)d1]; ++p)
+      chunks.push_back(csr.col[(size_t)p] / chunk_elems);
+    std::sort(chunks.begin(), chunks.end());
+    chunks.erase(std::unique(chunks.begin(), chunks.end()), chunks.end());
+    if ((int64_t)chunks.size() > max_chunks_per_block) {
+      plan.valid = false;
+      return;
+    }
+    plan.max_block_chunks = std::max(plan.max_block_chunks, (int64_t)chunks.size());
+    const int64_t base = (int64_t)plan.chunk_src.size();
+    plan.chunk_src.insert(plan.chunk_src.end(), chunks.begin(), chunks.end());
+    plan.blk_chunk_off[(size_t)b + 1] = base + (int64_t)chunks.size();
+    // LDS-local column of every link of the block
+    for (int64_t d = d0; d < d1; ++d) {
+      const int64_t s = d >> 6, r = d & 63;
+      const int64_t sbase = sell.slice_off[(size_t)s] + r;
+      const int64_t p0 = csr.rowptr[(size_t)d];
+      const int32_t len = sell.rowlen[(size_t)d];
+      for (int32_t k = 0; k < len; ++k) {
+        const int32_t c = csr.col[(size_t)(p0 + k)];
+        const int32_t ch = c / chunk_elems;
+        const int64_t li =
+            std::lower_bound(chunks.begin(), chunks.end(), ch) - chunks.begin();
+        plan.lcol[(size_t)(sbase + (int64_t)k * 64)] =
+            (int32_t)(li * chunk_elems + (c - ch * chunk_elems));
+      }
+    }
+  }
+  plan.total_chunks = (int64_t)plan.chunk_src.size();
+  plan.valid = true;
+}
+
+}  // namespace smm

@@ -1,0 +1,65 @@
+// Internal structures shared by the host builder (smm_build.cpp) and the
+// device side (smm_device.hip).  Not part of the ABI.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace smm {
+
+// Canonical CSR: row = destination cell, columns ascending, duplicates summed.
+// This is the structure scipy's coo_matrix((w,(dst,src))).tocsr() +
+// sum_duplicates() + sort_indices() yields, and what the reference's
+// sparse.COO([src,dst], w) holds after its constructor sorted the coords
+// (weights.py:37-39).
+struct HostCsr {
+  int64_t n_src = 0, n_dst = 0, nnz = 0;
+  int64_t n_used_src = 0;   // distinct source cells carrying >= 1 link (U of SURVEY 8d)
+  int64_t max_row_nnz = 0;
+  std::vector<int64_t> rowptr;  // n_dst + 1
+  std::vector<int32_t> col;     // nnz
+  std::vector<double> val;      // nnz
+};
+
+// SELL-64: destination rows in slices of 64 consecutive rows (= one wavefront);
+// inside a slice the links are stored slot-major (slot k of lane r at
+// off + k*64 + r) and padded to the longest row of the slice, so a wave reads
+// col/val with one coalesced 256-B / 512-B access per slot.
+struct HostSell {
+  int64_t n_slices = 0;
+  int64_t n_slots = 0;              // total padded slots (multiple of 64)
+  std::vector<int64_t> slice_off;   // n_slices + 1, element offsets (multiples of 64)
+  std::vector<int32_t> rowlen;      // n_slices * 64 (rows past n_dst have length 0)
+  std::vector<int32_t> col;         // n_slots (padding: 0)
+  std::vector<double> val;          // n_slots (padding: 0.0)
+};
+
+// Returns false and fills err on invalid input.
+bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
+               const int32_t* dst1, const double* w, HostCsr& out, std::string& err);
+void build_sell(const HostCsr& csr, HostSell& out);
+
+// Source-tile plan for the LDS-staged kernel.  Destination rows are grouped in
+// blocks of `slices_per_block` SELL slices; the distinct source cells a block
+// references are covered by aligned chunks of `chunk_elems` source elements
+// (one chunk = one 128-B line of f64).  The kernel copies a block's chunks to
+// LDS in list order with 16-B-per-lane coalesced loads, so LDS element
+// (c*chunk_elems + e) holds source element chunk_src[c]*chunk_elems + e, and
+// the block's links address LDS through lcol.
+struct HostTilePlan {
+  bool valid = false;
+  int32_t slices_per_block = 0;
+  int32_t chunk_elems = 0;
+  int64_t n_blocks = 0;
+  int64_t max_block_chunks = 0;       // largest chunk count of any block
+  int64_t total_chunks = 0;           // sum over blocks = staged lines per batch row
+  std::vector<int64_t> blk_chunk_off; // n_blocks + 1 -> index into chunk_src
+  std::vector<int32_t> chunk_src;     // source chunk index (element = idx * chunk_elems)
+  std::vector<int32_t> lcol;          // per SELL slot: LDS element index (layout of HostSell.col)
+};
+// Leaves plan.valid == false when a block needs more than max_chunks_per_block chunks.
+void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_per_block,
+                     int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan);
+
+}  // namespace smm

@@ -1,0 +1,215 @@
+"""HBM buffers, streams and events over the C ABI (no torch, no cupy)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_DTYPE_CODE = {np.dtype(np.float32): _lib.SMM_F32, np.dtype(np.float64): _lib.SMM_F64}
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPE_CODE[np.dtype(dtype)]
+    except KeyError:
+        raise TypeError(f"field dtype {dtype} not supported on device (float32/float64 only)")
+
+
+def device_count():
+    return _lib.device_count()
+
+
+def set_device(device):
+    _lib.call("smm_set_device", int(device))
+
+
+def current_device():
+    d = ctypes.c_int(0)
+    _lib.call("smm_get_device", ctypes.byref(d))
+    return d.value
+
+
+def device_name(device=0):
+    buf = ctypes.create_string_buffer(256)
+    _lib.call("smm_device_name", int(device), buf, 256)
+    return buf.value.decode()
+
+
+def mem_info():
+    f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    _lib.call("smm_mem_info", ctypes.byref(f), ctypes.byref(t))
+    return f.value, t.value
+
+
+def synchronize():
+    _lib.call("smm_device_sync")
+
+
+class Stream:
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _lib.call("smm_stream_create", ctypes.byref(h))
+        self.handle = h
+
+    def synchronize(self):
+        _lib.call("smm_stream_sync", self.handle)
+
+    def close(self):
+        if self.handle:
+            _lib.call("smm_stream_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _stream_handle(stream):
+    if stream is None:
+        return None
+    return stream.handle if isinstance(stream, Stream) else stream
+
+
+class Event:
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _lib.call("smm_event_create", ctypes.byref(h))
+        self.handle = h
+
+    def record(self, stream=None):
+        _lib.call("smm_event_record", self.handle, _stream_handle(stream))
+
+    def synchronize(self):
+        _lib.call("smm_event_sync", self.handle)
+
+    def elapsed_ms(self, stop):
+        ms = ctypes.c_float(0)
+        _lib.call("smm_event_elapsed_ms", self.handle, stop.handle, ctypes.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.call("smm_event_destroy", self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class DeviceArray:
+    """A C-contiguous array resident in HBM.  Owns its allocation unless it is a view."""
+
+    def __init__(self, shape, dtype, ptr=None, base=None):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape)) if not isinstance(shape, tuple) \
+            else tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.base = base
+        if ptr is None:
+            h = ctypes.c_void_p()
+            _lib.call("smm_malloc", ctypes.byref(h), self.nbytes)
+            self.ptr = h.value or 0
+            self._owned = True
+        else:
+            self.ptr = int(ptr)
+            self._owned = False
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        shape = list(shape)
+        if -1 in shape:
+            i = shape.index(-1)
+            known = 1
+            for k, s in enumerate(shape):
+                if k != i:
+                    known *= s
+            shape[i] = self.size // known if known else 0
+        out = DeviceArray(tuple(shape), self.dtype, ptr=self.ptr, base=self.base or self)
+        if out.size != self.size:
+            raise ValueError(f"cannot reshape {self.shape} into {tuple(shape)}")
+        return out
+
+    def rows(self, start, stop):
+        """View of rows [start, stop) along the first axis."""
+        start, stop = int(start), int(stop)
+        if not 0 <= start <= stop <= self.shape[0]:
+            raise IndexError("row range out of bounds")
+        row = self.size // self.shape[0] if self.shape[0] else 0
+        return DeviceArray((stop - start,) + self.shape[1:], self.dtype,
+                           ptr=self.ptr + start * row * self.dtype.itemsize, base=self.base or self)
+
+    def copy_from_host(self, host, stream=None):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        if host.size != self.size:
+            raise ValueError("size mismatch in copy_from_host")
+        _lib.call("smm_memcpy_h2d", ctypes.c_void_p(self.ptr), host.ctypes.data_as(ctypes.c_void_p),
+                  self.nbytes, _stream_handle(stream))
+        return self
+
+    def to_host(self, out=None, stream=None):
+        if out is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes != self.nbytes or not out.flags.c_contiguous:
+            raise ValueError("to_host needs a C-contiguous buffer of the same size")
+        _lib.call("smm_memcpy_d2h", out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.ptr),
+                  self.nbytes, _stream_handle(stream))
+        if stream is not None:
+            _lib.call("smm_stream_sync", _stream_handle(stream))
+        return out
+
+    def fill_bytes(self, value=0, stream=None):
+        _lib.call("smm_memset", ctypes.c_void_p(self.ptr), int(value), self.nbytes,
+                  _stream_handle(stream))
+        return self
+
+    def fill_random(self, seed, mean=0.0, sigma=1.0, stream=None):
+        """Counter-based pseudo-normal fill on the device (benchmarks, full-size tests)."""
+        _lib.call("smm_fill_random", ctypes.c_void_p(self.ptr), dtype_code(self.dtype), self.size,
+                  ctypes.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), float(mean), float(sigma),
+                  _stream_handle(stream))
+        return self
+
+    def free(self):
+        if self._owned and self.ptr:
+            _lib.call("smm_free", ctypes.c_void_p(self.ptr))
+        self.ptr = 0
+        self._owned = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.dtype}, ptr=0x{self.ptr:x})"
+
+
+def to_device(host, dtype=None, stream=None):
+    host = np.asarray(host)
+    if dtype is None:
+        dtype = host.dtype
+    return DeviceArray(host.shape, dtype).copy_from_host(host, stream=stream)
+
+
+def empty(shape, dtype=np.float64):
+    if not isinstance(shape, tuple):
+        shape = tuple(np.atleast_1d(shape).tolist())
+    return DeviceArray(shape, dtype)

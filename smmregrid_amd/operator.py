@@ -1,0 +1,186 @@
+"""Sparse regrid operators resident in HBM.
+
+`SparseOperator` stands where the reference keeps a lazy
+``dask.array`` of one ``sparse.COO`` of shape (S, D) (weights.py:37-42);
+`OperatorGroup` stands where it keeps the per-level Python list
+(weights.py:18-23).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, dtype_code, _stream_handle, current_device
+
+
+def _cptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class SparseOperator:
+    """(S x D) weights matrix in HBM, built from SCRIP links (weights.py:25-44)."""
+
+    def __init__(self, n_src, n_dst, src_address, dst_address, remap_matrix, device=None):
+        src = np.ascontiguousarray(src_address, dtype=np.int32).ravel()
+        dst = np.ascontiguousarray(dst_address, dtype=np.int32).ravel()
+        w = np.asarray(remap_matrix, dtype=np.float64)
+        if w.ndim == 2:
+            w = w[:, 0]          # only the first weight column is used (weights.py:33)
+        w = np.ascontiguousarray(w).ravel()
+        if not (src.size == dst.size == w.size):
+            raise ValueError("src_address, dst_address and remap_matrix differ in length")
+        if device is None:
+            device = current_device()
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        _lib.call("smm_operator_create", int(n_src), int(n_dst), int(src.size), _cptr(src),
+                  _cptr(dst), _cptr(w), self.device, ctypes.byref(h))
+        self.handle = h
+        vals = [ctypes.c_int64(0) for _ in range(5)]
+        _lib.call("smm_operator_info", self.handle, *[ctypes.byref(v) for v in vals])
+        self.n_src, self.n_dst, self.nnz, self.n_used_src, self.max_row_nnz = [v.value for v in vals]
+        self.has_imask = False
+        self.has_frac = False
+
+    # the reference's matrix is (S, D): keep .shape for code that inspects it
+    @property
+    def shape(self):
+        return (self.n_src, self.n_dst)
+
+    def set_epilogue(self, dst_imask=None, dst_frac=None):
+        """dst_grid_imask / dst_grid_frac of the weights file (regrid.py:509-510)."""
+        im = None if dst_imask is None else np.ascontiguousarray(dst_imask, dtype=np.int32).ravel()
+        fr = None if dst_frac is None else np.ascontiguousarray(dst_frac, dtype=np.float64).ravel()
+        for a, name in ((im, "dst_imask"), (fr, "dst_frac")):
+            if a is not None and a.size != self.n_dst:
+                raise ValueError(f"{name} has {a.size} entries, expected {self.n_dst}")
+        _lib.call("smm_operator_set_epilogue", self.handle, _cptr(im), _cptr(fr))
+        self.has_imask = im is not None
+        self.has_frac = fr is not None
+        return self
+
+    def export_csr(self):
+        """(rowptr int64[D+1], col int32[nnz], val float64[nnz]) -- the canonical CSR."""
+        rowptr = np.zeros(self.n_dst + 1, dtype=np.int64)
+        col = np.zeros(self.nnz, dtype=np.int32)
+        val = np.zeros(self.nnz, dtype=np.float64)
+        _lib.call("smm_operator_export_csr", self.handle, _cptr(rowptr), _cptr(col), _cptr(val))
+        return rowptr, col, val
+
+    def plan_info(self):
+        kind = ctypes.c_int(0)
+        lds = ctypes.c_int64(0)
+        staged = ctypes.c_int64(0)
+        _lib.call("smm_operator_plan_info", self.handle, ctypes.byref(kind), ctypes.byref(lds),
+                  ctypes.byref(staged))
+        return {"tile_plan": bool(kind.value), "lds_bytes": lds.value,
+                "staged_src_elems": staged.value}
+
+    def mask_apply(self, src_imask):
+        """weights.py:47-52 on the device: (src_imask . W) < 0.5 ? 0 : 1."""
+        src = np.ascontiguousarray(src_imask, dtype=np.int32).ravel()
+        if src.size != self.n_src:
+            raise ValueError(f"src_imask has {src.size} entries, expected {self.n_src}")
+        out = np.empty(self.n_dst, dtype=np.int32)
+        _lib.call("smm_operator_mask_apply", self.handle, _cptr(src), _cptr(out))
+        return out
+
+    def apply(self, x, y=None, masked=False, remap_area_min=0.0, out_dtype=np.float64,
+              flags=0, stream=None):
+        """Y = epilogue(fill(X) . W) for a device-resident X of shape (B, S)."""
+        if not isinstance(x, DeviceArray):
+            raise TypeError("SparseOperator.apply takes a DeviceArray (use Regridder for host data)")
+        if x.ndim != 2 or x.shape[1] != self.n_src:
+            raise ValueError(f"X must be (B, {self.n_src}), got {x.shape}")
+        n_batch = x.shape[0]
+        if y is None:
+            y = DeviceArray((n_batch, self.n_dst), out_dtype)
+        elif y.shape != (n_batch, self.n_dst):
+            raise ValueError(f"Y must be ({n_batch}, {self.n_dst}), got {y.shape}")
+        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
+        _lib.call("smm_apply", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype),
+                  self.n_src, ctypes.c_void_p(y.ptr), dtype_code(y.dtype), self.n_dst, n_batch,
+                  float(remap_area_min), fl, _stream_handle(stream))
+        return y
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.call("smm_operator_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return (f"SparseOperator(S={self.n_src}, D={self.n_dst}, nnz={self.nnz}, "
+                f"device={self.device})")
+
+
+class OperatorGroup:
+    """Ordered per-level operators applied in one launch (regrid.py:387-418)."""
+
+    def __init__(self, operators):
+        self.operators = list(operators)
+        if not self.operators:
+            raise ValueError("OperatorGroup needs at least one operator")
+        arr = (ctypes.c_void_p * len(self.operators))(*[op.handle for op in self.operators])
+        h = ctypes.c_void_p()
+        _lib.call("smm_group_create", arr, len(self.operators), ctypes.byref(h))
+        self.handle = h
+        self.n_src = self.operators[0].n_src
+        self.n_dst = self.operators[0].n_dst
+
+    def __len__(self):
+        return len(self.operators)
+
+    def __getitem__(self, i):
+        return self.operators[i]
+
+    def apply(self, x, level_index, masked_levels=None, y=None, masked=False, remap_area_min=0.0,
+              transpose=True, out_dtype=np.float64, flags=0, stream=None):
+        """x: DeviceArray (n_outer, n_lev, n_inner, S).  Returns
+        (n_outer, n_inner, n_lev, D) when transpose (regrid.py:420-427) else
+        (n_lev, n_outer, n_inner, D) (the concat order, regrid.py:410)."""
+        if not isinstance(x, DeviceArray) or x.ndim != 4 or x.shape[3] != self.n_src:
+            raise ValueError(f"X must be a DeviceArray (n_outer, n_lev, n_inner, {self.n_src})")
+        n_outer, n_lev, n_inner, S = x.shape
+        D = self.n_dst
+        lev = np.ascontiguousarray(level_index, dtype=np.int32).ravel()
+        if lev.size != n_lev:
+            raise ValueError("level_index must have one entry per data level")
+        ml = None
+        if masked_levels is not None:
+            ml = np.ascontiguousarray(masked_levels, dtype=np.uint8).ravel()
+            if ml.size != len(self.operators):
+                raise ValueError("masked_levels must have one entry per group member")
+        if transpose:
+            shape = (n_outer, n_inner, n_lev, D)
+            ys = (n_inner * n_lev * D, D, n_lev * D)          # (outer, lev, inner) strides
+        else:
+            shape = (n_lev, n_outer, n_inner, D)
+            ys = (n_inner * D, n_outer * n_inner * D, D)
+        if y is None:
+            y = DeviceArray(shape, out_dtype)
+        elif y.shape != shape:
+            raise ValueError(f"Y must be {shape}, got {y.shape}")
+        xs = (n_lev * n_inner * S, n_inner * S, S)
+        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
+        _lib.call("smm_group_apply", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype),
+                  xs[0], xs[1], xs[2], ctypes.c_void_p(y.ptr), dtype_code(y.dtype),
+                  ys[0], ys[1], ys[2], n_outer, n_lev, n_inner, _cptr(lev), _cptr(ml),
+                  float(remap_area_min), fl, _stream_handle(stream))
+        return y
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.call("smm_group_destroy", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,393 @@
+"""Regridder facade -- drop-in for smmregrid.regrid.Regridder on the apply path.
+
+Same constructor keywords, methods and exceptions as the reference
+(regrid.py:55-59, :233, :273, :339, :429, :458, :656); the arithmetic that the
+reference hands to dask/sparse (regrid.py:545-570) runs in the HIP library.
+Inputs may be xarray objects (when xarray is importable) or the lite
+containers of `smmregrid_amd.xrlite`; the result has the type of the input.
+A field whose ``data`` is a `DeviceArray` stays in HBM (no host copies).
+
+Unlike the reference the result is eager (numpy- or HBM-backed), not a lazy
+dask graph.
+"""
+import logging
+import math
+import os
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, empty, mem_info, to_device
+from .gridtype import GridType, tolist
+from .operator import OperatorGroup
+from .weights import (_level_slice, check_mask, compute_weights_matrix, compute_weights_matrix3d,
+                      mask_weights)
+from .xrlite import DataArray, Dataset, from_xarray, is_xarray, to_xarray
+
+DEFAULT_AREA_MIN = 0.5  # default minimum area for conservative remapping (regrid.py:49)
+
+
+def _logger(level):
+    log = logging.getLogger("smmregrid.Regrid")
+    log.setLevel(getattr(logging, str(level).upper(), logging.WARNING))
+    return log
+
+
+def _remove_degenerate_axes(a):
+    """dimension.py:22-37 of the reference: collapse axes along which a 2-D
+    coordinate array does not vary."""
+    a = np.asarray(a)
+    if a.ndim != 2:
+        return a
+    if (a == a[0:1, :]).all():
+        return a[0, :]
+    if (a == a[:, 0:1]).all():
+        return a[:, 0]
+    return a
+
+
+class Regridder(object):
+    """Main regridding class (reference: regrid.py:52)."""
+
+    def __init__(self, source_grid=None, target_grid=None, weights=None,
+                 method='con', remap_area_min=DEFAULT_AREA_MIN, transpose=True, mask_dim=None,
+                 vertical_dim=None, horizontal_dims=None, cdo_extra=None, cdo_options=None,
+                 check_nan=False, cdo='cdo', loglevel='WARNING', device=None):
+        if (source_grid is None or target_grid is None) and (weights is None):
+            raise ValueError("Either weights or source_grid/target_grid must be supplied")
+
+        if vertical_dim is not None:  # deprecated_argument (util.py:23-40)
+            import warnings
+            warnings.warn("'vertical_dim' is deprecated, use 'mask_dim'", DeprecationWarning)
+            if mask_dim is None:
+                mask_dim = vertical_dim
+
+        self.loggy = _logger(loglevel)
+        self.loglevel = loglevel
+        self.transpose = transpose
+        self.device = device
+        mask_dim = tolist(mask_dim)
+        horizontal_dims = tolist(horizontal_dims)
+        self.extra_dims = {'mask': mask_dim, 'horizontal': horizontal_dims}
+
+        self.remap_area_min = float(remap_area_min)
+        if self.remap_area_min < 0.0 or self.remap_area_min > 1.0:
+            raise ValueError('The remap_area_min provided must be between 0.0 and 1.0')
+
+        if weights is not None:
+            self.init_mode = 'weights'
+            self.grids = self._gridtype_from_weights(weights)
+        else:
+            self.init_mode = 'grids'
+            from .cdogenerate import CdoGenerate
+            if isinstance(source_grid, str) and os.path.sep in source_grid \
+                    and not os.path.isfile(source_grid):
+                raise FileNotFoundError(f'Cannot find grid file {source_grid}')
+            source_grid_array = from_xarray(source_grid)
+            self.grids = self._gridtype_from_data(source_grid_array)
+            if len(self.grids) == 0:
+                raise ValueError('Cannot find any gridtype in your data, aborting!')
+            for gridtype in self.grids:
+                generator = CdoGenerate(source_grid_array, target_grid, cdo=cdo,
+                                        cdo_options=cdo_options, cdo_extra=cdo_extra,
+                                        loglevel=loglevel)
+                gridtype.weights = generator.weights(method=method, mask_dim=gridtype.mask_dim)
+
+        for gridtype in self.grids:
+            self._setup_operators(gridtype)
+
+    # ------------------------------------------------------------------ init helpers
+    def _setup_operators(self, gridtype):
+        """regrid.py:189-203: operators, destination mask, `masked` flags; then the
+        epilogue vectors are placed next to the operators in HBM."""
+        w = gridtype.weights
+        if gridtype.mask_dim:
+            gridtype.weights_matrix = compute_weights_matrix3d(w, gridtype.mask_dim,
+                                                               device=self.device)
+        else:
+            gridtype.weights_matrix = compute_weights_matrix(w, device=self.device)
+
+        if "dst_grid_masked" in w.variables:
+            gridtype.masked = np.asarray(w["dst_grid_masked"].values)
+            if gridtype.masked.ndim == 0:
+                gridtype.masked = bool(gridtype.masked)
+        else:
+            gridtype.weights = mask_weights(w, gridtype.weights_matrix, gridtype.mask_dim)
+            gridtype.masked = check_mask(gridtype.weights, gridtype.mask_dim)
+        w = gridtype.weights
+
+        if gridtype.mask_dim:
+            for i, op in enumerate(gridtype.weights_matrix):
+                op.set_epilogue(_level_slice(w["dst_grid_imask"], gridtype.mask_dim, i),
+                                _level_slice(w["dst_grid_frac"], gridtype.mask_dim, i)
+                                if "dst_grid_frac" in w else None)
+            gridtype.group = OperatorGroup(gridtype.weights_matrix)
+        else:
+            gridtype.weights_matrix.set_epilogue(
+                w["dst_grid_imask"].values,
+                w["dst_grid_frac"].values if "dst_grid_frac" in w else None)
+
+    def _gridtype_from_weights(self, weights):
+        """regrid.py:205-223 + gridinspector.py:79-92."""
+        if isinstance(weights, str):
+            from .io import open_weights
+            weights = open_weights(weights)
+        weights = from_xarray(weights)
+        if not isinstance(weights, Dataset):
+            raise TypeError('weights must be a Dataset or a path to a weights file')
+        gridtype = GridType(dims=[], weights=weights)
+        if weights.coords:
+            gridtype.mask_dim = list(weights.coords)[0]
+        self.extra_dims['mask'] = [gridtype.mask_dim]
+        return [gridtype]
+
+    def _gridtype_from_data(self, data):
+        grids = []
+        arrays = data.data_vars.values() if isinstance(data, Dataset) else [data]
+        for arr in arrays:
+            if not isinstance(arr, DataArray):
+                continue
+            name = arr.name or ''
+            if any(s in name for s in ("bnds", "bounds", "vertices")):
+                continue
+            gt = GridType(dims=arr.dims, extra_dims=self.extra_dims)
+            if gt.horizontal_dims and gt not in grids:
+                grids.append(gt)
+        return grids
+
+    # ------------------------------------------------------------------ public API
+    def regrid(self, source_data):
+        """regrid.py:233-271."""
+        was_xarray = is_xarray(source_data)
+        data = from_xarray(source_data)
+        if isinstance(data, Dataset):
+            datagrids = self._gridtype_from_data(data)
+            if len(datagrids) > 1 and self.init_mode == 'weights':
+                raise ValueError(
+                    f'Cannot process data with {len(datagrids)} GridType initializing from weights')
+            out = data.map(self.regrid_array, keep_attrs=True)
+            degen = [k for k, v in out.data_vars.items() if v.dims == ()]
+            out = out.drop_vars(degen)
+            return to_xarray(out) if was_xarray else out
+        if isinstance(data, DataArray):
+            out = self.regrid_array(data)
+            return to_xarray(out) if was_xarray else out
+        raise TypeError('The object provided is not a Xarray object!')
+
+    def regrid_array(self, source_data):
+        """regrid.py:273-312."""
+        source_data = from_xarray(source_data)
+        datagridtype = GridType(dims=source_data.dims, extra_dims=self.extra_dims)
+        if datagridtype.mask_dim:
+            return self.regrid3d(source_data, datagridtype)
+        return self.regrid2d(source_data, datagridtype)
+
+    def _get_gridtype(self, datagridtype):
+        """regrid.py:324-337."""
+        if self.init_mode == 'weights':
+            self.grids[0].dims = datagridtype.dims
+            self.grids[0].horizontal_dims = datagridtype.horizontal_dims
+            self.grids[0].other_dims = datagridtype.other_dims
+        return next((grid for grid in self.grids if grid == datagridtype), None)
+
+    def regrid2d(self, source_data, datagridtype):
+        """regrid.py:429-456."""
+        gridtype = self._get_gridtype(datagridtype)
+        if gridtype is None:
+            return DataArray(data=None)
+        return self.apply_weights(source_data, gridtype.weights,
+                                  weights_matrix=gridtype.weights_matrix,
+                                  masked=gridtype.masked,
+                                  horizontal_dims=gridtype.horizontal_dims)
+
+    # ------------------------------------------------------------------ apply (2-D)
+    def _target_layout(self, weights):
+        """regrid.py:572-579: target shape/dims from dst_grid_dims."""
+        dst_grid_shape = np.asarray(weights["dst_grid_dims"].values).astype(np.int64)
+        rank = dst_grid_shape.size
+        if rank == 2:
+            return [int(dst_grid_shape[1]), int(dst_grid_shape[0])], ["i", "j"]
+        if rank == 1:
+            return [int(dst_grid_shape[0])], ['cell']
+        raise ValueError('Unknown dimensional target grid')
+
+    def _finish(self, data, dims, source_data, kept_dims, weights, tgt_shape, tgt_dims):
+        """regrid.py:586-626: coordinates, lat/lon in degrees, attrs."""
+        coords = {k: v for k, v in source_data.coords.items() if set(v.dims).issubset(kept_dims)}
+        axis_scale = 180.0 / math.pi
+        lat = _remove_degenerate_axes(
+            np.asarray(weights["dst_grid_center_lat"].values).reshape(tgt_shape))
+        lon = _remove_degenerate_axes(
+            np.asarray(weights["dst_grid_center_lon"].values).reshape(tgt_shape))
+        lat = np.round(lat * axis_scale, 10)
+        lon = np.round(lon * axis_scale, 10)
+        dims = list(dims)
+        if tgt_dims == ["i", "j"] and lat.ndim == 1 and lon.ndim == 1:
+            dims = [{"i": "lat", "j": "lon"}.get(d, d) for d in dims]
+            lat_dims, lon_dims = ("lat",), ("lon",)
+        else:
+            lat_dims = lon_dims = tuple(tgt_dims) if lat.ndim == len(tgt_dims) else (tgt_dims[0],)
+        out = DataArray(data, dims=dims, coords=coords, attrs=dict(source_data.attrs),
+                        name=source_data.name)
+        out.coords["lat"] = DataArray(lat, dims=lat_dims, name="lat", attrs={
+            "units": "degrees_north", "standard_name": "latitude", "axis": "Y"})
+        out.coords["lon"] = DataArray(lon, dims=lon_dims, name="lon", attrs={
+            "units": "degrees_east", "standard_name": "longitude", "axis": "X"})
+        out.attrs.pop('CDI_grid_type', None)
+        return out
+
+    @staticmethod
+    def _batch_rows(n_rows, row_bytes):
+        """Rows per pass so that X and Y chunks fit comfortably in free HBM."""
+        free, _ = mem_info()
+        budget = max(int(free * 0.6), 64 << 20)
+        return max(1, min(n_rows, budget // max(row_bytes, 1)))
+
+    def apply_weights(self, source_data, weights, weights_matrix=None, masked=True,
+                      horizontal_dims=None):
+        """regrid.py:458-628 for one 2-D operator."""
+        source_data = from_xarray(source_data)
+        weights = from_xarray(weights)
+        name = source_data.name or ''
+        if any(s in name for s in ("bnds", "bounds", "vertices")):
+            if 'time' in name:
+                return source_data
+            return DataArray(data=None)
+
+        if not any(x in source_data.dims for x in (horizontal_dims or [])):
+            self.loggy.error("None of dimensions on which we can interpolate is found in the DataArray.")
+            raise KeyError('Dimensions mismatch')
+
+        kept_dims = [d for d in source_data.dims if d not in horizontal_dims]
+        kept_shape = [source_data.sizes[d] for d in kept_dims]
+        tgt_shape, tgt_dims = self._target_layout(weights)
+
+        if weights_matrix is None:
+            weights_matrix = compute_weights_matrix(weights, device=self.device)
+            weights_matrix.set_epilogue(
+                weights["dst_grid_imask"].values,
+                weights["dst_grid_frac"].values if "dst_grid_frac" in weights else None)
+        op = weights_matrix
+        n_batch = int(np.prod(kept_shape)) if kept_shape else 1
+        masked = bool(np.asarray(masked).any()) if np.ndim(masked) else bool(masked)
+
+        src = source_data.data
+        if isinstance(src, DeviceArray):
+            x = src.reshape(n_batch, -1)
+            if x.shape[1] != op.n_src:
+                raise ValueError(f"source grid has {x.shape[1]} cells, weights expect {op.n_src}")
+            y = op.apply(x, masked=masked, remap_area_min=self.remap_area_min)
+            out_data = y.reshape(*(kept_shape + tgt_shape))
+        else:
+            host = np.asarray(src)
+            if host.dtype not in (np.float32, np.float64):
+                host = host.astype(np.float64)  # result_type(x, f64), regrid.py:550
+            host = np.ascontiguousarray(host).reshape(n_batch, -1)
+            if host.shape[1] != op.n_src:
+                raise ValueError(f"source grid has {host.shape[1]} cells, weights expect {op.n_src}")
+            out = np.empty((n_batch, op.n_dst), dtype=np.float64)
+            step = self._batch_rows(n_batch, op.n_src * host.dtype.itemsize + op.n_dst * 8)
+            for r0 in range(0, n_batch, step):
+                r1 = min(n_batch, r0 + step)
+                x = to_device(host[r0:r1])
+                y = op.apply(x, masked=masked, remap_area_min=self.remap_area_min)
+                y.to_host(out[r0:r1])
+                x.free()
+                y.free()
+            out_data = out.reshape(kept_shape + tgt_shape)
+
+        return self._finish(out_data, kept_dims + tgt_dims, source_data, kept_dims, weights,
+                            tgt_shape, tgt_dims)
+
+    # ------------------------------------------------------------------ apply (masked levels)
+    def regrid3d(self, source_data, datagridtype):
+        """regrid.py:339-427 as one grouped launch: per data level the nearest
+        weights level (tolerance 1e-3) selects operator, mask and frac."""
+        source_data = from_xarray(source_data)
+        gridtype = self._get_gridtype(datagridtype)
+        if gridtype is None:
+            return DataArray(data=None)
+        mask_dim = gridtype.mask_dim
+        weights = gridtype.weights
+        horizontal_dims = gridtype.horizontal_dims
+        name = source_data.name or ''
+        if "bnds" in name or "bounds" in name:
+            return source_data
+        if not any(x in source_data.dims for x in (horizontal_dims or [])):
+            raise KeyError('Dimensions mismatch')
+
+        wlev = np.asarray(weights.coords[mask_dim].values, dtype=np.float64)
+        dlev = np.asarray(source_data.coords[mask_dim].values, dtype=np.float64)
+        level_index = np.empty(dlev.size, dtype=np.int32)
+        for idx, lev in enumerate(dlev):
+            widx = int(np.argmin(np.abs(wlev - lev)))
+            if not abs(wlev[widx] - lev) <= 1e-3:
+                raise ValueError(f"{lev} not found in mask_dim {mask_dim}. "
+                                 f"Available levels: {list(wlev)}")
+            level_index[idx] = widx
+
+        kept_dims = [d for d in source_data.dims if d not in horizontal_dims]
+        p = kept_dims.index(mask_dim)
+        outer_dims, inner_dims = kept_dims[:p], kept_dims[p + 1:]
+        n_outer = int(np.prod([source_data.sizes[d] for d in outer_dims])) if outer_dims else 1
+        n_inner = int(np.prod([source_data.sizes[d] for d in inner_dims])) if inner_dims else 1
+        n_lev = source_data.sizes[mask_dim]
+        rest_dims = outer_dims + inner_dims
+        rest_shape = [source_data.sizes[d] for d in rest_dims]
+        tgt_shape, tgt_dims = self._target_layout(weights)
+        group = gridtype.group
+        masked_levels = np.broadcast_to(np.asarray(gridtype.masked, dtype=bool),
+                                        (len(group),)).astype(np.uint8)
+        any_masked = bool(masked_levels.any())
+
+        if self.transpose:
+            out_dims = rest_dims + [mask_dim] + tgt_dims
+            out_shape = rest_shape + [n_lev] + tgt_shape
+        else:
+            out_dims = [mask_dim] + rest_dims + tgt_dims
+            out_shape = [n_lev] + rest_shape + tgt_shape
+
+        src = source_data.data
+        S, D = group.n_src, group.n_dst
+        if isinstance(src, DeviceArray):
+            x = src.reshape(n_outer, n_lev, n_inner, -1)
+            y = group.apply(x, level_index, masked_levels, masked=any_masked,
+                            remap_area_min=self.remap_area_min, transpose=self.transpose)
+            out_data = y.reshape(*out_shape)
+        else:
+            host = np.asarray(src)
+            if host.dtype not in (np.float32, np.float64):
+                host = host.astype(np.float64)
+            host = np.ascontiguousarray(host).reshape(n_outer, n_lev, n_inner, -1)
+            if host.shape[3] != S:
+                raise ValueError(f"source grid has {host.shape[3]} cells, weights expect {S}")
+            if self.transpose:
+                out = np.empty((n_outer, n_inner, n_lev, D), dtype=np.float64)
+            else:
+                out = np.empty((n_lev, n_outer, n_inner, D), dtype=np.float64)
+            row_bytes = n_lev * n_inner * (S * host.dtype.itemsize + D * 8)
+            step = self._batch_rows(n_outer, row_bytes)
+            for o0 in range(0, n_outer, step):
+                o1 = min(n_outer, o0 + step)
+                x = to_device(host[o0:o1])
+                y = group.apply(x, level_index, masked_levels, masked=any_masked,
+                                remap_area_min=self.remap_area_min, transpose=self.transpose)
+                yh = y.to_host()
+                if self.transpose:
+                    out[o0:o1] = yh
+                else:
+                    out[:, o0:o1] = yh
+                x.free()
+                y.free()
+            out_data = out.reshape(out_shape)
+
+        kept_for_coords = kept_dims
+        w2d = weights
+        return self._finish(out_data, out_dims, source_data, kept_for_coords, w2d, tgt_shape, tgt_dims)
+
+
+def regrid(source_data, target_grid=None, weights=None, transpose=True, cdo='cdo'):
+    """One-shot helper (regrid.py:656-677)."""
+    regridder = Regridder(source_data, target_grid=target_grid, weights=weights, cdo=cdo,
+                          transpose=transpose)
+    return regridder.regrid(source_data)
