@@ -46,12 +46,15 @@ def parse_args():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="override the batch rows per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "sell", "tile"])
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant knob (0 = default)")
+    ap.add_argument("--jpb", type=int, default=0, help="tile kernel: batch rows per workgroup")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
                     help="N>1: RCCL gather of the Y shards to rank 0 inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget")
-    ap.add_argument("--traffic-json", default=None,
-                    help="file with {'hbm_bytes_per_launch': ...} from a rocprofv3 --pmc run")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
+                    help="PMC-derived HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                         "passes, corrected per MI355X_MICROARCH.md), keyed by workload/batch/kernel")
     return ap.parse_args()
 
 
@@ -61,30 +64,34 @@ def algorithmic_bytes(op, n_batch, sx, sy):
 
 
 def cpu_baseline(weights, n_batch_full, x_dtype, budget_s):
-    """Oracle (C port of regrid.py:545-570, OpenMP over batch rows) on a bounded sample."""
+    """Oracle (C port of regrid.py:545-570, OpenMP over batch rows) on a bounded sample:
+    a fixed block of distinct batch rows of the same workload, passed repeatedly until
+    about `budget_s` seconds of CPU work have been timed."""
     from oracle import oracle
     n_src, n_dst = weights.sizes["src_grid_size"], weights.sizes["dst_grid_size"]
     csr = oracle.coo_to_csr_c(n_src, n_dst, weights["src_address"].values,
                               weights["dst_address"].values, weights["remap_matrix"].values)
-    threads = oracle.c_lib().oracle_num_threads()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    threads = int(os.environ.get("SMM_CPU_THREADS", min(avail, 16)))  # one GPU's CPU share
     rng = np.random.default_rng(20260723)
     dt = np.float64 if x_dtype == "f64" else np.float32
-    probe = max(threads, 4)
-    x = (250.0 + 30.0 * rng.standard_normal((probe, n_src))).astype(dt)
+    rows = int(min(n_batch_full, max(threads * 8, 128)))
+    x = np.empty((rows, n_src), dtype=dt)
+    for r in range(rows):
+        x[r] = 250.0 + 30.0 * rng.standard_normal(n_src, dtype=np.float32 if dt == np.float32 else np.float64)
     frac = weights["dst_grid_frac"].values
-    t0 = time.perf_counter()
-    oracle.apply_c(csr, x, False, None, frac, 0.5, threads=threads)
-    t_probe = time.perf_counter() - t0
-    rows = int(min(n_batch_full, max(probe, probe * (budget_s / max(t_probe, 1e-6))), 512))
-    rows = max(threads, (rows // threads) * threads)
-    x = np.tile(x, (int(np.ceil(rows / probe)), 1))[:rows]
-    x += rng.standard_normal((rows, 1)).astype(dt)
-    t0 = time.perf_counter()
-    y = oracle.apply_c(csr, x, False, None, frac, 0.5, threads=threads)
-    dt_s = time.perf_counter() - t0
-    return {"value": rows * n_dst / dt_s, "unit": "cells/s", "cores": threads, "kind": "port",
-            "sample": f"{rows} of {n_batch_full} batch rows, oracle/oracle.c with OpenMP over rows, "
-                      f"{dt_s:.2f} s"}, y
+    oracle.apply_c(csr, x[:threads], False, None, frac, 0.5, threads=threads)   # warm the team
+    passes, spent = 0, 0.0
+    y = None
+    while spent < budget_s and passes < 1000:
+        t0 = time.perf_counter()
+        y = oracle.apply_c(csr, x, False, None, frac, 0.5, threads=threads)
+        spent += time.perf_counter() - t0
+        passes += 1
+    return {"value": passes * rows * n_dst / spent, "unit": "cells/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{rows} of {n_batch_full} batch rows x {passes} passes, oracle/oracle.c "
+                      f"(OpenMP over rows, {threads} threads of {avail} visible), {spent:.1f} s"}, y
 
 
 def main():
@@ -132,6 +139,7 @@ def main():
         y = DeviceArray((n_batch, n_dst), np.float64)
 
     flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
+    flags |= (args.variant << 16) | (args.jpb << 20)
     area_min = 0.5
 
     def step():
@@ -175,7 +183,8 @@ def main():
         achieved = b_alg / k_avg / 1e9
         traffic = None
         if args.traffic_json and os.path.exists(args.traffic_json):
-            traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+            key = f"{args.workload}/{n_batch}/{args.kernel}/{args.variant}"
+            traffic = json.load(open(args.traffic_json)).get(key, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "regridded cells/sec (dst_pts x time x lev)",
             "value": cells / elapsed,
@@ -192,7 +201,7 @@ def main():
             "config": {"workload": f"{args.workload}: {sgrid}->{tgrid} {method}, {n_batch} batch rows "
                                    f"per GPU, {x_dtype} in / f64 out, X and Y resident in HBM",
                        "S": n_src, "D": n_dst, "nnz": op.nnz, "U": op.n_used_src,
-                       "kernel": args.kernel, "gather": args.gather if world > 1 else "n/a",
+                       "kernel": args.kernel, "plan": op.plan_info(), "gather": args.gather if world > 1 else "n/a",
                        "device": device_name(local_rank)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

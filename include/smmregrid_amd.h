@@ -63,6 +63,10 @@ enum {
   SMM_APPLY_KERNEL_SELL = 1u << 8, /* force the row-per-lane SELL-64 kernel                  */
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };
+/* tuning knobs for benchmarks (0 = library default): kernel variant in bits 16..19,
+ * batch rows walked per workgroup of the tile kernel in bits 20..27 */
+#define SMM_APPLY_VARIANT_SHIFT 16
+#define SMM_APPLY_JPB_SHIFT 20
 
 typedef struct smm_operator* smm_operator_t; /* one (S x D) weights matrix resident in HBM      */
 typedef struct smm_group* smm_group_t;       /* ordered set of operators (one per masked level) */

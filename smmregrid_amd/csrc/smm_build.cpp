@@ -132,15 +132,19 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_pe
   plan.blk_chunk_off.assign((size_t)n_blocks + 1, 0);
   plan.lcol.assign((size_t)sell.n_slots, 0);
 
-  std::vector<int32_t> chunks;
+  std::vector<int32_t> chunks, cols;
   for (int64_t b = 0; b < n_blocks; ++b) {
     const int64_t d0 = b * rows_per_block;
     const int64_t d1 = std::min(csr.n_dst, d0 + rows_per_block);
+    cols.assign(csr.col.begin() + csr.rowptr[(size_t)d0], csr.col.begin() + csr.rowptr[(size_t)d1]);
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    plan.total_distinct += (int64_t)cols.size();
     chunks.clear();
-    for (int64_t p = csr.rowptr[(size_t)d0]; p < csr.rowptr[(size_t)d1]; ++p)
-      chunks.push_back(csr.col[(size_t)p] / chunk_elems);
-    std::sort(chunks.begin(), chunks.end());
-    chunks.erase(std::unique(chunks.begin(), chunks.end()), chunks.end());
+    for (int32_t c : cols) {
+      const int32_t ch = c / chunk_elems;
+      if (chunks.empty() || chunks.back() != ch) chunks.push_back(ch);
+    }
     if ((int64_t)chunks.size() > max_chunks_per_block) {
       plan.valid = false;
       return;

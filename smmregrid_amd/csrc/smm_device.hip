@@ -87,6 +87,7 @@ struct ApplyArgs {
   int j_per_block;   // tile kernel: batch rows walked by one workgroup
 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
 constexpr int kChunkElems = 16;          // staged chunk: 128 B of f64, 64 B of f32
@@ -278,6 +279,131 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile_kernel(ApplyArgs a, b
   }
 }
 
+// Kernel B, pipelined form.  Each thread owns up to NP staging pieces whose row
+// offsets are computed once (they do not depend on the batch row), keeps the
+// next batch row's pieces in registers while the current one is consumed from
+// LDS, so the HBM latency of row j+1 overlaps the gather/store of row j and no
+// index load sits in front of a data load.  NT: non-temporal loads/stores for
+// the once-touched X and Y streams.
+template <typename XT, typename YT, int MAXK, int NP, bool NT>
+__global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  int64_t bid = blockIdx.x;
+  const int64_t db = bid % a.n_dblocks;
+  bid /= a.n_dblocks;
+  const int64_t jt = bid % a.n_jtiles;
+  const int64_t l = bid / a.n_jtiles;
+  const int di = a.lev_map ? a.lev_map[l] : 0;
+  const LevelDesc L = a.descs[di];
+
+  const int64_t slice = db * kWavesPerBlock + wave;
+  const int64_t d = slice * 64 + lane;
+  const bool row_live = d < a.n_dst;
+
+  int len = 0;
+  int32_t lc[MAXK];
+  double w[MAXK];
+  if (row_live) {
+    const int64_t off = L.slice_off[slice];
+    len = L.rowlen[d];
+    const int32_t* __restrict__ cp = L.lcol + off + lane;
+    const double* __restrict__ vp = L.val + off + lane;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const bool on = k < len;
+      lc[k] = on ? cp[(int64_t)k * 64] : 0;
+      w[k] = on ? vp[(int64_t)k * 64] : 0.0;
+    }
+  }
+  bool dead = false;
+  if (row_live) {
+    const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
+    if (use_mask && L.imask) dead = (L.imask[d] == 0);
+    if (a.area_min > 0.0 && L.frac) dead = dead || (L.frac[d] < a.area_min);
+  }
+
+  const int64_t c0 = L.blk_chunk_off[db];
+  const int nch = (int)(L.blk_chunk_off[db + 1] - c0);
+  const int32_t* __restrict__ chunk_src = L.chunk_src + c0;
+  constexpr int kElemsPerPiece = 16 / (int)sizeof(XT);
+  constexpr int pieces_per_chunk = kChunkElems / kElemsPerPiece;
+  const int npieces = nch * pieces_per_chunk;
+  const XT* lds_x = (const XT*)smem;
+
+  // this thread's pieces: element offset inside a batch row, -1 = none
+  int32_t poff[NP];
+  unsigned clipped = 0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = tid + k * kThreads;
+    poff[k] = -1;
+    if (p < npieces) {
+      const int ch = p / pieces_per_chunk;
+      const int sub = p - ch * pieces_per_chunk;
+      const int64_t e0 = (int64_t)chunk_src[ch] * kChunkElems + (int64_t)sub * kElemsPerPiece;
+      if (e0 < a.n_src) {
+        poff[k] = (int32_t)e0;
+        if (e0 + kElemsPerPiece > a.n_src) clipped |= 1u << k;
+      }
+    }
+  }
+
+  const int64_t j_begin = jt * a.j_per_block;
+  int64_t j_end = j_begin + a.j_per_block;
+  if (j_end > a.n_j) j_end = a.n_j;
+  if (j_begin >= j_end) return;
+
+  u32x4 v[NP];
+  auto load_row = [&](int64_t j) {
+    const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (poff[k] >= 0) {
+        if (!((clipped >> k) & 1u)) {
+          const u32x4* src = (const u32x4*)(xrow + poff[k]);
+          v[k] = NT ? __builtin_nontemporal_load(src) : *src;
+        } else {
+          XT tmp[kElemsPerPiece];
+#pragma unroll
+          for (int e = 0; e < kElemsPerPiece; ++e)
+            tmp[e] = ((int64_t)poff[k] + e < a.n_src) ? xrow[poff[k] + e] : (XT)0;
+          __builtin_memcpy(&v[k], tmp, 16);
+        }
+      }
+    }
+  };
+
+  load_row(j_begin);
+  for (int64_t j = j_begin; j < j_end; ++j) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+      if (poff[k] >= 0) *(u32x4*)(smem + (size_t)(tid + k * kThreads) * 16) = v[k];
+    __syncthreads();
+    if (j + 1 < j_end) load_row(j + 1);
+    if (row_live) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < MAXK; ++k) {
+        if (k < len) {
+          const double xv = load_fixed(lds_x + lc[k], fill);
+          const double p = w[k] * xv;
+          acc = acc + p;
+        }
+      }
+      YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+      const YT out = (YT)epilogue(acc, dead);
+      if (NT)
+        __builtin_nontemporal_store(out, yrow + d);
+      else
+        yrow[d] = out;
+    }
+    __syncthreads();
+  }
+}
+
 // counter-based synthetic field: splitmix64 -> two uniforms -> Box-Muller
 template <typename T>
 __global__ void smm_fill_random_kernel(T* __restrict__ dst, int64_t n, uint64_t seed, double mean,
@@ -320,7 +446,8 @@ struct smm_operator {
   // tile plan
   bool tile_valid = false;
   int chunk_elems = 0;
-  int64_t tile_blocks = 0, tile_max_chunks = 0, tile_total_chunks = 0;
+  int64_t tile_blocks = 0, tile_max_chunks = 0, tile_total_chunks = 0, tile_total_distinct = 0;
+  bool tile_preferred = false;  // staged lines are used well enough to beat direct gathers
   int64_t* d_blk_chunk_off = nullptr;
   int32_t* d_chunk_src = nullptr;
   int32_t* d_lcol = nullptr;
@@ -345,6 +472,7 @@ struct smm_group {
   std::vector<smm_operator_t> ops;
   LevelDesc* d_descs = nullptr;
   bool tile_valid = false;
+  bool tile_preferred = false;
   int64_t tile_max_chunks = 0;
   int64_t max_row_nnz = 0;
   // uploaded (level_index, masked_levels) configurations, keyed by content
@@ -426,33 +554,60 @@ int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, hipStream_t s) {
 
 template <typename XT, typename YT>
 int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t max_row_nnz,
-                bool fill, hipStream_t s) {
+                bool fill, unsigned flags, hipStream_t s) {
   ApplyArgs args = a;
-  args.j_per_block = (int)std::min<int64_t>(a.n_j, 16);
+  const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
+  const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
+  args.j_per_block = (int)std::min<int64_t>(a.n_j, jpb ? jpb : 16);
   args.n_jtiles = (a.n_j + args.j_per_block - 1) / args.j_per_block;
   const int64_t total = args.n_dblocks * args.n_jtiles * n_lev;
   if (total <= 0) return SMM_OK;
   if (total > 0x7fffffffLL) return fail(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
   const size_t lds = (size_t)max_chunks * kChunkElems * sizeof(XT);
-  auto go = [&](auto k_tag) -> int {
+  const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
+  const int np_needed = (int)((max_pieces + kThreads - 1) / kThreads);
+
+  auto go1 = [&](auto k_tag) -> int {  // variant 1: unpipelined staging loop
     constexpr int MAXK = decltype(k_tag)::value;
     hipLaunchKernelGGL((smm_apply_tile_kernel<XT, YT, MAXK>), dim3((unsigned)total), dim3(kThreads),
                        lds, s, args, fill);
     SMM_HIP(hipGetLastError());
     return SMM_OK;
   };
-  if (max_row_nnz <= 4) return go(std::integral_constant<int, 4>());
-  if (max_row_nnz <= 8) return go(std::integral_constant<int, 8>());
-  if (max_row_nnz <= 16) return go(std::integral_constant<int, 16>());
-  if (max_row_nnz <= 32) return go(std::integral_constant<int, 32>());
-  return fail(SMM_ERR_UNSUPPORTED, "tile kernel supports at most 32 links per destination row");
+  auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
+    constexpr int MAXK = decltype(k_tag)::value;
+    constexpr int NP = decltype(np_tag)::value;
+    constexpr bool NT = decltype(nt_tag)::value;
+    hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NP, NT>), dim3((unsigned)total),
+                       dim3(kThreads), lds, s, args, fill);
+    SMM_HIP(hipGetLastError());
+    return SMM_OK;
+  };
+  auto with_k = [&](auto fn) -> int {
+    if (max_row_nnz <= 4) return fn(std::integral_constant<int, 4>());
+    if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
+    if (max_row_nnz <= 16) return fn(std::integral_constant<int, 16>());
+    if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
+    return fail(SMM_ERR_UNSUPPORTED, "tile kernel supports at most 32 links per destination row");
+  };
+  if (variant == 1 || np_needed > 16) return with_k(go1);
+  const bool nt = (variant != 2);  // default (0) and 3: non-temporal X loads / Y stores
+  return with_k([&](auto k_tag) -> int {
+    auto with_nt = [&](auto np_tag) -> int {
+      if (nt) return go2(k_tag, np_tag, std::true_type());
+      return go2(k_tag, np_tag, std::false_type());
+    };
+    if (np_needed <= 4) return with_nt(std::integral_constant<int, 4>());
+    if (np_needed <= 8) return with_nt(std::integral_constant<int, 8>());
+    return with_nt(std::integral_constant<int, 16>());
+  });
 }
 
 bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 // Common launch path for a single operator (descs = op->d_desc) or a group.
 int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t* d_lev_masked,
-              int64_t n_src, int64_t n_dst, bool tile_ok, int64_t tile_max_chunks,
+              int64_t n_src, int64_t n_dst, bool tile_ok, bool tile_preferred, int64_t tile_max_chunks,
               int64_t max_row_nnz, const void* x, int x_dtype, int64_t xs_o, int64_t xs_l,
               int64_t xs_i, void* y, int y_dtype, int64_t ys_o, int64_t ys_l, int64_t ys_i,
               int64_t n_outer, int64_t n_lev, int64_t n_inner, double area_min, unsigned flags,
@@ -491,6 +646,8 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
   if (flags & SMM_APPLY_KERNEL_TILE) {
     if (!tile_ok) return fail(SMM_ERR_UNSUPPORTED, "operator has no LDS tile plan");
     use_tile = true;
+  } else if (!(flags & SMM_APPLY_KERNEL_SELL)) {
+    use_tile = tile_ok && tile_preferred;
   }
   if (use_tile) {
     // 16-B staging loads need 16-B aligned batch rows
@@ -508,7 +665,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
   (x_dtype == SMM_F64                                                                \
        ? (y_dtype == SMM_F64 ? FN<double, double>(__VA_ARGS__) : FN<double, float>(__VA_ARGS__)) \
        : (y_dtype == SMM_F64 ? FN<float, double>(__VA_ARGS__) : FN<float, float>(__VA_ARGS__)))
-  if (use_tile) return SMM_DISPATCH(launch_tile, a, n_lev, tile_max_chunks, max_row_nnz, fill, s);
+  if (use_tile) return SMM_DISPATCH(launch_tile, a, n_lev, tile_max_chunks, max_row_nnz, fill, flags, s);
   return SMM_DISPATCH(launch_sell, a, n_lev, fill, s);
 #undef SMM_DISPATCH
 }
@@ -722,6 +879,10 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
       op->tile_blocks = plan.n_blocks;
       op->tile_max_chunks = plan.max_block_chunks;
       op->tile_total_chunks = plan.total_chunks;
+      op->tile_total_distinct = plan.total_distinct;
+      // at least a quarter of every staged 128-B line is consumed, rows fit the register file
+      op->tile_preferred = plan.total_distinct * 4 >= plan.total_chunks * (int64_t)plan.chunk_elems &&
+                           op->csr.max_row_nnz <= 32;
     }
     if ((rc = refresh_desc(op))) {
       release(op);
@@ -787,7 +948,7 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
 int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
                            int64_t* staged_src_elems) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
-  if (kernel_kind) *kernel_kind = op->tile_valid ? 1 : 0;
+  if (kernel_kind) *kernel_kind = (op->tile_valid ? 1 : 0) | (op->tile_preferred ? 2 : 0);
   if (lds_bytes) *lds_bytes = op->tile_valid ? op->tile_max_chunks * op->chunk_elems * 8 : 0;
   if (staged_src_elems) *staged_src_elems = op->tile_valid ? op->tile_total_chunks * op->chunk_elems : 0;
   return SMM_OK;
@@ -805,7 +966,7 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   DeviceGuard guard(op->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, op->tile_valid,
-                   op->tile_max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
+                   op->tile_preferred, op->tile_max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
 
@@ -837,7 +998,7 @@ int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t
     cleanup();
     return fail(SMM_ERR_HIP, "hipMemcpy failed in smm_operator_mask_apply");
   }
-  rc = run_apply(op->d_desc, nullptr, nullptr, S, D, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
+  rc = run_apply(op->d_desc, nullptr, nullptr, S, D, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
                  std::max<int64_t>(S, 1), 0, 0, dy, SMM_F64, D, 0, 0, 1, 1, 1, 0.0,
                  SMM_APPLY_NO_FILL, nullptr);
   if (rc == SMM_OK) {
@@ -870,10 +1031,12 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
   g->device = ops[0]->device;
   g->ops.assign(ops, ops + n_ops);
   g->tile_valid = true;
+  g->tile_preferred = true;
   std::vector<LevelDesc> descs((size_t)n_ops);
   for (int i = 0; i < n_ops; ++i) {
     descs[(size_t)i] = ops[i]->desc();
     g->tile_valid = g->tile_valid && ops[i]->tile_valid;
+    g->tile_preferred = g->tile_preferred && ops[i]->tile_preferred;
     g->tile_max_chunks = std::max(g->tile_max_chunks, ops[i]->tile_max_chunks);
     g->max_row_nnz = std::max(g->max_row_nnz, ops[i]->csr.max_row_nnz);
   }
@@ -949,7 +1112,7 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
   const uint8_t* d_masked = masked_levels ? (const uint8_t*)d_cfg + map_bytes : nullptr;
   const smm_operator* op0 = g->ops[0];
   return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_valid,
-                   g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
+                   g->tile_preferred, g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
 }
