@@ -3,16 +3,21 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (smm_apply) over the whole batch of the
-workload: config 2 of BASELINE.json by default -- r1440x721 -> r360x180
-bilinear, 3600 time steps, f64 -- with X and Y resident in HBM.  For N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank regrids its
-own 3600-step shard of the time axis (weak scaling; batch rows are independent,
-SURVEY 8e) and the Y shards are gathered to rank 0 with RCCL unless
---gather none.
+One "step" = one pass of the hot path over the whole batch of the workload.
+Default workload = config 2 of BASELINE.json (the configuration the metric is
+quoted on): r1440x721 -> r360x180 bilinear, 3600 time steps, f64, X and Y
+resident in HBM.  Other workloads (--workload): cfg3 (masked ocean levels,
+grouped launch), cfg5tile (config-5 geometry, one GPU's share of rows), cfg1.
 
-Rank 0 prints ONE JSON line with the driver's contract plus `roofline`
-(HBM bound, algorithmic bytes of SURVEY 8d / live HIP-event kernel time) and
+For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
+regrids its own full-size shard of the time axis (weak scaling; batch rows are
+independent) and the Y shards stay resident on their GPUs: `value`
+is that job (no data-path collective).  A second timed loop in the same run adds
+the RCCL gather of the Y shards to rank 0 after every step and is reported as
+`with_gather` beside it (xGMI-link bound; --gather none skips it).
+
+Rank 0 prints ONE JSON line: the driver's contract plus `roofline` (HBM bound;
+algorithmic bytes of SURVEY 8d over the live HIP-event kernel time) and
 `cpu_baseline` (the CPU oracle -- a port of the reference's step sequence --
 timed on this host's cores over a bounded sample of the same workload).
 """
@@ -31,10 +36,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
-    # name: (method, source grid, target grid, batch, x dtype)
+    # name: (method, source grid, target grid, batch rows, x dtype)
     "cfg2": ("bil", "r1440x721", "r360x180", 3600, "f64"),
-    "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),   # config-5 geometry, one GPU's worth of rows
+    "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
     "cfg1": ("bil", "r180x90", "r90x45", 1, "f64"),
+    # masked levels: (method, source nx x ny, target, (time steps, levels), x dtype)
+    "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
+    "cfg3s": ("con3d", (1442, 1021), "r360x180", (16, 8), "f64"),
 }
 
 
@@ -49,9 +57,9 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant knob (0 = default)")
     ap.add_argument("--jpb", type=int, default=0, help="tile kernel: batch rows per workgroup")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
-                    help="N>1: RCCL gather of the Y shards to rank 0 inside the timed region")
+                    help="N>1: also time the steps followed by the RCCL gather of the Y shards to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                          "passes, corrected per MI355X_MICROARCH.md), keyed by workload/batch/kernel")
@@ -63,35 +71,151 @@ def algorithmic_bytes(op, n_batch, sx, sy):
     return n_batch * (op.n_used_src * sx + op.n_dst * sy) + op.nnz * 12 + (op.n_dst + 1) * 4
 
 
-def cpu_baseline(weights, n_batch_full, x_dtype, budget_s):
-    """Oracle (C port of regrid.py:545-570, OpenMP over batch rows) on a bounded sample:
-    a fixed block of distinct batch rows of the same workload, passed repeatedly until
-    about `budget_s` seconds of CPU work have been timed."""
-    from oracle import oracle
-    n_src, n_dst = weights.sizes["src_grid_size"], weights.sizes["dst_grid_size"]
-    csr = oracle.coo_to_csr_c(n_src, n_dst, weights["src_address"].values,
-                              weights["dst_address"].values, weights["remap_matrix"].values)
+class Problem2D:
+    """One operator, X (B, S) -> Y (B, D)."""
+
+    def __init__(self, name, device, rank, batch=None):
+        from smmregrid_amd import SparseOperator, gridgen
+        from smmregrid_amd.device import DeviceArray
+        method, sgrid, tgrid, n_batch, self.x_dtype = WORKLOADS[name]
+        self.n_batch = batch or n_batch
+        self.weights = gridgen.generate_weights(sgrid, tgrid, method=method)
+        w = self.weights
+        self.n_src, self.n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
+        self.op = SparseOperator(self.n_src, self.n_dst, w["src_address"].values,
+                                 w["dst_address"].values, w["remap_matrix"].values, device=device)
+        self.op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
+        self.np_dt = np.float64 if self.x_dtype == "f64" else np.float32
+        self.x = DeviceArray((self.n_batch, self.n_src), self.np_dt)
+        self.x.fill_random(seed=20260723 + 1000003 * rank, mean=250.0, sigma=30.0)
+        self.y_shape = (self.n_batch, self.n_dst)
+        self.desc = (f"{name}: {sgrid}->{tgrid} {method}, {self.n_batch} batch rows per GPU, "
+                     f"{self.x_dtype} in / f64 out, X and Y resident in HBM")
+        self.meta = {"S": self.n_src, "D": self.n_dst, "nnz": self.op.nnz, "U": self.op.n_used_src,
+                     "plan": self.op.plan_info()}
+
+    def cells(self):
+        return float(self.n_dst) * self.n_batch
+
+    def alg_bytes(self):
+        return algorithmic_bytes(self.op, self.n_batch, np.dtype(self.np_dt).itemsize, 8)
+
+    def full_stream_bytes(self):
+        return self.n_batch * (self.n_src * np.dtype(self.np_dt).itemsize + self.n_dst * 8) + self.op.nnz * 12
+
+    def run(self, y, flags):
+        self.op.apply(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags)
+
+    def cpu_baseline(self, budget_s):
+        """Oracle (C port of regrid.py:545-570, OpenMP over batch rows) on a bounded sample:
+        a block of distinct batch rows of the same workload, passed repeatedly until about
+        `budget_s` seconds of CPU work have been timed."""
+        from oracle import oracle
+        w = self.weights
+        csr = oracle.coo_to_csr_c(self.n_src, self.n_dst, w["src_address"].values,
+                                  w["dst_address"].values, w["remap_matrix"].values)
+        threads, avail = cpu_threads()
+        rng = np.random.default_rng(20260723)
+        rows = int(min(self.n_batch, max(threads * 8, 128)))
+        x = np.empty((rows, self.n_src), dtype=self.np_dt)
+        for r in range(rows):
+            x[r] = 250.0 + 30.0 * rng.standard_normal(self.n_src, dtype=self.np_dt)
+        frac = w["dst_grid_frac"].values
+        oracle.apply_c(csr, x[:threads], False, None, frac, 0.5, threads=threads)  # warm the team
+        passes, spent = 0, 0.0
+        while spent < budget_s and passes < 1000:
+            t0 = time.perf_counter()
+            oracle.apply_c(csr, x, False, None, frac, 0.5, threads=threads)
+            spent += time.perf_counter() - t0
+            passes += 1
+        return {"value": passes * rows * self.n_dst / spent, "unit": "cells/s", "cores": threads,
+                "kind": "port",
+                "sample": f"{rows} of {self.n_batch} batch rows x {passes} passes, oracle/oracle.c "
+                          f"(OpenMP over rows, {threads} threads of {avail} visible), {spent:.1f} s"}
+
+
+class ProblemLevels:
+    """Config 3: per-level ocean masks, X (T, L, S) -> Y (T, L, D) in one grouped launch."""
+
+    def __init__(self, name, device, rank, batch=None):
+        from smmregrid_amd import OperatorGroup, gridgen
+        from smmregrid_amd.device import DeviceArray
+        from smmregrid_amd.weights import compute_weights_matrix3d
+        _, (nx, ny), tgrid, (n_t, n_lev), self.x_dtype = WORKLOADS[name]
+        self.n_t, self.n_lev = batch or n_t, n_lev
+        src = gridgen.regular_grid(nx, ny, name=f"tripolar-like {nx}x{ny}")
+        masks = gridgen.synthetic_ocean_masks(nx, ny, n_lev)
+        levels = np.arange(n_lev, dtype=np.float64)
+        w3 = gridgen.ConservativeLevels(src, tgrid).stack(masks, levels)
+        self.weights = w3
+        self.n_src, self.n_dst = w3.sizes["src_grid_size"], w3.sizes["dst_grid_size"]
+        self.ops = compute_weights_matrix3d(w3, "lev", device=device)
+        self.dst_imask = np.stack([op.mask_apply(masks[i]) for i, op in enumerate(self.ops)])
+        frac = w3["dst_grid_frac"].values
+        for i, op in enumerate(self.ops):
+            op.set_epilogue(self.dst_imask[i], frac[i])
+        self.group = OperatorGroup(self.ops)
+        self.masked_levels = (~(self.dst_imask == 1).all(axis=1)).astype(np.uint8)
+        self.level_index = np.arange(n_lev, dtype=np.int32)
+        # one time slab on the host (NaN on land per level), replicated over time on the device
+        rng = np.random.default_rng(20260723 + rank)
+        slab = (10.0 + 5.0 * rng.standard_normal((n_lev, self.n_src), dtype=np.float32)).astype(np.float64)
+        slab[masks == 0] = np.nan
+        self.slab, self.masks = slab, masks
+        self.x = DeviceArray((self.n_t, n_lev, 1, self.n_src), np.float64)
+        self.x.rows(0, 1).copy_from_host(slab.reshape(1, n_lev, 1, self.n_src))
+        from smmregrid_amd import _lib
+        import ctypes
+        for t in range(1, self.n_t):
+            _lib.call("smm_memcpy_d2d", ctypes.c_void_p(self.x.rows(t, t + 1).ptr),
+                      ctypes.c_void_p(self.x.ptr), slab.nbytes, None)
+        self.y_shape = (self.n_t, 1, n_lev, self.n_dst)
+        self.np_dt = np.float64
+        nnz = sum(op.nnz for op in self.ops)
+        self.desc = (f"{name}: {nx}x{ny} tripolar-like -> {tgrid} conservative, {self.n_t} time steps x "
+                     f"{n_lev} masked levels per GPU, f64, remap_area_min 0.5, grouped launch")
+        self.meta = {"S": self.n_src, "D": self.n_dst, "nnz_total": nnz, "levels": n_lev,
+                     "max_row_nnz": max(op.max_row_nnz for op in self.ops),
+                     "plan": self.ops[0].plan_info()}
+
+    def cells(self):
+        return float(self.n_dst) * self.n_t * self.n_lev
+
+    def alg_bytes(self):
+        return sum(algorithmic_bytes(op, self.n_t, 8, 8) for op in self.ops)
+
+    def full_stream_bytes(self):
+        return self.n_t * self.n_lev * (self.n_src + self.n_dst) * 8 + sum(op.nnz for op in self.ops) * 12
+
+    def run(self, y, flags):
+        self.group.apply(self.x, self.level_index, self.masked_levels, y=y, masked=True,
+                         remap_area_min=0.5, transpose=True, flags=flags)
+
+    def cpu_baseline(self, budget_s):
+        from oracle import oracle
+        threads, avail = cpu_threads()
+        csrs = [op.export_csr() for op in self.ops]
+        frac = self.weights["dst_grid_frac"].values
+        t_rows = max(threads, 16)
+        passes, spent = 0, 0.0
+        x = np.broadcast_to(self.slab[None], (t_rows,) + self.slab.shape)
+        while spent < budget_s and passes < 100:
+            t0 = time.perf_counter()
+            for lv in range(self.n_lev):
+                oracle.apply_c(csrs[lv], np.ascontiguousarray(x[:, lv]), bool(self.masked_levels[lv]),
+                               self.dst_imask[lv], frac[lv], 0.5, threads=threads)
+            spent += time.perf_counter() - t0
+            passes += 1
+        return {"value": passes * t_rows * self.n_lev * self.n_dst / spent, "unit": "cells/s",
+                "cores": threads, "kind": "port",
+                "sample": f"{t_rows} of {self.n_t} time steps x {self.n_lev} levels x {passes} passes, "
+                          f"oracle/oracle.c level by level (OpenMP over rows, {threads} threads of "
+                          f"{avail} visible), {spent:.1f} s"}
+
+
+def cpu_threads():
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    threads = int(os.environ.get("SMM_CPU_THREADS", min(avail, 16)))  # one GPU's CPU share
-    rng = np.random.default_rng(20260723)
-    dt = np.float64 if x_dtype == "f64" else np.float32
-    rows = int(min(n_batch_full, max(threads * 8, 128)))
-    x = np.empty((rows, n_src), dtype=dt)
-    for r in range(rows):
-        x[r] = 250.0 + 30.0 * rng.standard_normal(n_src, dtype=np.float32 if dt == np.float32 else np.float64)
-    frac = weights["dst_grid_frac"].values
-    oracle.apply_c(csr, x[:threads], False, None, frac, 0.5, threads=threads)   # warm the team
-    passes, spent = 0, 0.0
-    y = None
-    while spent < budget_s and passes < 1000:
-        t0 = time.perf_counter()
-        y = oracle.apply_c(csr, x, False, None, frac, 0.5, threads=threads)
-        spent += time.perf_counter() - t0
-        passes += 1
-    return {"value": passes * rows * n_dst / spent, "unit": "cells/s", "cores": threads,
-            "kind": "port",
-            "sample": f"{rows} of {n_batch_full} batch rows x {passes} passes, oracle/oracle.c "
-                      f"(OpenMP over rows, {threads} threads of {avail} visible), {spent:.1f} s"}, y
+    return int(os.environ.get("SMM_CPU_THREADS", min(avail, 16))), avail  # 16 = one GPU's CPU share
 
 
 def main():
@@ -99,95 +223,97 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    use_dist = world > 1 or bool(os.environ.get("SMM_BENCH_FORCE_DIST"))  # rehearsal of the N>1 path on one GPU
+    if world > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    from smmregrid_amd import SparseOperator, _lib, gridgen
-    from smmregrid_amd.device import DeviceArray, Event, set_device, synchronize, device_name
+    from smmregrid_amd import _lib
+    from smmregrid_amd.device import DeviceArray, Event, device_name, set_device, synchronize
 
-    dist = None
-    torch = None
-    if world > 1:
+    dist = torch = None
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     set_device(local_rank)
 
-    method, sgrid, tgrid, n_batch, x_dtype = WORKLOADS[args.workload]
-    if args.batch:
-        n_batch = args.batch
-    weights = gridgen.generate_weights(sgrid, tgrid, method=method)
-    n_src, n_dst = weights.sizes["src_grid_size"], weights.sizes["dst_grid_size"]
-    op = SparseOperator(n_src, n_dst, weights["src_address"].values, weights["dst_address"].values,
-                        weights["remap_matrix"].values, device=local_rank)
-    op.set_epilogue(weights["dst_grid_imask"].values, weights["dst_grid_frac"].values)
-    np_dt = np.float64 if x_dtype == "f64" else np.float32
-    sx = np.dtype(np_dt).itemsize
+    cls = ProblemLevels if WORKLOADS[args.workload][0] == "con3d" else Problem2D
+    prob = cls(args.workload, local_rank, rank, batch=args.batch)
 
-    # device-resident fields; with N > 1 torch owns the Y buffer so RCCL can move it
-    x = DeviceArray((n_batch, n_src), np_dt)
-    x.fill_random(seed=20260723 + 1000003 * rank, mean=250.0, sigma=30.0)
-    y_t = None
-    if world > 1:
-        y_t = torch.empty((n_batch, n_dst), dtype=torch.float64, device=f"cuda:{local_rank}")
-        y = DeviceArray((n_batch, n_dst), np.float64, ptr=y_t.data_ptr())
-        gathered = None
+    # with N > 1 torch owns the Y buffer so RCCL can move it
+    y_t = gathered = None
+    if use_dist:
+        y_t = torch.empty(prob.y_shape, dtype=torch.float64, device=f"cuda:{local_rank}")
+        y = DeviceArray(prob.y_shape, np.float64, ptr=y_t.data_ptr())
         if args.gather == "root" and rank == 0:
             gathered = [torch.empty_like(y_t) for _ in range(world)]
     else:
-        y = DeviceArray((n_batch, n_dst), np.float64)
+        y = DeviceArray(prob.y_shape, np.float64)
 
     flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
     flags |= (args.variant << 16) | (args.jpb << 20)
-    area_min = 0.5
 
-    def step():
-        op.apply(x, y=y, masked=False, remap_area_min=area_min, flags=flags)
-        if world > 1 and args.gather == "root":
-            torch.cuda.current_stream().synchronize()   # kernel ran on the null stream: ordered already
+    def step(events=None, gather=False):
+        if events:
+            events[0].record()
+        prob.run(y, flags)            # launches on the null stream, which torch's stream orders with
+        if events:
+            events[1].record()
+        if gather:
             dist.gather(y_t, gathered, dst=0)
 
     def barrier():
         synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    def timed(gather):
+        """W warm-up steps, then exactly K steps between barriers; MAX over ranks."""
+        for _ in range(args.warmup):
+            step(gather=gather)
+        barrier()
+        ev = [(Event(), Event()) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(ev[k], gather=gather)
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, [a.elapsed_ms(b) for a, b in ev]
 
-    # timed region: exactly K steps; per-launch kernel time from HIP events on the launch stream
-    ev = [(Event(), Event()) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record()
-        op.apply(x, y=y, masked=False, remap_area_min=area_min, flags=flags)
-        ev[k][1].record()
-        if world > 1 and args.gather == "root":
-            dist.gather(y_t, gathered, dst=0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_ms(b) for a, b in ev]
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the measured job: every rank regrids its shard, Y shards stay resident on their GPUs
+    elapsed, kernel_ms = timed(gather=False)
+    # the same job followed by the RCCL gather of the Y shards to rank 0 (north star's exchange
+    # step), reported beside it: xGMI-link bound, see DESIGN.md "Multi-GPU"
+    with_gather = None
+    if use_dist and args.gather == "root":
+        try:
+            g_elapsed, _ = timed(gather=True)
+            with_gather = {"value": prob.cells() * world * args.steps / g_elapsed, "unit": "cells/s",
+                           "ms_per_step": g_elapsed / args.steps * 1e3,
+                           "gathered_bytes_per_step": int(np.prod(prob.y_shape)) * 8 * (world - 1)}
+        except Exception as exc:  # report, never lose the compute measurement
+            with_gather = {"error": repr(exc)}
 
     if rank == 0:
-        cells = float(n_dst) * n_batch * world * args.steps
         k_avg = float(np.mean(kernel_ms)) * 1e-3
-        b_alg = algorithmic_bytes(op, n_batch, sx, 8)
+        b_alg = prob.alg_bytes()
         achieved = b_alg / k_avg / 1e9
         traffic = None
         if args.traffic_json and os.path.exists(args.traffic_json):
-            key = f"{args.workload}/{n_batch}/{args.kernel}/{args.variant}"
+            key = f"{args.workload}/{args.batch or 'default'}/{args.kernel}/{args.variant}"
             traffic = json.load(open(args.traffic_json)).get(key, {}).get("hbm_bytes_per_launch")
+        cfg = {"workload": prob.desc, "kernel": args.kernel,
+               "gather": args.gather if use_dist else "n/a", "device": device_name(local_rank)}
+        cfg.update(prob.meta)
         out = {
             "metric": "regridded cells/sec (dst_pts x time x lev)",
-            "value": cells / elapsed,
+            "value": prob.cells() * world * args.steps / elapsed,
             "unit": "cells/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -196,23 +322,22 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": x_dtype,
+            "dtype": prob.x_dtype,
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {sgrid}->{tgrid} {method}, {n_batch} batch rows "
-                                   f"per GPU, {x_dtype} in / f64 out, X and Y resident in HBM",
-                       "S": n_src, "D": n_dst, "nnz": op.nnz, "U": op.n_used_src,
-                       "kernel": args.kernel, "plan": op.plan_info(), "gather": args.gather if world > 1 else "n/a",
-                       "device": device_name(local_rank)},
+            "config": cfg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": k_avg * 1e3, "algorithmic_bytes": b_alg,
-                         "full_stream_bytes": n_batch * (n_src * sx + n_dst * 8) + op.nnz * 12},
+                         "full_stream_bytes": prob.full_stream_bytes(),
+                         "traffic_GBs": (traffic / k_avg / 1e9) if traffic else None},
         }
+        if with_gather is not None:
+            out["with_gather"] = with_gather
         if not args.no_cpu_baseline:
-            out["cpu_baseline"], _ = cpu_baseline(weights, n_batch, x_dtype, args.cpu_seconds)
+            out["cpu_baseline"] = prob.cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

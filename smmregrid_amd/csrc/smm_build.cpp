@@ -170,6 +170,11 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_pe
     }
   }
   plan.total_chunks = (int64_t)plan.chunk_src.size();
+  {
+    std::vector<int32_t> all(plan.chunk_src);
+    std::sort(all.begin(), all.end());
+    plan.distinct_chunks = (int64_t)(std::unique(all.begin(), all.end()) - all.begin());
+  }
   plan.valid = true;
 }
 

@@ -283,9 +283,9 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile_kernel(ApplyArgs a, b
 // offsets are computed once (they do not depend on the batch row), keeps the
 // next batch row's pieces in registers while the current one is consumed from
 // LDS, so the HBM latency of row j+1 overlaps the gather/store of row j and no
-// index load sits in front of a data load.  NT: non-temporal loads/stores for
-// the once-touched X and Y streams.
-template <typename XT, typename YT, int MAXK, int NP, bool NT>
+// index load sits in front of a data load.  NT bit 0: non-temporal X loads (only
+// when no staged line is shared between blocks), bit 1: non-temporal Y stores.
+template <typename XT, typename YT, int MAXK, int NP, int NT>
 __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -303,19 +303,26 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
   const int64_t d = slice * 64 + lane;
   const bool row_live = d < a.n_dst;
 
+  // MAXK > 0: the row's links live in registers across batch rows;
+  // MAXK == 0 (rows longer than 32 links): they are re-read per batch row (L2 hits).
+  constexpr int KREG = MAXK > 0 ? MAXK : 1;
   int len = 0;
-  int32_t lc[MAXK];
-  double w[MAXK];
+  int32_t lc[KREG];
+  double w[KREG];
+  const int32_t* __restrict__ cp = nullptr;
+  const double* __restrict__ vp = nullptr;
   if (row_live) {
     const int64_t off = L.slice_off[slice];
     len = L.rowlen[d];
-    const int32_t* __restrict__ cp = L.lcol + off + lane;
-    const double* __restrict__ vp = L.val + off + lane;
+    cp = L.lcol + off + lane;
+    vp = L.val + off + lane;
+    if (MAXK > 0) {
 #pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const bool on = k < len;
-      lc[k] = on ? cp[(int64_t)k * 64] : 0;
-      w[k] = on ? vp[(int64_t)k * 64] : 0.0;
+      for (int k = 0; k < KREG; ++k) {
+        const bool on = k < len;
+        lc[k] = on ? cp[(int64_t)k * 64] : 0;
+        w[k] = on ? vp[(int64_t)k * 64] : 0.0;
+      }
     }
   }
   bool dead = false;
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
       if (poff[k] >= 0) {
         if (!((clipped >> k) & 1u)) {
           const u32x4* src = (const u32x4*)(xrow + poff[k]);
-          v[k] = NT ? __builtin_nontemporal_load(src) : *src;
+          v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
         } else {
           XT tmp[kElemsPerPiece];
 #pragma unroll
@@ -385,17 +392,26 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
     if (j + 1 < j_end) load_row(j + 1);
     if (row_live) {
       double acc = 0.0;
+      if (MAXK > 0) {
 #pragma unroll
-      for (int k = 0; k < MAXK; ++k) {
-        if (k < len) {
-          const double xv = load_fixed(lds_x + lc[k], fill);
-          const double p = w[k] * xv;
+        for (int k = 0; k < KREG; ++k) {
+          if (k < len) {
+            const double xv = load_fixed(lds_x + lc[k], fill);
+            const double p = w[k] * xv;
+            acc = acc + p;
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int k = 0; k < len; ++k) {
+          const double xv = load_fixed(lds_x + cp[(int64_t)k * 64], fill);
+          const double p = vp[(int64_t)k * 64] * xv;
           acc = acc + p;
         }
       }
       YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
       const YT out = (YT)epilogue(acc, dead);
-      if (NT)
+      if (NT & 2)
         __builtin_nontemporal_store(out, yrow + d);
       else
         yrow[d] = out;
@@ -448,6 +464,7 @@ struct smm_operator {
   int chunk_elems = 0;
   int64_t tile_blocks = 0, tile_max_chunks = 0, tile_total_chunks = 0, tile_total_distinct = 0;
   bool tile_preferred = false;  // staged lines are used well enough to beat direct gathers
+  bool tile_reuse = false;      // some staged lines are shared by several blocks (keep them cacheable)
   int64_t* d_blk_chunk_off = nullptr;
   int32_t* d_chunk_src = nullptr;
   int32_t* d_lcol = nullptr;
@@ -473,6 +490,7 @@ struct smm_group {
   LevelDesc* d_descs = nullptr;
   bool tile_valid = false;
   bool tile_preferred = false;
+  bool tile_reuse = false;
   int64_t tile_max_chunks = 0;
   int64_t max_row_nnz = 0;
   // uploaded (level_index, masked_levels) configurations, keyed by content
@@ -554,7 +572,7 @@ int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, hipStream_t s) {
 
 template <typename XT, typename YT>
 int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t max_row_nnz,
-                bool fill, unsigned flags, hipStream_t s) {
+                bool tile_reuse, bool fill, unsigned flags, hipStream_t s) {
   ApplyArgs args = a;
   const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
   const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
@@ -567,8 +585,8 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
   const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
   const int np_needed = (int)((max_pieces + kThreads - 1) / kThreads);
 
-  auto go1 = [&](auto k_tag) -> int {  // variant 1: unpipelined staging loop
-    constexpr int MAXK = decltype(k_tag)::value;
+  auto go1 = [&](auto k_tag) -> int {  // variant 1: unpipelined staging loop (never reached with 0)
+    constexpr int MAXK = decltype(k_tag)::value > 0 ? decltype(k_tag)::value : 32;
     hipLaunchKernelGGL((smm_apply_tile_kernel<XT, YT, MAXK>), dim3((unsigned)total), dim3(kThreads),
                        lds, s, args, fill);
     SMM_HIP(hipGetLastError());
@@ -577,7 +595,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
     constexpr int NP = decltype(np_tag)::value;
-    constexpr bool NT = decltype(nt_tag)::value;
+    constexpr int NT = decltype(nt_tag)::value;
     hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NP, NT>), dim3((unsigned)total),
                        dim3(kThreads), lds, s, args, fill);
     SMM_HIP(hipGetLastError());
@@ -588,14 +606,28 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
     if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
     if (max_row_nnz <= 16) return fn(std::integral_constant<int, 16>());
     if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
-    return fail(SMM_ERR_UNSUPPORTED, "tile kernel supports at most 32 links per destination row");
+    return fn(std::integral_constant<int, 0>());  // long rows: links streamed from L2
   };
-  if (variant == 1 || np_needed > 16) return with_k(go1);
-  const bool nt = (variant != 2);  // default (0) and 3: non-temporal X loads / Y stores
+  if (variant == 1 || np_needed > 16) {
+    if (max_row_nnz > 32)
+      return fail(SMM_ERR_UNSUPPORTED, "unpipelined tile kernel supports at most 32 links per row");
+    return with_k(go1);
+  }
+  // variant 0: X loads non-temporal only if no staged line is shared between blocks
+  // (tile_reuse false), Y stores always non-temporal; 2: none; 3: both; 4: stores; 5: loads
+  int nt = tile_reuse ? 2 : 3;
+  if (variant == 2) nt = 0;
+  if (variant == 3) nt = 3;
+  if (variant == 4) nt = 2;
+  if (variant == 5) nt = 1;
   return with_k([&](auto k_tag) -> int {
     auto with_nt = [&](auto np_tag) -> int {
-      if (nt) return go2(k_tag, np_tag, std::true_type());
-      return go2(k_tag, np_tag, std::false_type());
+      switch (nt) {
+        case 0: return go2(k_tag, np_tag, std::integral_constant<int, 0>());
+        case 1: return go2(k_tag, np_tag, std::integral_constant<int, 1>());
+        case 2: return go2(k_tag, np_tag, std::integral_constant<int, 2>());
+        default: return go2(k_tag, np_tag, std::integral_constant<int, 3>());
+      }
     };
     if (np_needed <= 4) return with_nt(std::integral_constant<int, 4>());
     if (np_needed <= 8) return with_nt(std::integral_constant<int, 8>());
@@ -607,7 +639,8 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 // Common launch path for a single operator (descs = op->d_desc) or a group.
 int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t* d_lev_masked,
-              int64_t n_src, int64_t n_dst, bool tile_ok, bool tile_preferred, int64_t tile_max_chunks,
+              int64_t n_src, int64_t n_dst, bool tile_ok, bool tile_preferred, bool tile_reuse,
+              int64_t tile_max_chunks,
               int64_t max_row_nnz, const void* x, int x_dtype, int64_t xs_o, int64_t xs_l,
               int64_t xs_i, void* y, int y_dtype, int64_t ys_o, int64_t ys_l, int64_t ys_i,
               int64_t n_outer, int64_t n_lev, int64_t n_inner, double area_min, unsigned flags,
@@ -653,10 +686,9 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
     // 16-B staging loads need 16-B aligned batch rows
     const bool al = aligned16(x) && (xs_o * xsz) % 16 == 0 && (xs_l * xsz) % 16 == 0 &&
                     (xs_i * xsz) % 16 == 0;
-    if (!al || max_row_nnz > 32) {
+    if (!al) {
       if (flags & SMM_APPLY_KERNEL_TILE)
-        return fail(SMM_ERR_UNSUPPORTED,
-                    "tile kernel needs 16-byte aligned batch rows and <= 32 links per row");
+        return fail(SMM_ERR_UNSUPPORTED, "tile kernel needs 16-byte aligned batch rows");
       use_tile = false;
     }
   }
@@ -665,7 +697,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
   (x_dtype == SMM_F64                                                                \
        ? (y_dtype == SMM_F64 ? FN<double, double>(__VA_ARGS__) : FN<double, float>(__VA_ARGS__)) \
        : (y_dtype == SMM_F64 ? FN<float, double>(__VA_ARGS__) : FN<float, float>(__VA_ARGS__)))
-  if (use_tile) return SMM_DISPATCH(launch_tile, a, n_lev, tile_max_chunks, max_row_nnz, fill, flags, s);
+  if (use_tile) return SMM_DISPATCH(launch_tile, a, n_lev, tile_max_chunks, max_row_nnz, tile_reuse, fill, flags, s);
   return SMM_DISPATCH(launch_sell, a, n_lev, fill, s);
 #undef SMM_DISPATCH
 }
@@ -880,9 +912,9 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
       op->tile_max_chunks = plan.max_block_chunks;
       op->tile_total_chunks = plan.total_chunks;
       op->tile_total_distinct = plan.total_distinct;
+      op->tile_reuse = plan.total_chunks * 50 > plan.distinct_chunks * 51;  // > 2 % of lines staged twice
       // at least a quarter of every staged 128-B line is consumed, rows fit the register file
-      op->tile_preferred = plan.total_distinct * 4 >= plan.total_chunks * (int64_t)plan.chunk_elems &&
-                           op->csr.max_row_nnz <= 32;
+      op->tile_preferred = plan.total_distinct * 4 >= plan.total_chunks * (int64_t)plan.chunk_elems;
     }
     if ((rc = refresh_desc(op))) {
       release(op);
@@ -966,7 +998,7 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   DeviceGuard guard(op->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, op->tile_valid,
-                   op->tile_preferred, op->tile_max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
+                   op->tile_preferred, op->tile_reuse, op->tile_max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
 
@@ -998,7 +1030,7 @@ int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t
     cleanup();
     return fail(SMM_ERR_HIP, "hipMemcpy failed in smm_operator_mask_apply");
   }
-  rc = run_apply(op->d_desc, nullptr, nullptr, S, D, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
+  rc = run_apply(op->d_desc, nullptr, nullptr, S, D, false, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
                  std::max<int64_t>(S, 1), 0, 0, dy, SMM_F64, D, 0, 0, 1, 1, 1, 0.0,
                  SMM_APPLY_NO_FILL, nullptr);
   if (rc == SMM_OK) {
@@ -1037,6 +1069,7 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
     descs[(size_t)i] = ops[i]->desc();
     g->tile_valid = g->tile_valid && ops[i]->tile_valid;
     g->tile_preferred = g->tile_preferred && ops[i]->tile_preferred;
+    g->tile_reuse = g->tile_reuse || ops[i]->tile_reuse;
     g->tile_max_chunks = std::max(g->tile_max_chunks, ops[i]->tile_max_chunks);
     g->max_row_nnz = std::max(g->max_row_nnz, ops[i]->csr.max_row_nnz);
   }
@@ -1112,7 +1145,7 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
   const uint8_t* d_masked = masked_levels ? (const uint8_t*)d_cfg + map_bytes : nullptr;
   const smm_operator* op0 = g->ops[0];
   return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_valid,
-                   g->tile_preferred, g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
+                   g->tile_preferred, g->tile_reuse, g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
 }

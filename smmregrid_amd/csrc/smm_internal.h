@@ -55,6 +55,7 @@ struct HostTilePlan {
   int64_t max_block_chunks = 0;       // largest chunk count of any block
   int64_t total_chunks = 0;           // sum over blocks = staged lines per batch row
   int64_t total_distinct = 0;         // sum over blocks of distinct source cells referenced
+  int64_t distinct_chunks = 0;        // distinct source chunks over the whole operator
   std::vector<int64_t> blk_chunk_off; // n_blocks + 1 -> index into chunk_src
   std::vector<int32_t> chunk_src;     // source chunk index (element = idx * chunk_elems)
   std::vector<int32_t> lcol;          // per SELL slot: LDS element index (layout of HostSell.col)

@@ -356,3 +356,65 @@ def stack_level_weights(weights_list, levels, mask_dim="lev", method="con"):
             out = np.stack([w[name].values for w in weights_list], axis=0)
         ds[name] = ((mask_dim,) + tuple(v0.dims), out)
     return ds
+
+
+# --------------------------------------------------------------------------- masked levels
+
+class ConservativeLevels:
+    """Conservative weights for many land/sea masks of one grid pair: the
+    overlap geometry is computed once, each level only filters and normalises
+    (what the reference gets from one ``cdo -sellevidx,k`` run per level,
+    cdogenerate.py:179-228)."""
+
+    def __init__(self, src, dst):
+        self.src, self.dst = parse_grid(src), parse_grid(dst)
+        if self.src.kind != "regular" or self.dst.kind != "regular":
+            raise ValueError("conservative generation needs regular source and destination grids")
+        nx, mx = self.src.lon.size, self.dst.lon.size
+        ld, ls, lw = _overlap_1d(self.src.lon_b, self.dst.lon_b, periodic=360.0)
+        td, ts, tw = _overlap_1d(np.sin(self.src.lat_b * DEG), np.sin(self.dst.lat_b * DEG))
+        dst_addr = (td[:, None] * mx + ld[None, :]).ravel()
+        src_addr = (ts[:, None] * nx + ls[None, :]).ravel()
+        area = (tw[:, None] * (lw[None, :] * DEG)).ravel()
+        order = np.lexsort((src_addr, dst_addr))
+        self.dst_addr, self.src_addr, self.area = dst_addr[order], src_addr[order], area[order]
+        self.dst_area = (np.diff(np.sin(self.dst.lat_b * DEG))[:, None] *
+                         (np.diff(self.dst.lon_b) * DEG)[None, :]).ravel()
+
+    def level(self, src_mask=None, norm="fracarea"):
+        dst_addr, src_addr, area = self.dst_addr, self.src_addr, self.area
+        imask = None
+        if src_mask is not None:
+            imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+            keep = imask[src_addr] != 0
+            dst_addr, src_addr, area = dst_addr[keep], src_addr[keep], area[keep]
+        covered = np.bincount(dst_addr, weights=area, minlength=self.dst.size)
+        frac = covered / self.dst_area
+        w = area / (covered[dst_addr] if norm == "fracarea" else self.dst_area[dst_addr])
+        return _scrip_dataset(self.src, self.dst, src_addr + 1, dst_addr + 1, w, "con",
+                              src_imask=imask, dst_frac=frac, dst_area=self.dst_area, norm=norm)
+
+    def stack(self, masks, levels, mask_dim="lev"):
+        return stack_level_weights([self.level(m) for m in masks], levels, mask_dim=mask_dim,
+                                   method="con")
+
+
+def synthetic_ocean_masks(nx, ny, n_lev, seed=20260723, top=0.66, bottom=0.05):
+    """Depth-dependent land/sea masks (n_lev, ny*nx) for benchmarks: a smooth random
+    bathymetry thresholded so the ocean fraction falls monotonically from `top`
+    at level 0 to `bottom` at the deepest level, deeper oceans nested in shallower ones."""
+    rng = np.random.default_rng(seed)
+    cy, cx = max(ny // 24, 4), max(nx // 24, 4)
+    coarse = rng.standard_normal((cy, cx))
+    yi = np.linspace(0, cy - 1, ny)
+    xi = np.linspace(0, cx - 1, nx)
+    y0 = np.clip(np.floor(yi).astype(int), 0, cy - 2)
+    x0 = np.clip(np.floor(xi).astype(int), 0, cx - 2)
+    fy = (yi - y0)[:, None]
+    fx = (xi - x0)[None, :]
+    b = ((1 - fy) * (1 - fx) * coarse[y0][:, x0] + (1 - fy) * fx * coarse[y0][:, x0 + 1] +
+         fy * (1 - fx) * coarse[y0 + 1][:, x0] + fy * fx * coarse[y0 + 1][:, x0 + 1])
+    b += 0.05 * rng.standard_normal((ny, nx))
+    fracs = np.linspace(top, bottom, n_lev) if n_lev > 1 else np.array([top])
+    thr = np.quantile(b, 1.0 - fracs)
+    return (b.ravel()[None, :] > thr[:, None]).astype(np.int32)

@@ -32,10 +32,10 @@ KERNELS = [("sell", _lib.APPLY_KERNEL_SELL), ("tile", _lib.APPLY_KERNEL_TILE)]
 
 
 def need_kernel(op, kname):
-    """Skip a tile-kernel case when the operator has no LDS plan or rows longer than 32 links
-    (the library refuses the forced flag there, see test_long_rows_use_sell_and_tile_refuses)."""
+    """Skip a tile-kernel case when the operator has no LDS plan (a block's source
+    footprint exceeds the LDS budget): the library refuses the forced flag there."""
     ops = op if isinstance(op, (list, tuple)) else [op]
-    if kname == "tile" and any((not o.plan_info()["tile_plan"]) or o.max_row_nnz > 32 for o in ops):
+    if kname == "tile" and any(not o.plan_info()["tile_plan"] for o in ops):
         pytest.skip("tile kernel not applicable to this operator")
 
 
@@ -114,17 +114,16 @@ def test_apply_ragged_rows(hip, rng, kname, kflag):
     assert_same(y, oracle.apply_c(csr, x), exact=True)
 
 
-def test_long_rows_use_sell_and_tile_refuses(hip, rng):
-    n_src, n_dst = 2000, 100
+@pytest.mark.parametrize("kname,kflag", KERNELS)
+def test_long_rows(hip, rng, kname, kflag):
+    # rows longer than 32 links: the tile kernel streams the links from L2 instead of registers
+    n_src, n_dst = 2000, 300
     src, dst, w = ragged_links(rng, n_src, n_dst, max_len=120)
     op = make_op(n_src, n_dst, src, dst, w)
     assert op.max_row_nnz > 32
-    x = field(rng, 4, n_src)
-    assert_same(run(op, x), oracle.apply_c(op.export_csr(), x), exact=True)
-    if op.plan_info()["tile_plan"]:
-        with pytest.raises(_lib.SmmError) as e:
-            run(op, x, flags=_lib.APPLY_KERNEL_TILE)
-        assert e.value.code == _lib.SMM_ERR_UNSUPPORTED
+    need_kernel(op, kname)
+    x = field(rng, 5, n_src, nan_frac=0.02)
+    assert_same(run(op, x, flags=kflag), oracle.apply_c(op.export_csr(), x), exact=True)
 
 
 def test_odd_source_size_f64_rows_not_16B_aligned(hip, rng):
