@@ -117,6 +117,10 @@ void build_sell(const HostCsr& csr, HostSell& out) {
       out.col[(size_t)(base + (int64_t)k * 64)] = csr.col[(size_t)(p0 + k)];
       out.val[(size_t)(base + (int64_t)k * 64)] = csr.val[(size_t)(p0 + k)];
     }
+    // padding slots of the slice repeat the row's last column (a cached, valid address)
+    const int64_t nslots = (out.slice_off[(size_t)s + 1] - out.slice_off[(size_t)s]) / 64;
+    const int32_t padcol = len > 0 ? csr.col[(size_t)(p0 + len - 1)] : 0;
+    for (int64_t k = len; k < nslots; ++k) out.col[(size_t)(base + k * 64)] = padcol;
   }
 }
 

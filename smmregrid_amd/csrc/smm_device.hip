@@ -156,18 +156,21 @@ __global__ __launch_bounds__(kThreads) void smm_apply_sell_kernel(ApplyArgs a, b
 #pragma unroll
   for (int t = 0; t < BT; ++t) acc[t] = 0.0;
 
+  // Padded slots carry a valid column (the row's last one) and are masked out of the
+  // sum by a select, so the loop body is branch-free and two slots are in flight.
+#pragma unroll 2
   for (int k = 0; k < nslots; ++k) {
     const int32_t c = cp[(int64_t)k * 64];
     const double w = vp[(int64_t)k * 64];
-    if (k < len) {
-      double xv[BT];
+    const bool on = k < len;
+    double xv[BT];
 #pragma unroll
-      for (int t = 0; t < BT; ++t) xv[t] = load_fixed(xr[t] + c, fill);
+    for (int t = 0; t < BT; ++t) xv[t] = load_fixed(xr[t] + c, fill);
 #pragma unroll
-      for (int t = 0; t < BT; ++t) {
-        const double p = w * xv[t];
-        acc[t] = acc[t] + p;
-      }
+    for (int t = 0; t < BT; ++t) {
+      const double p = w * xv[t];
+      const double s = acc[t] + p;
+      acc[t] = on ? s : acc[t];
     }
   }
 
@@ -586,7 +589,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
   const int np_needed = (int)((max_pieces + kThreads - 1) / kThreads);
 
   auto go1 = [&](auto k_tag) -> int {  // variant 1: unpipelined staging loop (never reached with 0)
-    constexpr int MAXK = decltype(k_tag)::value > 0 ? decltype(k_tag)::value : 32;
+    constexpr int MAXK = (decltype(k_tag)::value > 0 && decltype(k_tag)::value <= 32) ? decltype(k_tag)::value : 32;
     hipLaunchKernelGGL((smm_apply_tile_kernel<XT, YT, MAXK>), dim3((unsigned)total), dim3(kThreads),
                        lds, s, args, fill);
     SMM_HIP(hipGetLastError());
@@ -606,7 +609,8 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
     if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
     if (max_row_nnz <= 16) return fn(std::integral_constant<int, 16>());
     if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
-    return fn(std::integral_constant<int, 0>());  // long rows: links streamed from L2
+    if (max_row_nnz <= 48) return fn(std::integral_constant<int, 48>());
+    return fn(std::integral_constant<int, 0>());  // longer rows: links streamed from L2
   };
   if (variant == 1 || np_needed > 16) {
     if (max_row_nnz > 32)
