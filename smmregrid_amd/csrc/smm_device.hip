@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile_kernel(ApplyArgs a, b
 // index load sits in front of a data load.  NT bit 0: non-temporal X loads (only
 // when no staged line is shared between blocks), bit 1: non-temporal Y stores.
 template <typename XT, typename YT, int MAXK, int NP, int NT>
-__global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
+__global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -308,9 +308,10 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
 
   // MAXK > 0: the row's links live in registers across batch rows;
   // MAXK == 0 (rows longer than 32 links): they are re-read per batch row (L2 hits).
-  constexpr int KREG = MAXK > 0 ? MAXK : 1;
+  // LDS indices are < 8192 (512 chunks of 16 elements): two per register.
+  constexpr int KREG = MAXK > 0 ? MAXK : 2;
   int len = 0;
-  int32_t lc[KREG];
+  uint32_t lc2[KREG / 2];
   double w[KREG];
   const int32_t* __restrict__ cp = nullptr;
   const double* __restrict__ vp = nullptr;
@@ -321,13 +322,20 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
     vp = L.val + off + lane;
     if (MAXK > 0) {
 #pragma unroll
-      for (int k = 0; k < KREG; ++k) {
-        const bool on = k < len;
-        lc[k] = on ? cp[(int64_t)k * 64] : 0;
-        w[k] = on ? vp[(int64_t)k * 64] : 0.0;
+      for (int k = 0; k < KREG; k += 2) {
+        const uint32_t c0 = (k < len) ? (uint32_t)cp[(int64_t)k * 64] : 0u;
+        const uint32_t c1 = (k + 1 < len) ? (uint32_t)cp[(int64_t)(k + 1) * 64] : 0u;
+        lc2[k / 2] = c0 | (c1 << 16);
+        w[k] = (k < len) ? vp[(int64_t)k * 64] : 0.0;
+        w[k + 1] = (k + 1 < len) ? vp[(int64_t)(k + 1) * 64] : 0.0;
       }
     }
   }
+  // wave-uniform trip counts: longest row of this wave, pieces owned by its lanes
+  int wmax = len;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
+  wmax = __builtin_amdgcn_readfirstlane(wmax);
   bool dead = false;
   if (row_live) {
     const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
@@ -343,6 +351,9 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
   const int npieces = nch * pieces_per_chunk;
   const XT* lds_x = (const XT*)smem;
 
+  // pieces [wave*64 + k*256, +64) belong to this wave in round k: rounds that can hold any
+  const int np_w = __builtin_amdgcn_readfirstlane(
+      npieces > wave * 64 ? (npieces - wave * 64 + kThreads - 1) / kThreads : 0);
   // this thread's pieces: element offset inside a batch row, -1 = none
   int32_t poff[NP];
   unsigned clipped = 0;
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
     const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      if (poff[k] >= 0) {
+      if (k < np_w && poff[k] >= 0) {
         if (!((clipped >> k) & 1u)) {
           const u32x4* src = (const u32x4*)(xrow + poff[k]);
           v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
@@ -389,19 +400,27 @@ __global__ __launch_bounds__(kThreads) void smm_apply_tile2_kernel(ApplyArgs a, 
   load_row(j_begin);
   for (int64_t j = j_begin; j < j_end; ++j) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k)
-      if (poff[k] >= 0) *(u32x4*)(smem + (size_t)(tid + k * kThreads) * 16) = v[k];
+    for (int k = 0; k < NP; ++k) {
+      if (k < np_w && poff[k] >= 0) *(u32x4*)(smem + (size_t)(tid + k * kThreads) * 16) = v[k];
+    }
     __syncthreads();
     if (j + 1 < j_end) load_row(j + 1);
     if (row_live) {
       double acc = 0.0;
       if (MAXK > 0) {
 #pragma unroll
-        for (int k = 0; k < KREG; ++k) {
-          if (k < len) {
-            const double xv = load_fixed(lds_x + lc[k], fill);
-            const double p = w[k] * xv;
-            acc = acc + p;
+        for (int k0 = 0; k0 < KREG; k0 += 4) {
+          if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int k = k0 + kk;
+              if (k < KREG && k < len) {
+                const uint32_t li = (k & 1) ? (lc2[k / 2] >> 16) : (lc2[k / 2] & 0xFFFFu);
+                const double xv = load_fixed(lds_x + li, fill);
+                const double p = w[k] * xv;
+                acc = acc + p;
+              }
+            }
           }
         }
       } else {
