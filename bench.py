@@ -40,6 +40,12 @@ WORKLOADS = {
     "cfg2": ("bil", "r1440x721", "r360x180", 3600, "f64"),
     "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
     "cfg1": ("bil", "r180x90", "r90x45", 1, "f64"),
+    # config-4 geometry (n1280-like regular Gaussian 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch
+    "cfg4s": ("bil", "r5120x2560", "hp1024", 128, "f32"),
+    # one masked level of config 3 as a 2-D problem (ocean fraction in the name), for kernel tuning
+    "cfg3L66": ("conmask", (1442, 1021, 0.66), "r360x180", 1024, "f64"),
+    "cfg3L35": ("conmask", (1442, 1021, 0.35), "r360x180", 1024, "f64"),
+    "cfg3L05": ("conmask", (1442, 1021, 0.05), "r360x180", 1024, "f64"),
     # masked levels: (method, source nx x ny, target, (time steps, levels), x dtype)
     "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
     "cfg3s": ("con3d", (1442, 1021), "r360x180", (16, 8), "f64"),
@@ -79,7 +85,13 @@ class Problem2D:
         from smmregrid_amd.device import DeviceArray
         method, sgrid, tgrid, n_batch, self.x_dtype = WORKLOADS[name]
         self.n_batch = batch or n_batch
-        self.weights = gridgen.generate_weights(sgrid, tgrid, method=method)
+        if method == "conmask":
+            nx, ny, frac = sgrid
+            mask = gridgen.synthetic_ocean_masks(nx, ny, 1, top=frac)[0]
+            self.weights = gridgen.conservative_weights(gridgen.regular_grid(nx, ny), tgrid, src_mask=mask)
+            sgrid = f"{nx}x{ny} ocean {frac}"
+        else:
+            self.weights = gridgen.generate_weights(sgrid, tgrid, method=method)
         w = self.weights
         self.n_src, self.n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
         self.op = SparseOperator(self.n_src, self.n_dst, w["src_address"].values,

@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmmregrid_hip.so")
+LIB_PATH = os.environ.get("SMM_LIB_PATH") or os.path.join(_HERE, "libsmmregrid_hip.so")
 
 SMM_OK = 0
 SMM_ERR_INVALID = 1

@@ -90,8 +90,11 @@ struct ApplyArgs {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
-constexpr int kChunkElems = 16;          // staged chunk: 128 B of f64, 64 B of f32
-constexpr int64_t kTileMaxChunks = 512;  // 64 KiB of f64 per staged batch row
+#ifndef SMM_CHUNK_ELEMS
+#define SMM_CHUNK_ELEMS 16
+#endif
+constexpr int kChunkElems = SMM_CHUNK_ELEMS;               // staged chunk: 128 B of f64, 64 B of f32
+constexpr int64_t kTileMaxChunks = 8192 / SMM_CHUNK_ELEMS;  // 64 KiB of f64 per staged batch row
 
 template <typename T>
 __device__ __forceinline__ double load_fixed(const T* __restrict__ p, bool fill) {
@@ -192,102 +195,19 @@ __global__ __launch_bounds__(kThreads) void smm_apply_sell_kernel(ApplyArgs a, b
 // block's source chunks (whole 128-B lines, list order) into LDS with
 // 16-B-per-lane coalesced loads -- every needed HBM line is fetched exactly
 // once by a full-width access -- then each lane gathers its row's links from
-// LDS.  The links (LDS index + weight) stay in registers across batch rows.
-template <typename XT, typename YT, int MAXK>
-__global__ __launch_bounds__(kThreads) void smm_apply_tile_kernel(ApplyArgs a, bool fill) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  int64_t bid = blockIdx.x;
-  const int64_t db = bid % a.n_dblocks;
-  bid /= a.n_dblocks;
-  const int64_t jt = bid % a.n_jtiles;
-  const int64_t l = bid / a.n_jtiles;
-  const int di = a.lev_map ? a.lev_map[l] : 0;
-  const LevelDesc L = a.descs[di];
-
-  const int64_t slice = db * kWavesPerBlock + wave;
-  const int64_t d = slice * 64 + lane;
-  const bool wave_live = slice * 64 < a.n_dst;
-
-  // links of this lane's row -> registers
-  int len = 0;
-  int32_t lc[MAXK];
-  double w[MAXK];
-  if (wave_live) {
-    const int64_t off = L.slice_off[slice];
-    len = L.rowlen[d];
-    const int32_t* __restrict__ cp = L.lcol + off + lane;
-    const double* __restrict__ vp = L.val + off + lane;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const bool on = k < len;
-      lc[k] = on ? cp[(int64_t)k * 64] : 0;
-      w[k] = on ? vp[(int64_t)k * 64] : 0.0;
-    }
-  }
-  bool dead = false;
-  if (wave_live && d < a.n_dst) {
-    const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
-    if (use_mask && L.imask) dead = (L.imask[d] == 0);
-    if (a.area_min > 0.0 && L.frac) dead = dead || (L.frac[d] < a.area_min);
-  }
-
-  const int64_t c0 = L.blk_chunk_off[db];
-  const int nch = (int)(L.blk_chunk_off[db + 1] - c0);
-  const int32_t* __restrict__ chunk_src = L.chunk_src + c0;
-  constexpr int kElemsPerPiece = 16 / (int)sizeof(XT);
-  constexpr int pieces_per_chunk = kChunkElems / kElemsPerPiece;
-  const int npieces = nch * pieces_per_chunk;
-  const XT* lds_x = (const XT*)smem;
-
-  const int64_t j_begin = jt * a.j_per_block;
-  int64_t j_end = j_begin + a.j_per_block;
-  if (j_end > a.n_j) j_end = a.n_j;
-
-  for (int64_t j = j_begin; j < j_end; ++j) {
-    const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
-    // stage: piece p = (chunk p / ppc, sub-piece p % ppc) -> LDS byte p * 16
-    for (int p = tid; p < npieces; p += kThreads) {
-      const int ch = p / pieces_per_chunk;
-      const int sub = p - ch * pieces_per_chunk;
-      const int64_t e0 = (int64_t)chunk_src[ch] * kChunkElems + (int64_t)sub * kElemsPerPiece;
-      uint4 v;
-      if (e0 + kElemsPerPiece <= a.n_src) {
-        v = *(const uint4*)(xrow + e0);
-      } else {
-        XT tmp[kElemsPerPiece];
-#pragma unroll
-        for (int e = 0; e < kElemsPerPiece; ++e) tmp[e] = (e0 + e < a.n_src) ? xrow[e0 + e] : (XT)0;
-        __builtin_memcpy(&v, tmp, 16);
-      }
-      *(uint4*)(smem + (size_t)p * 16) = v;
-    }
-    __syncthreads();
-    if (wave_live && d < a.n_dst) {
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < MAXK; ++k) {
-        if (k < len) {
-          const double xv = load_fixed(lds_x + lc[k], fill);
-          const double p = w[k] * xv;
-          acc = acc + p;
-        }
-      }
-      YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
-      yrow[d] = (YT)epilogue(acc, dead);
-    }
-    __syncthreads();
-  }
-}
-
+// LDS.
+//
 // Kernel B, pipelined form.  Each thread owns up to NP staging pieces whose row
 // offsets are computed once (they do not depend on the batch row), keeps the
 // next batch row's pieces in registers while the current one is consumed from
 // LDS, so the HBM latency of row j+1 overlaps the gather/store of row j and no
-// index load sits in front of a data load.  NT bit 0: non-temporal X loads (only
-// when no staged line is shared between blocks), bit 1: non-temporal Y stores.
+// index load sits in front of a data load.  Every global / LDS load in the loop
+// is unconditional (clamped address + select): a load inside a per-lane branch
+// makes hipcc wait for it before the next one, which serialises the memory
+// round trips.  NT bit 0: non-temporal X loads (only when no staged line is
+// shared between blocks), bit 1: non-temporal Y stores.
+typedef u32x4 u32x4_u __attribute__((aligned(4)));  // 16-B piece that may start on any element
+
 template <typename XT, typename YT, int MAXK, int NP, int NT>
 __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -302,40 +222,49 @@ __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs 
   const int di = a.lev_map ? a.lev_map[l] : 0;
   const LevelDesc L = a.descs[di];
 
-  const int64_t slice = db * kWavesPerBlock + wave;
+  const int64_t slice = db * kWavesPerBlock + wave;   // always < n_slices: n_dblocks * 4 slices are padded
   const int64_t d = slice * 64 + lane;
   const bool row_live = d < a.n_dst;
+  const bool slice_live = slice * 64 < a.n_dst;
 
-  // MAXK > 0: the row's links live in registers across batch rows;
-  // MAXK == 0 (rows longer than 32 links): they are re-read per batch row (L2 hits).
-  // LDS indices are < 8192 (512 chunks of 16 elements): two per register.
+  // MAXK > 0: the row's links live in registers across batch rows (LDS indices are
+  // < 8192, two per register); MAXK == 0 (rows longer than 48 links): re-read per row.
   constexpr int KREG = MAXK > 0 ? MAXK : 2;
-  int len = 0;
+  int len = 0, nslots = 0;
   uint32_t lc2[KREG / 2];
   double w[KREG];
-  const int32_t* __restrict__ cp = nullptr;
-  const double* __restrict__ vp = nullptr;
-  if (row_live) {
-    const int64_t off = L.slice_off[slice];
+  int64_t soff = 0;
+  if (slice_live) {
+    soff = L.slice_off[slice];
+    nslots = (int)((L.slice_off[slice + 1] - soff) >> 6);
     len = L.rowlen[d];
-    cp = L.lcol + off + lane;
-    vp = L.val + off + lane;
-    if (MAXK > 0) {
+  }
+  const int32_t* __restrict__ cp = L.lcol + soff + lane;   // global pointers on every path
+  const double* __restrict__ vp = L.val + soff + lane;
+  if (MAXK > 0 && nslots > 0) {  // wave-uniform; loads unconditional, slots past the slice clamp
 #pragma unroll
-      for (int k = 0; k < KREG; k += 2) {
-        const uint32_t c0 = (k < len) ? (uint32_t)cp[(int64_t)k * 64] : 0u;
-        const uint32_t c1 = (k + 1 < len) ? (uint32_t)cp[(int64_t)(k + 1) * 64] : 0u;
-        lc2[k / 2] = c0 | (c1 << 16);
-        w[k] = (k < len) ? vp[(int64_t)k * 64] : 0.0;
-        w[k + 1] = (k + 1 < len) ? vp[(int64_t)(k + 1) * 64] : 0.0;
-      }
+    for (int k = 0; k < KREG; k += 2) {
+      const int k0 = min(k, nslots - 1), k1 = min(k + 1, nslots - 1);
+      const uint32_t c0 = (uint32_t)cp[(int64_t)k0 * 64];
+      const uint32_t c1 = (uint32_t)cp[(int64_t)k1 * 64];
+      lc2[k / 2] = (k < len ? c0 : 0u) | ((k + 1 < len ? c1 : 0u) << 16);
+      w[k] = vp[(int64_t)k0 * 64];
+      w[k + 1] = vp[(int64_t)k1 * 64];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KREG; k += 2) {
+      lc2[k / 2] = 0u;
+      w[k] = 0.0;
+      w[k + 1] = 0.0;
     }
   }
-  // wave-uniform trip counts: longest row of this wave, pieces owned by its lanes
+  // wave-uniform trip count: longest row of this wave
   int wmax = len;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
   wmax = __builtin_amdgcn_readfirstlane(wmax);
+
   bool dead = false;
   if (row_live) {
     const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
@@ -351,26 +280,37 @@ __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs 
   const int npieces = nch * pieces_per_chunk;
   const XT* lds_x = (const XT*)smem;
 
-  // pieces [wave*64 + k*256, +64) belong to this wave in round k: rounds that can hold any
+  // Pieces [wave*64 + k*256, +64) belong to this wave in round k.  poff = element offset of
+  // the piece inside a batch row (clamped so that the 16-B load stays inside the row),
+  // shift = elements by which the clamp moved it (non-zero only for the row's last piece),
+  // pvalid bit k = the piece exists.
   const int np_w = __builtin_amdgcn_readfirstlane(
       npieces > wave * 64 ? (npieces - wave * 64 + kThreads - 1) / kThreads : 0);
-  // this thread's pieces: element offset inside a batch row, -1 = none
   int32_t poff[NP];
-  unsigned clipped = 0;
+  unsigned pvalid = 0, shifted = 0;
+  int shift_amt = 0;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
     const int p = tid + k * kThreads;
-    poff[k] = -1;
-    if (p < npieces) {
-      const int ch = p / pieces_per_chunk;
-      const int sub = p - ch * pieces_per_chunk;
-      const int64_t e0 = (int64_t)chunk_src[ch] * kChunkElems + (int64_t)sub * kElemsPerPiece;
-      if (e0 < a.n_src) {
+    poff[k] = 0;
+    if (k < np_w) {
+      const int pc = min(p, npieces - 1);
+      const int ch = pc / pieces_per_chunk;
+      const int sub = pc - ch * pieces_per_chunk;
+      int64_t e0 = (int64_t)chunk_src[ch] * kChunkElems + (int64_t)sub * kElemsPerPiece;
+      if (p < npieces && e0 < a.n_src) {
+        pvalid |= 1u << k;
+        if (e0 + kElemsPerPiece > a.n_src) {
+          const int64_t e1 = a.n_src >= kElemsPerPiece ? a.n_src - kElemsPerPiece : 0;
+          shifted |= 1u << k;
+          shift_amt = (int)(e0 - e1);
+          e0 = e1;
+        }
         poff[k] = (int32_t)e0;
-        if (e0 + kElemsPerPiece > a.n_src) clipped |= 1u << k;
       }
     }
   }
+  const bool tiny_row = a.n_src < kElemsPerPiece;  // cannot happen with a planned operator of >= 1 chunk
 
   const int64_t j_begin = jt * a.j_per_block;
   int64_t j_end = j_begin + a.j_per_block;
@@ -382,61 +322,99 @@ __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs 
     const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-      if (k < np_w && poff[k] >= 0) {
-        if (!((clipped >> k) & 1u)) {
-          const u32x4* src = (const u32x4*)(xrow + poff[k]);
-          v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
-        } else {
-          XT tmp[kElemsPerPiece];
+      if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
+        const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
+        v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+  };
+  auto store_tile = [&]() {
 #pragma unroll
-          for (int e = 0; e < kElemsPerPiece; ++e)
-            tmp[e] = ((int64_t)poff[k] + e < a.n_src) ? xrow[poff[k] + e] : (XT)0;
-          __builtin_memcpy(&v[k], tmp, 16);
+    for (int k = 0; k < NP; ++k) {
+      if (k < np_w) {
+        u32x4 piece = v[k];
+        if ((shifted >> k) & 1u) {  // last piece of the row: move the valid tail to the front
+          XT tmp[2 * kElemsPerPiece];
+          __builtin_memcpy(tmp, &piece, 16);
+#pragma unroll
+          for (int e = 0; e < kElemsPerPiece; ++e) tmp[kElemsPerPiece + e] = (XT)0;
+          XT out[kElemsPerPiece];
+#pragma unroll
+          for (int e = 0; e < kElemsPerPiece; ++e) {
+            XT val = (XT)0;
+#pragma unroll
+            for (int q = 0; q < kElemsPerPiece; ++q)
+              if (q == e + shift_amt) val = tmp[q];
+            out[e] = val;
+          }
+          __builtin_memcpy(&piece, out, 16);
         }
+        if ((pvalid >> k) & 1u) *(u32x4*)(smem + (size_t)(tid + k * kThreads) * 16) = piece;
       }
     }
   };
 
-  load_row(j_begin);
-  for (int64_t j = j_begin; j < j_end; ++j) {
+#ifndef SMM_EXP_SKIP_STAGE
+  if (!tiny_row) load_row(j_begin);
+#else
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      if (k < np_w && poff[k] >= 0) *(u32x4*)(smem + (size_t)(tid + k * kThreads) * 16) = v[k];
-    }
+  for (int k = 0; k < NP; ++k) v[k] = u32x4{0, 0, 0, 0};
+#endif
+  for (int64_t j = j_begin; j < j_end; ++j) {
+    store_tile();
     __syncthreads();
-    if (j + 1 < j_end) load_row(j + 1);
-    if (row_live) {
+#ifndef SMM_EXP_SKIP_STAGE
+    if (j + 1 < j_end && !tiny_row) load_row(j + 1);
+#endif
+    if (slice_live) {
       double acc = 0.0;
+#ifdef SMM_EXP_SKIP_COMPUTE
+      if (false) {
+#else
       if (MAXK > 0) {
+#endif
 #pragma unroll
         for (int k0 = 0; k0 < KREG; k0 += 4) {
           if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static
+            double xv[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
               const int k = k0 + kk;
-              if (k < KREG && k < len) {
-                const uint32_t li = (k & 1) ? (lc2[k / 2] >> 16) : (lc2[k / 2] & 0xFFFFu);
-                const double xv = load_fixed(lds_x + li, fill);
-                const double p = w[k] * xv;
-                acc = acc + p;
+              const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
+                                          : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
+              xv[kk] = load_fixed(lds_x + li, fill);  // unconditional: index 0 for unused slots
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int k = k0 + kk;
+              if (k < KREG) {
+                const double p = w[k] * xv[kk];
+                const double sum = acc + p;
+                acc = (k < len) ? sum : acc;
               }
             }
           }
         }
       } else {
 #pragma unroll 4
-        for (int k = 0; k < len; ++k) {
-          const double xv = load_fixed(lds_x + cp[(int64_t)k * 64], fill);
-          const double p = vp[(int64_t)k * 64] * xv;
-          acc = acc + p;
+        for (int k = 0; k < wmax; ++k) {
+          const int kc = min(k, nslots - 1);
+          const bool on = k < len;
+          const int32_t li = cp[(int64_t)kc * 64];
+          const double xv = load_fixed(lds_x + (on ? li : 0), fill);
+          const double p = vp[(int64_t)kc * 64] * xv;
+          const double sum = acc + p;
+          acc = on ? sum : acc;
         }
       }
-      YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
-      const YT out = (YT)epilogue(acc, dead);
-      if (NT & 2)
-        __builtin_nontemporal_store(out, yrow + d);
-      else
-        yrow[d] = out;
+      if (row_live) {
+        YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+        const YT out = (YT)epilogue(acc, dead);
+        if (NT & 2)
+          __builtin_nontemporal_store(out, yrow + d);
+        else
+          yrow[d] = out;
+      }
     }
     __syncthreads();
   }
@@ -607,13 +585,6 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
   const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
   const int np_needed = (int)((max_pieces + kThreads - 1) / kThreads);
 
-  auto go1 = [&](auto k_tag) -> int {  // variant 1: unpipelined staging loop (never reached with 0)
-    constexpr int MAXK = (decltype(k_tag)::value > 0 && decltype(k_tag)::value <= 32) ? decltype(k_tag)::value : 32;
-    hipLaunchKernelGGL((smm_apply_tile_kernel<XT, YT, MAXK>), dim3((unsigned)total), dim3(kThreads),
-                       lds, s, args, fill);
-    SMM_HIP(hipGetLastError());
-    return SMM_OK;
-  };
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
     constexpr int NP = decltype(np_tag)::value;
@@ -631,11 +602,8 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
     if (max_row_nnz <= 48) return fn(std::integral_constant<int, 48>());
     return fn(std::integral_constant<int, 0>());  // longer rows: links streamed from L2
   };
-  if (variant == 1 || np_needed > 16) {
-    if (max_row_nnz > 32)
-      return fail(SMM_ERR_UNSUPPORTED, "unpipelined tile kernel supports at most 32 links per row");
-    return with_k(go1);
-  }
+  if (np_needed > 16)
+    return fail(SMM_ERR_UNSUPPORTED, "tile plan exceeds the staging register budget");
   // variant 0: X loads non-temporal only if no staged line is shared between blocks
   // (tile_reuse false), Y stores always non-temporal; 2: none; 3: both; 4: stores; 5: loads
   int nt = tile_reuse ? 2 : 3;

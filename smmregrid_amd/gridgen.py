@@ -229,11 +229,12 @@ def bilinear_weights(src, dst):
     j1 = np.clip(np.searchsorted(src.lat, lat, side="right"), 1, ny - 1)
     j0 = j1 - 1
     fy = np.clip((lat - src.lat[j0]) / (src.lat[j1] - src.lat[j0]), 0.0, 1.0)
-    d = np.arange(lon.size, dtype=np.int64)
-    src_addr = np.stack([j0 * nx + i0, j0 * nx + i1, j1 * nx + i0, j1 * nx + i1], axis=1).ravel() + 1
-    w = np.stack([(1 - fx) * (1 - fy), fx * (1 - fy), (1 - fx) * fy, fx * fy], axis=1).ravel()
-    dst_addr = np.repeat(d, 4) + 1
-    src_addr, dst_addr, w = _sort_links(src_addr, dst_addr, w)
+    src4 = np.stack([j0 * nx + i0, j0 * nx + i1, j1 * nx + i0, j1 * nx + i1], axis=1)
+    w4 = np.stack([(1 - fx) * (1 - fy), fx * (1 - fy), (1 - fx) * fy, fx * fy], axis=1)
+    order = np.argsort(src4, axis=1, kind="stable")      # links sorted by (dst, src) as CDO stores them
+    src_addr = (np.take_along_axis(src4, order, axis=1).ravel() + 1).astype(np.int32)
+    w = np.take_along_axis(w4, order, axis=1).ravel()
+    dst_addr = np.repeat(np.arange(1, lon.size + 1, dtype=np.int32), 4)
     return _scrip_dataset(src, dst, src_addr, dst_addr, w, "bil")
 
 

@@ -31,7 +31,12 @@ def main():
     args = ap.parse_args()
     method, sgrid, tgrid, n_batch, x_dtype = WORKLOADS[args.workload]
     n_batch = args.batch or n_batch
-    w = gridgen.generate_weights(sgrid, tgrid, method=method)
+    if method == "conmask":
+        nx, ny, frac = sgrid
+        mask = gridgen.synthetic_ocean_masks(nx, ny, 1, top=frac)[0]
+        w = gridgen.conservative_weights(gridgen.regular_grid(nx, ny), tgrid, src_mask=mask)
+    else:
+        w = gridgen.generate_weights(sgrid, tgrid, method=method)
     n_src, n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
     op = SparseOperator(n_src, n_dst, w["src_address"].values, w["dst_address"].values,
                         w["remap_matrix"].values, device=0)
