@@ -170,6 +170,20 @@ int smm_apply(smm_operator_t op,
               int64_t n_batch, double remap_area_min, unsigned flags, void* stream);
 
 /*
+ * Same product for fields in HOST memory (what Regridder.apply_weights receives,
+ * regrid.py:537-541): the batch rows are cut into chunks that flow through a
+ * double-buffered pipeline -- copy into pinned staging (skipped for pinned
+ * buffers, e.g. from smm_host_alloc), H2D, kernel, D2H -- on two streams, so
+ * transfers of one chunk overlap the kernel of the other.  Synchronous: Y is
+ * complete on return.  chunk_rows <= 0 picks ~256 MiB of X per chunk.
+ * This path is PCIe-bound (about 100x below the device-resident rate).
+ */
+int smm_apply_host(smm_operator_t op,
+                   const void* x_host, int x_dtype, int64_t ldx,
+                   void* y_host, int y_dtype, int64_t ldy,
+                   int64_t n_batch, double remap_area_min, unsigned flags, int64_t chunk_rows);
+
+/*
  * Masked-level apply (regrid.py:387-418 in one launch).  The kept dims of the
  * field are viewed as (n_outer, n_lev, n_inner) around the mask dimension;
  * data level l uses group member level_index[l] (host int32[n_lev], result of

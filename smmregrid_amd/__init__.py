@@ -4,10 +4,10 @@ from .regrid import Regridder, regrid
 from .cdogenerate import CdoGenerate, cdo_generate_weights
 from .gridtype import GridType
 from .operator import SparseOperator, OperatorGroup
-from .device import DeviceArray, to_device
+from .device import DeviceArray, pinned_empty, to_device
 from .xrlite import DataArray, Dataset
 
 __version__ = '0.1.0'
 
 __all__ = ["Regridder", "regrid", "CdoGenerate", "cdo_generate_weights", "GridType",
-           "SparseOperator", "OperatorGroup", "DeviceArray", "to_device", "DataArray", "Dataset"]
+           "SparseOperator", "OperatorGroup", "DeviceArray", "to_device", "pinned_empty", "DataArray", "Dataset"]

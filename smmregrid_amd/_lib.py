@@ -81,6 +81,7 @@ SIGNATURES = {
     "smm_group_create": [_pp, _int, _pp],
     "smm_group_destroy": [_p],
     "smm_apply": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _p],
+    "smm_apply_host": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _i64],
     "smm_group_apply": [_p, _p, _int, _i64, _i64, _i64, _p, _int, _i64, _i64, _i64,
                         _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
 }

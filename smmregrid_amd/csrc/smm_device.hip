@@ -26,6 +26,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/smmregrid_amd.h"
@@ -991,6 +992,154 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, op->tile_valid,
                    op->tile_preferred, op->tile_reuse, op->tile_max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
+}
+
+// ---- host-buffer path: chunked, double-buffered H2D -> kernel -> D2H pipeline
+
+namespace {
+
+// parallel host copy (pageable <-> pinned staging); a single thread tops out far below PCIe
+void host_copy(void* dst, const void* src, size_t bytes) {
+  const size_t kMin = 8u << 20;
+  unsigned nt = std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+  if (bytes < 2 * kMin) nt = 1;
+  if (nt == 1) {
+    memcpy(dst, src, bytes);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const size_t per = (bytes / nt + 63) & ~(size_t)63;
+  for (unsigned t = 0; t < nt; ++t) {
+    const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
+    if (hi > lo) pool.emplace_back([=] { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
+  }
+  for (auto& th : pool) th.join();
+}
+
+bool is_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+struct HostPipe {
+  hipStream_t stream[2] = {nullptr, nullptr};
+  void* dx[2] = {nullptr, nullptr};
+  void* dy[2] = {nullptr, nullptr};
+  void* hx[2] = {nullptr, nullptr};
+  void* hy[2] = {nullptr, nullptr};
+  ~HostPipe() {
+    for (int i = 0; i < 2; ++i) {
+      if (stream[i]) (void)hipStreamDestroy(stream[i]);
+      (void)hipFree(dx[i]);
+      (void)hipFree(dy[i]);
+      if (hx[i]) (void)hipHostFree(hx[i]);
+      if (hy[i]) (void)hipHostFree(hy[i]);
+    }
+  }
+};
+
+}  // namespace
+
+int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t ldx, void* y_host,
+                   int y_dtype, int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags,
+                   int64_t chunk_rows) {
+  if (!op) return fail(SMM_ERR_INVALID, "null operator");
+  if (n_batch < 0) return fail(SMM_ERR_INVALID, "negative batch size");
+  if (n_batch == 0 || op->csr.n_dst == 0) return SMM_OK;
+  if (!x_host || !y_host) return fail(SMM_ERR_INVALID, "null field pointer");
+  if ((x_dtype != SMM_F32 && x_dtype != SMM_F64) || (y_dtype != SMM_F32 && y_dtype != SMM_F64))
+    return fail(SMM_ERR_UNSUPPORTED, "field dtype must be SMM_F32 or SMM_F64");
+  const int64_t S = op->csr.n_src, D = op->csr.n_dst;
+  if (ldx < S || ldy < D) return fail(SMM_ERR_INVALID, "ldx/ldy smaller than the grid size");
+  DeviceGuard guard(op->device);
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
+
+  const size_t xsz = x_dtype == SMM_F64 ? 8 : 4, ysz = y_dtype == SMM_F64 ? 8 : 4;
+  const size_t xrow = (size_t)ldx * xsz, yrow = (size_t)ldy * ysz;   // host row pitches
+  const size_t xrow_d = (((size_t)S * xsz + 15) / 16) * 16;            // device rows 16-B aligned
+  const int64_t ldx_d = (int64_t)(xrow_d / xsz);
+  if (chunk_rows <= 0) {
+    chunk_rows = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(xrow_d, 1)));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const int64_t fit = (int64_t)(free_b / 4 / (xrow_d + (size_t)D * ysz + 1));
+      chunk_rows = std::max<int64_t>(1, std::min(chunk_rows, fit));
+    }
+  }
+  chunk_rows = std::min(chunk_rows, n_batch);
+  const bool x_pinned = is_pinned(x_host), y_pinned = is_pinned(y_host);
+  // a pinned source with the device pitch can be DMA'd row-block-wise without staging
+  const bool x_direct = x_pinned, y_direct = y_pinned;
+
+  HostPipe pipe;
+  for (int i = 0; i < 2; ++i) {
+    SMM_HIP(hipStreamCreateWithFlags(&pipe.stream[i], hipStreamNonBlocking));
+    SMM_HIP(hipMalloc(&pipe.dx[i], (size_t)chunk_rows * xrow_d));
+    SMM_HIP(hipMalloc(&pipe.dy[i], (size_t)chunk_rows * D * ysz));
+    if (!x_direct) SMM_HIP(hipHostMalloc(&pipe.hx[i], (size_t)chunk_rows * S * xsz, hipHostMallocDefault));
+    if (!y_direct) SMM_HIP(hipHostMalloc(&pipe.hy[i], (size_t)chunk_rows * D * ysz, hipHostMallocDefault));
+  }
+
+  const int64_t n_chunks = (n_batch + chunk_rows - 1) / chunk_rows;
+  auto drain = [&](int64_t c) -> int {  // results of chunk c: wait, then pinned -> user rows
+    const int b = (int)(c & 1);
+    SMM_HIP(hipStreamSynchronize(pipe.stream[b]));
+    if (!y_direct) {
+      const int64_t r0 = c * chunk_rows, rows = std::min(chunk_rows, n_batch - r0);
+      if ((int64_t)ldy == D) {
+        host_copy((char*)y_host + (size_t)r0 * yrow, pipe.hy[b], (size_t)rows * D * ysz);
+      } else {
+        for (int64_t r = 0; r < rows; ++r)
+          memcpy((char*)y_host + (size_t)(r0 + r) * yrow, (char*)pipe.hy[b] + (size_t)r * D * ysz,
+                 (size_t)D * ysz);
+      }
+    }
+    return SMM_OK;
+  };
+
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    const int b = (int)(c & 1);
+    const int64_t r0 = c * chunk_rows, rows = std::min(chunk_rows, n_batch - r0);
+    if (c >= 2) {
+      int rc = drain(c - 2);  // buffer b is free again once chunk c-2 has been delivered
+      if (rc) return rc;
+    }
+    const char* xsrc = (const char*)x_host + (size_t)r0 * xrow;
+    if (!x_direct) {
+      if (ldx == S) {
+        host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
+      } else {
+        for (int64_t r = 0; r < rows; ++r)
+          memcpy((char*)pipe.hx[b] + (size_t)r * S * xsz, xsrc + (size_t)r * xrow, (size_t)S * xsz);
+      }
+      SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, pipe.hx[b], (size_t)S * xsz, (size_t)S * xsz,
+                               (size_t)rows, hipMemcpyHostToDevice, pipe.stream[b]));
+    } else {
+      SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, xsrc, xrow, (size_t)S * xsz, (size_t)rows,
+                               hipMemcpyHostToDevice, pipe.stream[b]));
+    }
+    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, op->tile_valid, op->tile_preferred,
+                       op->tile_reuse, op->tile_max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
+                       ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
+                       pipe.stream[b]);
+    if (rc) return rc;
+    if (!y_direct) {
+      SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)rows * D * ysz, hipMemcpyDeviceToHost,
+                             pipe.stream[b]));
+    } else {
+      SMM_HIP(hipMemcpy2DAsync((char*)y_host + (size_t)r0 * yrow, yrow, pipe.dy[b], (size_t)D * ysz,
+                               (size_t)D * ysz, (size_t)rows, hipMemcpyDeviceToHost, pipe.stream[b]));
+    }
+  }
+  for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks; ++c) {
+    int rc = drain(c);
+    if (rc) return rc;
+  }
+  return SMM_OK;
 }
 
 int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask) {

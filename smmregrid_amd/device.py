@@ -213,3 +213,38 @@ def empty(shape, dtype=np.float64):
     if not isinstance(shape, tuple):
         shape = tuple(np.atleast_1d(shape).tolist())
     return DeviceArray(shape, dtype)
+
+
+class _PinnedBlock:
+    """Owner of one hipHostMalloc allocation (kept alive by the numpy array's base)."""
+
+    def __init__(self, nbytes):
+        h = ctypes.c_void_p()
+        _lib.call("smm_host_alloc", ctypes.byref(h), max(int(nbytes), 1))
+        self.ptr = h.value
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.call("smm_host_free", ctypes.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory: smm_apply_host DMAs it without staging copies."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    n = int(np.prod(shape)) if shape else 1
+    block = _PinnedBlock(n * dtype.itemsize)
+    buf = (ctypes.c_char * max(block.nbytes, 1)).from_address(block.ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+    _PINNED_KEEPALIVE[id(buf)] = block
+    import weakref
+    weakref.finalize(buf, _PINNED_KEEPALIVE.pop, id(buf), None)
+    return arr
+
+
+_PINNED_KEEPALIVE = {}

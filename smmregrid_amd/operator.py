@@ -103,6 +103,30 @@ class SparseOperator:
                   float(remap_area_min), fl, _stream_handle(stream))
         return y
 
+    def apply_host(self, x, out=None, masked=False, remap_area_min=0.0, out_dtype=np.float64,
+                   flags=0, chunk_rows=0):
+        """Same product for a host (numpy) array of shape (B, S): the rows stream through the
+        library's double-buffered H2D / kernel / D2H pipeline (smm_apply_host).  Arrays from
+        `pinned_empty` are DMA'd without staging copies.  Returns a (B, D) numpy array."""
+        x = np.asarray(x)
+        if x.dtype not in (np.float32, np.float64):
+            x = x.astype(np.float64)          # result_type(x, f64), regrid.py:550
+        if x.ndim != 2 or x.shape[1] != self.n_src:
+            raise ValueError(f"X must be (B, {self.n_src}), got {x.shape}")
+        if x.strides[1] != x.itemsize or x.strides[0] % x.itemsize or x.strides[0] < self.n_src * x.itemsize:
+            x = np.ascontiguousarray(x)
+        n_batch = x.shape[0]
+        if out is None:
+            out = np.empty((n_batch, self.n_dst), dtype=out_dtype)
+        if out.shape != (n_batch, self.n_dst) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous ({n_batch}, {self.n_dst}) array")
+        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
+        _lib.call("smm_apply_host", self.handle, _cptr(x), dtype_code(x.dtype),
+                  x.strides[0] // x.itemsize if n_batch > 1 else max(self.n_src, 1),
+                  _cptr(out), dtype_code(out.dtype), self.n_dst, n_batch, float(remap_area_min), fl,
+                  int(chunk_rows))
+        return out
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.call("smm_operator_destroy", self.handle)

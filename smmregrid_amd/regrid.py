@@ -285,15 +285,8 @@ class Regridder(object):
             host = np.ascontiguousarray(host).reshape(n_batch, -1)
             if host.shape[1] != op.n_src:
                 raise ValueError(f"source grid has {host.shape[1]} cells, weights expect {op.n_src}")
-            out = np.empty((n_batch, op.n_dst), dtype=np.float64)
-            step = self._batch_rows(n_batch, op.n_src * host.dtype.itemsize + op.n_dst * 8)
-            for r0 in range(0, n_batch, step):
-                r1 = min(n_batch, r0 + step)
-                x = to_device(host[r0:r1])
-                y = op.apply(x, masked=masked, remap_area_min=self.remap_area_min)
-                y.to_host(out[r0:r1])
-                x.free()
-                y.free()
+            # host field: chunks stream through the library's H2D / kernel / D2H pipeline
+            out = op.apply_host(host, masked=masked, remap_area_min=self.remap_area_min)
             out_data = out.reshape(kept_shape + tgt_shape)
 
         return self._finish(out_data, kept_dims + tgt_dims, source_data, kept_dims, weights,

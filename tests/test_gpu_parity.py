@@ -307,3 +307,34 @@ def test_config2_geometry_properties(hip, rng):
     # spot parity against the oracle on a row subset
     ref = oracle.apply_c(op.export_csr(), x1[:3])
     assert_same(y1[:3], ref, exact=True)
+
+
+# ----------------------------------------------------------------- host-buffer streaming pipeline
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_apply_host_pipeline_matches_device_path(hip, rng, dtype):
+    from smmregrid_amd import pinned_empty
+    n_src, n_dst = 3001, 777                      # odd S: device rows are re-pitched to 16 B
+    src, dst, w = random_links(rng, n_src, n_dst, 5000)
+    op = make_op(n_src, n_dst, src, dst, w)
+    imask = (rng.random(n_dst) > 0.2).astype(np.int32)
+    frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    csr = op.export_csr()
+    x = field(rng, 37, n_src, dtype=dtype, nan_frac=0.02)
+    ref = oracle.apply_c(csr, x, True, imask, frac, 0.4)
+    for chunk in (0, 1, 5, 16, 64):               # single chunk, many chunks, ragged tail
+        y = op.apply_host(x, masked=True, remap_area_min=0.4, chunk_rows=chunk)
+        assert_same(y, ref, exact=True)
+    # pinned input and output buffers are DMA'd directly
+    xp = pinned_empty(x.shape, dtype)
+    xp[...] = x
+    yp = pinned_empty((37, n_dst), np.float64)
+    op.apply_host(xp, out=yp, masked=True, remap_area_min=0.4, chunk_rows=7)
+    assert_same(np.array(yp), ref, exact=True)
+    # a row-strided view (ldx > S) is consumed without a copy
+    wide = np.zeros((37, n_src + 13), dtype=dtype)
+    wide[:, :n_src] = x
+    y = op.apply_host(wide[:, :n_src], masked=True, remap_area_min=0.4, chunk_rows=9)
+    assert_same(y, ref, exact=True)
+    assert op.apply_host(np.zeros((0, n_src), dtype)).shape == (0, n_dst)
