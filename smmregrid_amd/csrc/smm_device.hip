@@ -577,7 +577,12 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
   ApplyArgs args = a;
   const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
   const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
-  args.j_per_block = (int)std::min<int64_t>(a.n_j, jpb ? jpb : 16);
+  // Batch rows walked per workgroup: the prologue (links -> registers) is amortised over
+  // them, so heavier rows want longer walks; keep >= ~4096 workgroups to fill 256 CUs.
+  int64_t walk = jpb ? (int64_t)jpb : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 32 : 64));
+  if (!jpb)
+    while (walk > 1 && a.n_dblocks * ((a.n_j + walk - 1) / walk) * n_lev < 4096) walk /= 2;
+  args.j_per_block = (int)std::min<int64_t>(a.n_j, walk);
   args.n_jtiles = (a.n_j + args.j_per_block - 1) / args.j_per_block;
   const int64_t total = args.n_dblocks * args.n_jtiles * n_lev;
   if (total <= 0) return SMM_OK;
@@ -1203,16 +1208,18 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
   g->device = ops[0]->device;
   g->ops.assign(ops, ops + n_ops);
   g->tile_valid = true;
-  g->tile_preferred = true;
+  int64_t nnz_all = 0, nnz_pref = 0;  // one launch covers all levels: the links' majority decides
   std::vector<LevelDesc> descs((size_t)n_ops);
   for (int i = 0; i < n_ops; ++i) {
     descs[(size_t)i] = ops[i]->desc();
     g->tile_valid = g->tile_valid && ops[i]->tile_valid;
-    g->tile_preferred = g->tile_preferred && ops[i]->tile_preferred;
+    nnz_all += ops[i]->csr.nnz;
+    if (ops[i]->tile_preferred) nnz_pref += ops[i]->csr.nnz;
     g->tile_reuse = g->tile_reuse || ops[i]->tile_reuse;
     g->tile_max_chunks = std::max(g->tile_max_chunks, ops[i]->tile_max_chunks);
     g->max_row_nnz = std::max(g->max_row_nnz, ops[i]->csr.max_row_nnz);
   }
+  g->tile_preferred = 2 * nnz_pref >= nnz_all;
   DeviceGuard guard(g->device);
   int rc = guard.ok ? upload(&g->d_descs, descs) : fail(SMM_ERR_HIP, "cannot select device");
   if (rc) {
