@@ -115,6 +115,14 @@ class Problem2D:
     def full_stream_bytes(self):
         return self.n_batch * (self.n_src * np.dtype(self.np_dt).itemsize + self.n_dst * 8) + self.op.nnz * 12
 
+    def line_bytes(self):
+        """Bytes of the whole 128-B source lines the links touch (what any kernel must move
+        from HBM in the native (B, S) layout) + Y + the operator once."""
+        staged = self.op.plan_info()["staged_src_elems"]
+        if not staged:
+            return None
+        return self.n_batch * (staged * np.dtype(self.np_dt).itemsize + self.n_dst * 8) + self.op.nnz * 12
+
     def run(self, y, flags):
         self.op.apply(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags)
 
@@ -198,6 +206,12 @@ class ProblemLevels:
 
     def full_stream_bytes(self):
         return self.n_t * self.n_lev * (self.n_src + self.n_dst) * 8 + sum(op.nnz for op in self.ops) * 12
+
+    def line_bytes(self):
+        staged = [op.plan_info()["staged_src_elems"] for op in self.ops]
+        if not all(op.plan_info()["tile_plan"] for op in self.ops):
+            return None
+        return self.n_t * (sum(staged) + self.n_lev * self.n_dst) * 8 + sum(op.nnz for op in self.ops) * 12
 
     def run(self, y, flags):
         self.group.apply(self.x, self.level_index, self.masked_levels, y=y, masked=True,
@@ -341,6 +355,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_ms": k_avg * 1e3, "algorithmic_bytes": b_alg,
                          "full_stream_bytes": prob.full_stream_bytes(),
+                         "line_granular_bytes": prob.line_bytes(),
+                         "line_granular_frac": (prob.line_bytes() / k_avg / 1e9 / HBM_PEAK_GBS)
+                         if prob.line_bytes() else None,
                          "traffic_GBs": (traffic / k_avg / 1e9) if traffic else None},
         }
         if with_gather is not None:

@@ -318,6 +318,22 @@ __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs 
   if (j_end > a.n_j) j_end = a.n_j;
   if (j_begin >= j_end) return;
 
+  if (npieces == 0) {
+    // no destination row of this block has a link (land-only block): nothing to stage,
+    // no barrier needed -- every batch row gets epilogue(0)
+    if (row_live) {
+      const YT out = (YT)epilogue(0.0, dead);
+      for (int64_t j = j_begin; j < j_end; ++j) {
+        YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+        if (NT & 2)
+          __builtin_nontemporal_store(out, yrow + d);
+        else
+          yrow[d] = out;
+      }
+    }
+    return;
+  }
+
   u32x4 v[NP];
   auto load_row = [&](int64_t j) {
     const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);

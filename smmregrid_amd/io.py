@@ -1,6 +1,8 @@
 """Weights files without xarray/netCDF4: ``.npz`` (this package's cache format)
 and NetCDF-3 classic / 64-bit-offset (``scipy.io.netcdf_file``).  HDF5-based
 NetCDF-4 files need xarray (then pass the opened Dataset to Regridder)."""
+import json
+
 import numpy as np
 
 from .xrlite import DataArray, Dataset, HAVE_XARRAY
@@ -16,14 +18,14 @@ def save_weights(weights, path):
         payload["var__" + k] = v.values
         meta["dims"][k] = list(v.dims)
     meta["coords"] = list(weights.coords)
-    payload["__meta__"] = np.array(repr(meta))
+    payload["__meta__"] = np.array(json.dumps(meta))
     np.savez_compressed(path, **payload)
 
 
 def open_weights(path):
     if str(path).endswith(".npz"):
         z = np.load(path, allow_pickle=False)
-        meta = eval(str(z["__meta__"]), {"__builtins__": {}})  # repr of plain dict/list/str
+        meta = json.loads(str(z["__meta__"]))
         ds = Dataset(attrs=meta["attrs"])
         for k, dims in meta["dims"].items():
             arr = DataArray(z["var__" + k], dims=dims, name=k)
