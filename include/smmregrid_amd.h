@@ -154,6 +154,8 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
 /* per-level set (replaces the list built by weights.py:7-23); borrows the operators */
 int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out);
 int smm_group_destroy(smm_group_t g);
+/* bit 0: every member has an LDS tile plan of the group's block shape, bit 1: the tile kernel is the default */
+int smm_group_plan_info(smm_group_t g, int* kernel_kind, int* slices_per_block);
 
 /* ----------------------------------------------------------------- apply */
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "smm_operator_plan_info": [_p, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     "smm_group_create": [_pp, _int, _pp],
     "smm_group_destroy": [_p],
+    "smm_group_plan_info": [_p, ctypes.POINTER(_int), ctypes.POINTER(_int)],
     "smm_apply": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _p],
     "smm_apply_host": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _i64],
     "smm_group_apply": [_p, _p, _int, _i64, _i64, _i64, _p, _int, _i64, _i64, _i64,

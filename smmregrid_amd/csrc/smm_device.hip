@@ -209,8 +209,15 @@ __global__ __launch_bounds__(kThreads) void smm_apply_sell_kernel(ApplyArgs a, b
 // shared between blocks), bit 1: non-temporal Y stores.
 typedef u32x4 u32x4_u __attribute__((aligned(4)));  // 16-B piece that may start on any element
 
+// Rows with more than 16 links run one wave (64 destination rows) per workgroup: their source
+// tiles are large, and single-wave workgroups need no workgroup barrier, so the waves of a CU
+// drift apart and overlap each other's HBM waits.
+constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPerBlock : 1; }
+
 template <typename XT, typename YT, int MAXK, int NP, int NT>
-__global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
+__global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
+  constexpr int WPB = tile_waves(MAXK);
+  constexpr int T = WPB * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs 
   const int di = a.lev_map ? a.lev_map[l] : 0;
   const LevelDesc L = a.descs[di];
 
-  const int64_t slice = db * kWavesPerBlock + wave;   // always < n_slices: n_dblocks * 4 slices are padded
+  const int64_t slice = db * WPB + wave;
   const int64_t d = slice * 64 + lane;
   const bool row_live = d < a.n_dst;
   const bool slice_live = slice * 64 < a.n_dst;
@@ -286,13 +293,13 @@ __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs 
   // shift = elements by which the clamp moved it (non-zero only for the row's last piece),
   // pvalid bit k = the piece exists.
   const int np_w = __builtin_amdgcn_readfirstlane(
-      npieces > wave * 64 ? (npieces - wave * 64 + kThreads - 1) / kThreads : 0);
+      npieces > wave * 64 ? (npieces - wave * 64 + T - 1) / T : 0);
   int32_t poff[NP];
   unsigned pvalid = 0, shifted = 0;
   int shift_amt = 0;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
-    const int p = tid + k * kThreads;
+    const int p = tid + k * T;
     poff[k] = 0;
     if (k < np_w) {
       const int pc = min(p, npieces - 1);
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(kThreads, 2) void smm_apply_tile2_kernel(ApplyArgs 
           }
           __builtin_memcpy(&piece, out, 16);
         }
-        if ((pvalid >> k) & 1u) *(u32x4*)(smem + (size_t)(tid + k * kThreads) * 16) = piece;
+        if ((pvalid >> k) & 1u) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = piece;
       }
     }
   };
@@ -476,17 +483,23 @@ struct smm_operator {
   int32_t* d_rowlen = nullptr;
   uint8_t* d_imask = nullptr;
   double* d_frac = nullptr;
-  // tile plan
-  bool tile_valid = false;
-  int chunk_elems = 0;
-  int64_t tile_blocks = 0, tile_max_chunks = 0, tile_total_chunks = 0, tile_total_distinct = 0;
-  bool tile_preferred = false;  // staged lines are used well enough to beat direct gathers
-  bool tile_reuse = false;      // some staged lines are shared by several blocks (keep them cacheable)
-  int64_t* d_blk_chunk_off = nullptr;
-  int32_t* d_chunk_src = nullptr;
-  int32_t* d_lcol = nullptr;
-  LevelDesc* d_desc = nullptr;  // one-element device copy
-  LevelDesc desc() const {
+  // LDS tile plans: [0] = 4 slices (256 rows) per block, [1] = 1 slice per block (heavy rows).
+  // The operator's own shape is built at create time, the other one on demand when the
+  // operator joins a group of the other shape.
+  struct TilePlan {
+    bool built = false, valid = false;
+    int64_t max_chunks = 0, total_chunks = 0;
+    bool preferred = false;  // staged lines are used well enough to beat direct gathers
+    bool reuse = false;      // some staged lines are shared by several blocks (keep them cacheable)
+    int64_t* d_blk_chunk_off = nullptr;
+    int32_t* d_chunk_src = nullptr;
+    int32_t* d_lcol = nullptr;
+  } plan[2];
+  smm::HostSell sell_shape;  // slice_off / rowlen only (col/val dropped after upload)
+  std::mutex plan_mu;
+  int native_plan() const { return csr.max_row_nnz > 16 ? 1 : 0; }
+  LevelDesc* d_desc = nullptr;  // one-element device copy (native plan)
+  LevelDesc desc(int which) const {
     LevelDesc L;
     L.slice_off = d_slice_off;
     L.col = d_col;
@@ -494,9 +507,9 @@ struct smm_operator {
     L.rowlen = d_rowlen;
     L.imask = d_imask;
     L.frac = d_frac;
-    L.blk_chunk_off = d_blk_chunk_off;
-    L.chunk_src = d_chunk_src;
-    L.lcol = d_lcol;
+    L.blk_chunk_off = plan[which].d_blk_chunk_off;
+    L.chunk_src = plan[which].d_chunk_src;
+    L.lcol = plan[which].d_lcol;
     return L;
   }
 };
@@ -505,6 +518,7 @@ struct smm_group {
   int device = -1;
   std::vector<smm_operator_t> ops;
   LevelDesc* d_descs = nullptr;
+  int tile_which = 0;  // plan shape shared by all members
   bool tile_valid = false;
   bool tile_preferred = false;
   bool tile_reuse = false;
@@ -546,7 +560,7 @@ struct DeviceGuard {
 };
 
 int refresh_desc(smm_operator* op) {
-  const LevelDesc L = op->desc();
+  const LevelDesc L = op->desc(op->native_plan());
   if (!op->d_desc) SMM_HIP(hipMalloc((void**)&op->d_desc, sizeof(LevelDesc)));
   SMM_HIP(hipMemcpy(op->d_desc, &L, sizeof(LevelDesc), hipMemcpyHostToDevice));
   return SMM_OK;
@@ -560,11 +574,37 @@ void release(smm_operator* op) {
   (void)hipFree(op->d_rowlen);
   (void)hipFree(op->d_imask);
   (void)hipFree(op->d_frac);
-  (void)hipFree(op->d_blk_chunk_off);
-  (void)hipFree(op->d_chunk_src);
-  (void)hipFree(op->d_lcol);
+  for (auto& pl : op->plan) {
+    (void)hipFree(pl.d_blk_chunk_off);
+    (void)hipFree(pl.d_chunk_src);
+    (void)hipFree(pl.d_lcol);
+  }
   (void)hipFree(op->d_desc);
   delete op;
+}
+
+// Build and upload tile plan `which` of the operator if it does not exist yet.
+int ensure_plan(smm_operator* op, int which) {
+  std::lock_guard<std::mutex> lock(op->plan_mu);
+  smm_operator::TilePlan& pl = op->plan[which];
+  if (pl.built) return SMM_OK;
+  const int spb = which ? 1 : kWavesPerBlock;
+  smm::HostTilePlan hp;
+  // LDS / staging-register budget per destination row is the same for both block shapes
+  smm::build_tile_plan(op->csr, op->sell_shape, spb, kChunkElems, kTileMaxChunks * spb / kWavesPerBlock, hp);
+  pl.built = true;
+  if (!hp.valid) return SMM_OK;
+  int rc = SMM_OK;
+  if ((rc = upload(&pl.d_blk_chunk_off, hp.blk_chunk_off)) || (rc = upload(&pl.d_chunk_src, hp.chunk_src)) ||
+      (rc = upload(&pl.d_lcol, hp.lcol)))
+    return rc;
+  pl.valid = true;
+  pl.max_chunks = hp.max_block_chunks;
+  pl.total_chunks = hp.total_chunks;
+  pl.reuse = hp.total_chunks * 50 > hp.distinct_chunks * 51;  // > 2 % of lines staged twice
+  // at least a quarter of every staged 128-B line is consumed
+  pl.preferred = hp.total_distinct * 4 >= hp.total_chunks * (int64_t)hp.chunk_elems;
+  return SMM_OK;
 }
 
 template <typename XT, typename YT>
@@ -588,8 +628,8 @@ int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, hipStream_t s) {
 }
 
 template <typename XT, typename YT>
-int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t max_row_nnz,
-                bool tile_reuse, bool fill, unsigned flags, hipStream_t s) {
+int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_chunks,
+                int64_t max_row_nnz, bool tile_reuse, bool fill, unsigned flags, hipStream_t s) {
   ApplyArgs args = a;
   const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
   const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
@@ -605,21 +645,24 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int64_t max_chunks, int64_t m
   if (total > 0x7fffffffLL) return fail(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
   const size_t lds = (size_t)max_chunks * kChunkElems * sizeof(XT);
   const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
-  const int np_needed = (int)((max_pieces + kThreads - 1) / kThreads);
+  const int threads = (tile_which ? 1 : kWavesPerBlock) * 64;  // == tile_waves(MAXK) * 64
+  const int np_needed = (int)((max_pieces + threads - 1) / threads);
 
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
     constexpr int NP = decltype(np_tag)::value;
     constexpr int NT = decltype(nt_tag)::value;
     hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NP, NT>), dim3((unsigned)total),
-                       dim3(kThreads), lds, s, args, fill);
+                       dim3(tile_waves(MAXK) * 64), lds, s, args, fill);
     SMM_HIP(hipGetLastError());
     return SMM_OK;
   };
-  auto with_k = [&](auto fn) -> int {
-    if (max_row_nnz <= 4) return fn(std::integral_constant<int, 4>());
-    if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
-    if (max_row_nnz <= 16) return fn(std::integral_constant<int, 16>());
+  auto with_k = [&](auto fn) -> int {  // plan shape 0 <-> MAXK <= 16 (4 waves), shape 1 <-> MAXK >= 32 / 0 (1 wave)
+    if (!tile_which) {
+      if (max_row_nnz <= 4) return fn(std::integral_constant<int, 4>());
+      if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
+      return fn(std::integral_constant<int, 16>());
+    }
     if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
     if (max_row_nnz <= 48) return fn(std::integral_constant<int, 48>());
     return fn(std::integral_constant<int, 0>());  // longer rows: links streamed from L2
@@ -652,8 +695,8 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15u) == 0; }
 
 // Common launch path for a single operator (descs = op->d_desc) or a group.
 int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t* d_lev_masked,
-              int64_t n_src, int64_t n_dst, bool tile_ok, bool tile_preferred, bool tile_reuse,
-              int64_t tile_max_chunks,
+              int64_t n_src, int64_t n_dst, int tile_which, bool tile_ok, bool tile_preferred,
+              bool tile_reuse, int64_t tile_max_chunks,
               int64_t max_row_nnz, const void* x, int x_dtype, int64_t xs_o, int64_t xs_l,
               int64_t xs_i, void* y, int y_dtype, int64_t ys_o, int64_t ys_l, int64_t ys_i,
               int64_t n_outer, int64_t n_lev, int64_t n_inner, double area_min, unsigned flags,
@@ -682,7 +725,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
   a.n_inner = n_inner;
   a.n_src = n_src;
   a.n_dst = n_dst;
-  a.n_dblocks = ((n_dst + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;
+  a.n_dblocks = ((n_dst + 63) / 64 + kWavesPerBlock - 1) / kWavesPerBlock;  // SELL: 4 slices per workgroup
   a.area_min = area_min;
   a.masked = (flags & SMM_APPLY_MASKED) ? 1 : 0;
   const bool fill = !(flags & SMM_APPLY_NO_FILL);
@@ -710,7 +753,12 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
   (x_dtype == SMM_F64                                                                \
        ? (y_dtype == SMM_F64 ? FN<double, double>(__VA_ARGS__) : FN<double, float>(__VA_ARGS__)) \
        : (y_dtype == SMM_F64 ? FN<float, double>(__VA_ARGS__) : FN<float, float>(__VA_ARGS__)))
-  if (use_tile) return SMM_DISPATCH(launch_tile, a, n_lev, tile_max_chunks, max_row_nnz, tile_reuse, fill, flags, s);
+  if (use_tile) {
+    const int64_t spb = tile_which ? 1 : kWavesPerBlock;  // slices per block of the tile plan
+    a.n_dblocks = ((n_dst + 63) / 64 + spb - 1) / spb;
+  }
+  if (use_tile)
+    return SMM_DISPATCH(launch_tile, a, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_reuse, fill, flags, s);
   return SMM_DISPATCH(launch_sell, a, n_lev, fill, s);
 #undef SMM_DISPATCH
 }
@@ -897,8 +945,6 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
     }
     smm::HostSell sell;
     smm::build_sell(op->csr, sell);
-    smm::HostTilePlan plan;
-    smm::build_tile_plan(op->csr, sell, kWavesPerBlock, kChunkElems, kTileMaxChunks, plan);
 
     DeviceGuard guard(device);
     if (!guard.ok) {
@@ -913,21 +959,13 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
       release(op);
       return rc;
     }
-    if (plan.valid) {
-      if ((rc = upload(&op->d_blk_chunk_off, plan.blk_chunk_off)) ||
-          (rc = upload(&op->d_chunk_src, plan.chunk_src)) || (rc = upload(&op->d_lcol, plan.lcol))) {
-        release(op);
-        return rc;
-      }
-      op->tile_valid = true;
-      op->chunk_elems = plan.chunk_elems;
-      op->tile_blocks = plan.n_blocks;
-      op->tile_max_chunks = plan.max_block_chunks;
-      op->tile_total_chunks = plan.total_chunks;
-      op->tile_total_distinct = plan.total_distinct;
-      op->tile_reuse = plan.total_chunks * 50 > plan.distinct_chunks * 51;  // > 2 % of lines staged twice
-      // at least a quarter of every staged 128-B line is consumed, rows fit the register file
-      op->tile_preferred = plan.total_distinct * 4 >= plan.total_chunks * (int64_t)plan.chunk_elems;
+    op->sell_shape.n_slices = sell.n_slices;
+    op->sell_shape.n_slots = sell.n_slots;
+    op->sell_shape.slice_off = std::move(sell.slice_off);
+    op->sell_shape.rowlen = std::move(sell.rowlen);
+    if ((rc = ensure_plan(op, op->native_plan()))) {
+      release(op);
+      return rc;
     }
     if ((rc = refresh_desc(op))) {
       release(op);
@@ -993,9 +1031,10 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
 int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
                            int64_t* staged_src_elems) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
-  if (kernel_kind) *kernel_kind = (op->tile_valid ? 1 : 0) | (op->tile_preferred ? 2 : 0);
-  if (lds_bytes) *lds_bytes = op->tile_valid ? op->tile_max_chunks * op->chunk_elems * 8 : 0;
-  if (staged_src_elems) *staged_src_elems = op->tile_valid ? op->tile_total_chunks * op->chunk_elems : 0;
+  const smm_operator::TilePlan& pl = op->plan[op->native_plan()];
+  if (kernel_kind) *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0);
+  if (lds_bytes) *lds_bytes = pl.valid ? pl.max_chunks * kChunkElems * 8 : 0;
+  if (staged_src_elems) *staged_src_elems = pl.valid ? pl.total_chunks * kChunkElems : 0;
   return SMM_OK;
 }
 
@@ -1010,8 +1049,10 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
     return fail(SMM_ERR_INVALID, "remap_area_min > 0 requested but the operator has no dst_frac");
   DeviceGuard guard(op->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
-  return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, op->tile_valid,
-                   op->tile_preferred, op->tile_reuse, op->tile_max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
+  const int pw = op->native_plan();
+  const smm_operator::TilePlan& pl = op->plan[pw];
+  return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid,
+                   pl.preferred, pl.reuse, pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
 
@@ -1143,8 +1184,10 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
       SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, xsrc, xrow, (size_t)S * xsz, (size_t)rows,
                                hipMemcpyHostToDevice, pipe.stream[b]));
     }
-    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, op->tile_valid, op->tile_preferred,
-                       op->tile_reuse, op->tile_max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
+    const int pw = op->native_plan();
+    const smm_operator::TilePlan& pl = op->plan[pw];
+    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, pw, pl.valid, pl.preferred, pl.reuse,
+                       pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
                        ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
                        pipe.stream[b]);
     if (rc) return rc;
@@ -1191,7 +1234,7 @@ int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t
     cleanup();
     return fail(SMM_ERR_HIP, "hipMemcpy failed in smm_operator_mask_apply");
   }
-  rc = run_apply(op->d_desc, nullptr, nullptr, S, D, false, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
+  rc = run_apply(op->d_desc, nullptr, nullptr, S, D, 0, false, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
                  std::max<int64_t>(S, 1), 0, 0, dy, SMM_F64, D, 0, 0, 1, 1, 1, 0.0,
                  SMM_APPLY_NO_FILL, nullptr);
   if (rc == SMM_OK) {
@@ -1224,25 +1267,45 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
   g->device = ops[0]->device;
   g->ops.assign(ops, ops + n_ops);
   g->tile_valid = true;
-  int64_t nnz_all = 0, nnz_pref = 0;  // one launch covers all levels: the links' majority decides
+  // one launch covers all levels: one plan shape for all members (single-wave blocks as soon as
+  // any level has rows longer than 16 links), and the links' majority decides tile vs SELL
+  for (int i = 0; i < n_ops; ++i) g->tile_which = g->tile_which || ops[i]->native_plan();
+  DeviceGuard guard(g->device);
+  if (!guard.ok) {
+    delete g;
+    return fail(SMM_ERR_HIP, "cannot select device");
+  }
+  int64_t nnz_all = 0, nnz_pref = 0;
   std::vector<LevelDesc> descs((size_t)n_ops);
   for (int i = 0; i < n_ops; ++i) {
-    descs[(size_t)i] = ops[i]->desc();
-    g->tile_valid = g->tile_valid && ops[i]->tile_valid;
+    int prc = ensure_plan(ops[i], g->tile_which);
+    if (prc) {
+      delete g;
+      return prc;
+    }
+    const smm_operator::TilePlan& pl = ops[i]->plan[g->tile_which];
+    descs[(size_t)i] = ops[i]->desc(g->tile_which);
+    g->tile_valid = g->tile_valid && pl.valid;
     nnz_all += ops[i]->csr.nnz;
-    if (ops[i]->tile_preferred) nnz_pref += ops[i]->csr.nnz;
-    g->tile_reuse = g->tile_reuse || ops[i]->tile_reuse;
-    g->tile_max_chunks = std::max(g->tile_max_chunks, ops[i]->tile_max_chunks);
+    if (pl.preferred) nnz_pref += ops[i]->csr.nnz;
+    g->tile_reuse = g->tile_reuse || pl.reuse;
+    g->tile_max_chunks = std::max(g->tile_max_chunks, pl.max_chunks);
     g->max_row_nnz = std::max(g->max_row_nnz, ops[i]->csr.max_row_nnz);
   }
   g->tile_preferred = 2 * nnz_pref >= nnz_all;
-  DeviceGuard guard(g->device);
-  int rc = guard.ok ? upload(&g->d_descs, descs) : fail(SMM_ERR_HIP, "cannot select device");
+  int rc = upload(&g->d_descs, descs);
   if (rc) {
     delete g;
     return rc;
   }
   *out = g;
+  return SMM_OK;
+}
+
+int smm_group_plan_info(smm_group_t g, int* kernel_kind, int* slices_per_block) {
+  if (!g) return fail(SMM_ERR_INVALID, "null group");
+  if (kernel_kind) *kernel_kind = (g->tile_valid ? 1 : 0) | (g->tile_preferred ? 2 : 0);
+  if (slices_per_block) *slices_per_block = g->tile_which ? 1 : kWavesPerBlock;
   return SMM_OK;
 }
 
@@ -1307,8 +1370,8 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
   const int32_t* d_map = (const int32_t*)d_cfg;
   const uint8_t* d_masked = masked_levels ? (const uint8_t*)d_cfg + map_bytes : nullptr;
   const smm_operator* op0 = g->ops[0];
-  return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_valid,
-                   g->tile_preferred, g->tile_reuse, g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
+  return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_which,
+                   g->tile_valid, g->tile_preferred, g->tile_reuse, g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
 }

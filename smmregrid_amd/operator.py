@@ -160,6 +160,12 @@ class OperatorGroup:
     def __len__(self):
         return len(self.operators)
 
+    def plan_info(self):
+        kind, spb = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.call("smm_group_plan_info", self.handle, ctypes.byref(kind), ctypes.byref(spb))
+        return {"tile_plan": bool(kind.value & 1), "tile_preferred": bool(kind.value & 2),
+                "slices_per_block": spb.value}
+
     def __getitem__(self, i):
         return self.operators[i]
 

@@ -229,8 +229,8 @@ def test_group_apply_random(hip, rng, transpose, kname, kflag):
         op.set_epilogue(imask[l], frac[l])
         ops.append(op)
         csrs.append(op.export_csr())
-    need_kernel(ops, kname)
     grp = OperatorGroup(ops)
+    need_kernel(grp, kname)
     level_index = np.array([3, 0, 4, 4], np.int32)          # 4 data levels, sub-selection + repeat
     masked_levels = np.array([1, 0, 1, 1, 0], np.uint8)
     for n_outer, n_inner in [(3, 1), (2, 3), (1, 1), (9, 2)]:
@@ -271,8 +271,8 @@ def test_golden_masked_levels(hip, kname, kflag):
         assert np.array_equal(op.mask_apply(z["src_imask"][i]), z["dst_imask"][i])
         op.set_epilogue(z["dst_imask"][i], z["dst_frac"][i])
         ops.append(op)
-    need_kernel(ops, kname)
     grp = OperatorGroup(ops)
+    need_kernel(grp, kname)
     x = z["x"]                                               # (T, L, S)
     T, L, S = x.shape
     dy = grp.apply(to_device(x.reshape(T, L, 1, S)), z["level_index"],
