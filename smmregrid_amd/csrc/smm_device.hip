@@ -635,7 +635,11 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
   // Batch rows walked per workgroup: the prologue (links -> registers) is amortised over
   // them, so heavier rows want longer walks; keep >= ~4096 workgroups to fill 256 CUs.
-  int64_t walk = jpb ? (int64_t)jpb : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 32 : 64));
+  // An operator that does not stay in L2 (links x 12 B beyond ~32 MB) is re-read from HBM by every
+  // walk: amortise it over long walks whatever the row length.
+  const bool big_operator = a.n_dst * std::max<int64_t>(max_row_nnz, 1) * 12 > (32ll << 20);
+  int64_t walk = jpb ? (int64_t)jpb
+                     : (big_operator ? 64 : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 32 : 64)));
   if (!jpb)
     while (walk > 1 && a.n_dblocks * ((a.n_j + walk - 1) / walk) * n_lev < 4096) walk /= 2;
   args.j_per_block = (int)std::min<int64_t>(a.n_j, walk);
