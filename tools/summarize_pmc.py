@@ -18,7 +18,7 @@ import os
 
 
 def mean_counter(d, kernel_substr):
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if kernel_substr in r["Kernel_Name"]:
