@@ -469,6 +469,55 @@ __global__ void smm_mask_threshold_kernel(const double* __restrict__ y, int32_t*
   if (i < n) m[i] = (y[i] < 0.5) ? 0 : 1;
 }
 
+// Staging resources of the host-buffer pipeline, cached per operator (allocation costs
+// milliseconds, a small regrid microseconds): two streams, two device X/Y chunk buffers,
+// two pinned X/Y staging buffers, grown on demand.
+struct HostPipe {
+  hipStream_t stream[2] = {nullptr, nullptr};
+  void* dx[2] = {nullptr, nullptr};
+  void* dy[2] = {nullptr, nullptr};
+  void* hx[2] = {nullptr, nullptr};
+  void* hy[2] = {nullptr, nullptr};
+  size_t cap_dx = 0, cap_dy = 0, cap_hx = 0, cap_hy = 0;
+  hipError_t ensure(size_t need_dx, size_t need_dy, size_t need_hx, size_t need_hy) {
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i)
+      if (!stream[i]) e = hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking);
+    auto grow_dev = [&](void* (&buf)[2], size_t& cap, size_t need) {
+      if (need <= cap || e != hipSuccess) return;
+      for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        (void)hipFree(buf[i]);
+        buf[i] = nullptr;
+        e = hipMalloc(&buf[i], need);
+      }
+      cap = e == hipSuccess ? need : 0;
+    };
+    auto grow_host = [&](void* (&buf)[2], size_t& cap, size_t need) {
+      if (need <= cap || e != hipSuccess) return;
+      for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        if (buf[i]) (void)hipHostFree(buf[i]);
+        buf[i] = nullptr;
+        e = hipHostMalloc(&buf[i], need, hipHostMallocDefault);
+      }
+      cap = e == hipSuccess ? need : 0;
+    };
+    grow_dev(dx, cap_dx, need_dx);
+    grow_dev(dy, cap_dy, need_dy);
+    grow_host(hx, cap_hx, need_hx);
+    grow_host(hy, cap_hy, need_hy);
+    return e;
+  }
+  ~HostPipe() {
+    for (int i = 0; i < 2; ++i) {
+      if (stream[i]) (void)hipStreamDestroy(stream[i]);
+      (void)hipFree(dx[i]);
+      (void)hipFree(dy[i]);
+      if (hx[i]) (void)hipHostFree(hx[i]);
+      if (hy[i]) (void)hipHostFree(hy[i]);
+    }
+  }
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------ handles
@@ -497,6 +546,8 @@ struct smm_operator {
   } plan[2];
   smm::HostSell sell_shape;  // slice_off / rowlen only (col/val dropped after upload)
   std::mutex plan_mu;
+  std::mutex pipe_mu;        // smm_apply_host calls on one operator take turns
+  HostPipe pipe;
   int native_plan() const { return csr.max_row_nnz > 16 ? 1 : 0; }
   LevelDesc* d_desc = nullptr;  // one-element device copy (native plan)
   LevelDesc desc(int which) const {
@@ -1091,23 +1142,6 @@ bool is_pinned(const void* p) {
   return attr.type == hipMemoryTypeHost;
 }
 
-struct HostPipe {
-  hipStream_t stream[2] = {nullptr, nullptr};
-  void* dx[2] = {nullptr, nullptr};
-  void* dy[2] = {nullptr, nullptr};
-  void* hx[2] = {nullptr, nullptr};
-  void* hy[2] = {nullptr, nullptr};
-  ~HostPipe() {
-    for (int i = 0; i < 2; ++i) {
-      if (stream[i]) (void)hipStreamDestroy(stream[i]);
-      (void)hipFree(dx[i]);
-      (void)hipFree(dy[i]);
-      if (hx[i]) (void)hipHostFree(hx[i]);
-      if (hy[i]) (void)hipHostFree(hy[i]);
-    }
-  }
-};
-
 }  // namespace
 
 int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t ldx, void* y_host,
@@ -1130,8 +1164,10 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
   const int64_t ldx_d = (int64_t)(xrow_d / xsz);
   if (chunk_rows <= 0) {
     chunk_rows = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(xrow_d, 1)));
+    chunk_rows = std::min(chunk_rows, n_batch);
+    const size_t need = 2 * (size_t)chunk_rows * (xrow_d + (size_t)D * ysz);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    if (need > ((size_t)2 << 30) && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const int64_t fit = (int64_t)(free_b / 4 / (xrow_d + (size_t)D * ysz + 1));
       chunk_rows = std::max<int64_t>(1, std::min(chunk_rows, fit));
     }
@@ -1141,14 +1177,11 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
   // a pinned source with the device pitch can be DMA'd row-block-wise without staging
   const bool x_direct = x_pinned, y_direct = y_pinned;
 
-  HostPipe pipe;
-  for (int i = 0; i < 2; ++i) {
-    SMM_HIP(hipStreamCreateWithFlags(&pipe.stream[i], hipStreamNonBlocking));
-    SMM_HIP(hipMalloc(&pipe.dx[i], (size_t)chunk_rows * xrow_d));
-    SMM_HIP(hipMalloc(&pipe.dy[i], (size_t)chunk_rows * D * ysz));
-    if (!x_direct) SMM_HIP(hipHostMalloc(&pipe.hx[i], (size_t)chunk_rows * S * xsz, hipHostMallocDefault));
-    if (!y_direct) SMM_HIP(hipHostMalloc(&pipe.hy[i], (size_t)chunk_rows * D * ysz, hipHostMallocDefault));
-  }
+  std::lock_guard<std::mutex> pipe_lock(op->pipe_mu);
+  HostPipe& pipe = op->pipe;
+  SMM_HIP(pipe.ensure((size_t)chunk_rows * xrow_d, (size_t)chunk_rows * D * ysz,
+                      x_direct ? 0 : (size_t)chunk_rows * S * xsz,
+                      y_direct ? 0 : (size_t)chunk_rows * D * ysz));
 
   const int64_t n_chunks = (n_batch + chunk_rows - 1) / chunk_rows;
   auto drain = [&](int64_t c) -> int {  // results of chunk c: wait, then pinned -> user rows

@@ -374,3 +374,27 @@ def test_apply_is_reentrant_across_threads_and_streams(hip, rng):
     assert not errors
     for o, r in zip(outs, refs):
         assert_same(o, r, exact=True)
+
+
+@pytest.mark.parametrize("kname,kflag", KERNELS)
+def test_row_pitch_larger_than_grid(hip, rng, kname, kflag):
+    """smm_apply with ldx > S and ldy > D (fields embedded in wider device buffers)."""
+    import ctypes
+    from smmregrid_amd.device import DeviceArray
+    n_src, n_dst, B = 1024, 300, 6
+    src, dst, w = random_links(rng, n_src, n_dst, 1500)
+    op = make_op(n_src, n_dst, src, dst, w)
+    need_kernel(op, kname)
+    ldx, ldy = n_src + 16, n_dst + 5
+    xw = np.full((B, ldx), np.nan)
+    xw[:, :n_src] = field(rng, B, n_src)
+    yw = np.full((B, ldy), -7.0)
+    dx, dy = to_device(xw), to_device(yw)
+    _lib.call("smm_apply", op.handle, ctypes.c_void_p(dx.ptr), _lib.SMM_F64, ldx, ctypes.c_void_p(dy.ptr),
+              _lib.SMM_F64, ldy, B, 0.0, kflag, None)
+    got = dy.to_host()
+    assert_same(got[:, :n_dst], oracle.apply_c(op.export_csr(), np.ascontiguousarray(xw[:, :n_src])), exact=True)
+    assert (got[:, n_dst:] == -7.0).all()          # the padding columns of Y are untouched
+    with pytest.raises(_lib.SmmError):             # pitch smaller than the grid
+        _lib.call("smm_apply", op.handle, ctypes.c_void_p(dx.ptr), _lib.SMM_F64, n_src - 1,
+                  ctypes.c_void_p(dy.ptr), _lib.SMM_F64, ldy, B, 0.0, 0, None)
