@@ -205,6 +205,18 @@ int smm_group_apply(smm_group_t g,
                     const int32_t* level_index, const uint8_t* masked_levels,
                     double remap_area_min, unsigned flags, void* stream);
 
+/*
+ * Host-buffer variant (the fields Regridder.regrid3d receives): X host C-contiguous
+ * (n_outer, n_lev, n_inner, S); Y host (n_outer, n_inner, n_lev, D) when transpose != 0
+ * (regrid.py:420-427) else (n_lev, n_outer, n_inner, D) (regrid.py:410).  Chunks of the outer
+ * axis flow through the same double-buffered pipeline as smm_apply_host.  Synchronous.
+ */
+int smm_group_apply_host(smm_group_t g,
+                         const void* x_host, int x_dtype, void* y_host, int y_dtype,
+                         int64_t n_outer, int64_t n_lev, int64_t n_inner, int transpose,
+                         const int32_t* level_index, const uint8_t* masked_levels,
+                         double remap_area_min, unsigned flags, int64_t chunk_outer);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,7 @@ SIGNATURES = {
     "smm_apply_host": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _i64],
     "smm_group_apply": [_p, _p, _int, _i64, _i64, _i64, _p, _int, _i64, _i64, _i64,
                         _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
+    "smm_group_apply_host": [_p, _p, _int, _p, _int, _i64, _i64, _i64, _int, _p, _p, _dbl, _uint, _i64],
 }
 SPECIAL = {"smm_abi_version": (_int, []), "smm_last_error": (ctypes.c_char_p, [])}
 

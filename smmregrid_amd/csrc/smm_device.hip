@@ -578,6 +578,8 @@ struct smm_group {
   // uploaded (level_index, masked_levels) configurations, keyed by content
   std::mutex mu;
   std::map<std::string, void*> cfg_cache;
+  std::mutex pipe_mu;  // smm_group_apply_host calls on one group take turns
+  HostPipe pipe;
 };
 
 namespace {
@@ -1411,6 +1413,112 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
                    g->tile_valid, g->tile_preferred, g->tile_reuse, g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
+}
+
+// Host-buffer variant of smm_group_apply: X host (n_outer, n_lev, n_inner, S) C-contiguous,
+// Y host (n_outer, n_inner, n_lev, D) when transpose != 0 (regrid.py:420-427), else
+// (n_lev, n_outer, n_inner, D) (concat order, regrid.py:410).  Chunks of the outer axis
+// stream through the group's double-buffered H2D / kernel / D2H pipeline.
+int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y_host, int y_dtype,
+                         int64_t n_outer, int64_t n_lev, int64_t n_inner, int transpose,
+                         const int32_t* level_index, const uint8_t* masked_levels,
+                         double remap_area_min, unsigned flags, int64_t chunk_outer) {
+  if (!g) return fail(SMM_ERR_INVALID, "null group");
+  if (n_outer < 0 || n_lev < 0 || n_inner < 0) return fail(SMM_ERR_INVALID, "negative batch size");
+  if ((x_dtype != SMM_F32 && x_dtype != SMM_F64) || (y_dtype != SMM_F32 && y_dtype != SMM_F64))
+    return fail(SMM_ERR_UNSUPPORTED, "field dtype must be SMM_F32 or SMM_F64");
+  const int64_t S = g->ops[0]->csr.n_src, D = g->ops[0]->csr.n_dst;
+  if (n_outer == 0 || n_lev == 0 || n_inner == 0 || D == 0) return SMM_OK;
+  if (!x_host || !y_host) return fail(SMM_ERR_INVALID, "null field pointer");
+  DeviceGuard guard(g->device);
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
+
+  const size_t xsz = x_dtype == SMM_F64 ? 8 : 4, ysz = y_dtype == SMM_F64 ? 8 : 4;
+  const size_t xrow_d = (((size_t)S * xsz + 15) / 16) * 16;   // device rows 16-B aligned
+  const int64_t ldx_d = (int64_t)(xrow_d / xsz);
+  const int64_t rows_per_outer = n_lev * n_inner;
+  const size_t x_outer_d = (size_t)rows_per_outer * xrow_d;   // device bytes per outer index
+  const size_t y_outer = (size_t)rows_per_outer * D * ysz;    // Y bytes per outer index
+  if (chunk_outer <= 0) {
+    chunk_outer = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(x_outer_d, 1)));
+    chunk_outer = std::min(chunk_outer, n_outer);
+    size_t free_b = 0, total_b = 0;
+    if (2 * (size_t)chunk_outer * (x_outer_d + y_outer) > ((size_t)2 << 30) &&
+        hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      chunk_outer = std::max<int64_t>(1, std::min<int64_t>(chunk_outer, (int64_t)(free_b / 4 / (x_outer_d + y_outer + 1))));
+  }
+  chunk_outer = std::min(chunk_outer, n_outer);
+  const bool x_direct = is_pinned(x_host), y_direct = is_pinned(y_host);
+
+  std::lock_guard<std::mutex> pipe_lock(g->pipe_mu);
+  HostPipe& pipe = g->pipe;
+  SMM_HIP(pipe.ensure((size_t)chunk_outer * x_outer_d, (size_t)chunk_outer * y_outer,
+                      x_direct ? 0 : (size_t)chunk_outer * rows_per_outer * S * xsz,
+                      y_direct ? 0 : (size_t)chunk_outer * y_outer));
+
+  const int64_t n_chunks = (n_outer + chunk_outer - 1) / chunk_outer;
+  auto drain = [&](int64_t c) -> int {
+    const int b = (int)(c & 1);
+    SMM_HIP(hipStreamSynchronize(pipe.stream[b]));
+    if (!y_direct) {
+      const int64_t o0 = c * chunk_outer, no = std::min(chunk_outer, n_outer - o0);
+      if (transpose) {
+        host_copy((char*)y_host + (size_t)o0 * y_outer, pipe.hy[b], (size_t)no * y_outer);
+      } else {  // device chunk is (n_lev, no, n_inner, D); host is (n_lev, n_outer, n_inner, D)
+        const size_t blk = (size_t)no * n_inner * D * ysz;
+        for (int64_t l = 0; l < n_lev; ++l)
+          host_copy((char*)y_host + ((size_t)l * n_outer + (size_t)o0) * n_inner * D * ysz,
+                    (char*)pipe.hy[b] + (size_t)l * blk, blk);
+      }
+    }
+    return SMM_OK;
+  };
+
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    const int b = (int)(c & 1);
+    const int64_t o0 = c * chunk_outer, no = std::min(chunk_outer, n_outer - o0);
+    const int64_t rows = no * rows_per_outer;
+    if (c >= 2) {
+      int rc = drain(c - 2);
+      if (rc) return rc;
+    }
+    const char* xsrc = (const char*)x_host + (size_t)o0 * rows_per_outer * S * xsz;
+    const void* h2d_src = xsrc;
+    if (!x_direct) {
+      host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
+      h2d_src = pipe.hx[b];
+    }
+    SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, h2d_src, (size_t)S * xsz, (size_t)S * xsz, (size_t)rows,
+                             hipMemcpyHostToDevice, pipe.stream[b]));
+    int64_t ys_o, ys_l, ys_i;
+    if (transpose) {
+      ys_o = n_inner * n_lev * D, ys_l = D, ys_i = n_lev * D;
+    } else {
+      ys_o = n_inner * D, ys_l = no * n_inner * D, ys_i = D;
+    }
+    int rc = smm_group_apply(g, pipe.dx[b], x_dtype, rows_per_outer * ldx_d, n_inner * ldx_d, ldx_d,
+                             pipe.dy[b], y_dtype, ys_o, ys_l, ys_i, no, n_lev, n_inner, level_index,
+                             masked_levels, remap_area_min, flags, pipe.stream[b]);
+    if (rc) return rc;
+    if (!y_direct) {
+      SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)no * y_outer, hipMemcpyDeviceToHost,
+                             pipe.stream[b]));
+    } else if (transpose) {
+      SMM_HIP(hipMemcpyAsync((char*)y_host + (size_t)o0 * y_outer, pipe.dy[b], (size_t)no * y_outer,
+                             hipMemcpyDeviceToHost, pipe.stream[b]));
+    } else {
+      const size_t blk = (size_t)no * n_inner * D * ysz;
+      for (int64_t l = 0; l < n_lev; ++l)
+        SMM_HIP(hipMemcpyAsync((char*)y_host + ((size_t)l * n_outer + (size_t)o0) * n_inner * D * ysz,
+                               (char*)pipe.dy[b] + (size_t)l * blk, blk, hipMemcpyDeviceToHost,
+                               pipe.stream[b]));
+    }
+  }
+  for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks; ++c) {
+    int rc = drain(c);
+    if (rc) return rc;
+  }
+  return SMM_OK;
 }
 
 }  // extern "C"

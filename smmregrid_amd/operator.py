@@ -204,6 +204,33 @@ class OperatorGroup:
                   float(remap_area_min), fl, _stream_handle(stream))
         return y
 
+    def apply_host(self, x, level_index, masked_levels=None, masked=False, remap_area_min=0.0,
+                   transpose=True, out_dtype=np.float64, flags=0, chunk_outer=0):
+        """Host (numpy) variant: x of shape (n_outer, n_lev, n_inner, S); chunks of the outer
+        axis stream through the group's H2D / kernel / D2H pipeline (smm_group_apply_host)."""
+        x = np.asarray(x)
+        if x.dtype not in (np.float32, np.float64):
+            x = x.astype(np.float64)
+        x = np.ascontiguousarray(x)
+        if x.ndim != 4 or x.shape[3] != self.n_src:
+            raise ValueError(f"X must be (n_outer, n_lev, n_inner, {self.n_src}), got {x.shape}")
+        n_outer, n_lev, n_inner, _ = x.shape
+        lev = np.ascontiguousarray(level_index, dtype=np.int32).ravel()
+        if lev.size != n_lev:
+            raise ValueError("level_index must have one entry per data level")
+        ml = None
+        if masked_levels is not None:
+            ml = np.ascontiguousarray(masked_levels, dtype=np.uint8).ravel()
+            if ml.size != len(self.operators):
+                raise ValueError("masked_levels must have one entry per group member")
+        shape = (n_outer, n_inner, n_lev, self.n_dst) if transpose else (n_lev, n_outer, n_inner, self.n_dst)
+        out = np.empty(shape, dtype=out_dtype)
+        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
+        _lib.call("smm_group_apply_host", self.handle, _cptr(x), dtype_code(x.dtype), _cptr(out),
+                  dtype_code(out.dtype), n_outer, n_lev, n_inner, int(bool(transpose)), _cptr(lev),
+                  _cptr(ml), float(remap_area_min), fl, int(chunk_outer))
+        return out
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.call("smm_group_destroy", self.handle)

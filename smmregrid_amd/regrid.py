@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray, empty, mem_info, to_device
+from .device import DeviceArray
 from .gridtype import GridType, tolist
 from .operator import OperatorGroup
 from .weights import (_level_slice, check_mask, compute_weights_matrix, compute_weights_matrix3d,
@@ -236,13 +236,6 @@ class Regridder(object):
         out.attrs.pop('CDI_grid_type', None)
         return out
 
-    @staticmethod
-    def _batch_rows(n_rows, row_bytes):
-        """Rows per pass so that X and Y chunks fit comfortably in free HBM."""
-        free, _ = mem_info()
-        budget = max(int(free * 0.6), 64 << 20)
-        return max(1, min(n_rows, budget // max(row_bytes, 1)))
-
     def apply_weights(self, source_data, weights, weights_matrix=None, masked=True,
                       horizontal_dims=None):
         """regrid.py:458-628 for one 2-D operator."""
@@ -354,24 +347,9 @@ class Regridder(object):
             host = np.ascontiguousarray(host).reshape(n_outer, n_lev, n_inner, -1)
             if host.shape[3] != S:
                 raise ValueError(f"source grid has {host.shape[3]} cells, weights expect {S}")
-            if self.transpose:
-                out = np.empty((n_outer, n_inner, n_lev, D), dtype=np.float64)
-            else:
-                out = np.empty((n_lev, n_outer, n_inner, D), dtype=np.float64)
-            row_bytes = n_lev * n_inner * (S * host.dtype.itemsize + D * 8)
-            step = self._batch_rows(n_outer, row_bytes)
-            for o0 in range(0, n_outer, step):
-                o1 = min(n_outer, o0 + step)
-                x = to_device(host[o0:o1])
-                y = group.apply(x, level_index, masked_levels, masked=any_masked,
-                                remap_area_min=self.remap_area_min, transpose=self.transpose)
-                yh = y.to_host()
-                if self.transpose:
-                    out[o0:o1] = yh
-                else:
-                    out[:, o0:o1] = yh
-                x.free()
-                y.free()
+            # host field: chunks of the outer axis stream through the group's pipeline
+            out = group.apply_host(host, level_index, masked_levels, masked=any_masked,
+                                   remap_area_min=self.remap_area_min, transpose=self.transpose)
             out_data = out.reshape(out_shape)
 
         kept_for_coords = kept_dims

@@ -398,3 +398,28 @@ def test_row_pitch_larger_than_grid(hip, rng, kname, kflag):
     with pytest.raises(_lib.SmmError):             # pitch smaller than the grid
         _lib.call("smm_apply", op.handle, ctypes.c_void_p(dx.ptr), _lib.SMM_F64, n_src - 1,
                   ctypes.c_void_p(dy.ptr), _lib.SMM_F64, ldy, B, 0.0, 0, None)
+
+
+@pytest.mark.parametrize("transpose", [True, False])
+def test_group_apply_host_pipeline(hip, rng, transpose):
+    S, D, L = 642, 130, 4
+    ops, csrs = [], []
+    imask = (rng.random((L, D)) > 0.3).astype(np.int32)
+    frac = rng.random((L, D))
+    for l in range(L):
+        src, dst, w = random_links(rng, S, D, 400 + 100 * l)
+        op = make_op(S, D, src, dst, w)
+        op.set_epilogue(imask[l], frac[l])
+        ops.append(op)
+        csrs.append(op.export_csr())
+    grp = OperatorGroup(ops)
+    level_index = np.array([2, 0, 3], np.int32)
+    masked_levels = np.array([1, 1, 0, 1], np.uint8)
+    for n_outer, n_inner, dtype in [(7, 1, np.float64), (5, 2, np.float32), (1, 1, np.float64)]:
+        x = field(rng, n_outer * 3 * n_inner, S, dtype=dtype, nan_frac=0.03).reshape(n_outer, 3, n_inner, S)
+        ref = oracle.apply_levels(csrs, x, 1, level_index, masked_levels.astype(bool), imask, frac, 0.4,
+                                  transpose)
+        for chunk in (0, 1, 2, 3):
+            y = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.4,
+                               transpose=transpose, chunk_outer=chunk)
+            assert_same(y, ref, exact=True)
