@@ -423,3 +423,63 @@ def test_group_apply_host_pipeline(hip, rng, transpose):
             y = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.4,
                                transpose=transpose, chunk_outer=chunk)
             assert_same(y, ref, exact=True)
+
+
+# ----------------------------------------------------------------- full-size properties (configs 3 and 5 geometry)
+
+def test_config5_geometry_conserves_area_integral(hip, rng):
+    """r1440x721 -> r720x360 conservative at full grid size: the area-weighted integral of every
+    batch row is preserved (size-independent property), rows are stochastic."""
+    w = gridgen.conservative_weights("r1440x721", "r720x360")
+    S, D = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
+    assert (S, D) == (1038240, 259200)
+    op = make_op(S, D, w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values)
+    assert op.n_used_src == S and op.plan_info()["tile_preferred"]
+    src, dst = gridgen.parse_grid("r1440x721"), gridgen.parse_grid("r720x360")
+
+    def areas(g):
+        return (np.diff(np.sin(np.radians(g.lat_b)))[:, None] * np.radians(np.diff(g.lon_b))[None, :]).ravel()
+    x = field(rng, 6, S)
+    y = op.apply(to_device(x)).to_host()
+    np.testing.assert_allclose((y * areas(dst)).sum(axis=1), (x * areas(src)).sum(axis=1), rtol=1e-11)
+    ys = op.apply(to_device(x), flags=_lib.APPLY_KERNEL_SELL).to_host()
+    assert_same(y, ys, exact=True)
+    assert_same(y[:2], oracle.apply_c(op.export_csr(), x[:2]), exact=True)
+
+
+def test_config3_geometry_masked_levels(hip, rng):
+    """1442x1021 -> r360x180 conservative with two ocean masks (shallow, deep) at full grid size:
+    a field that is constant over the ocean regrids to the same constant wherever the unmasked
+    fraction reaches remap_area_min and to NaN elsewhere; level sub-selection picks the deep mask."""
+    src = gridgen.regular_grid(1442, 1021)
+    masks = gridgen.synthetic_ocean_masks(1442, 1021, 2, top=0.66, bottom=0.2)
+    w3 = gridgen.ConservativeLevels(src, "r360x180").stack(masks, [5.0, 3000.0])
+    ll = w3["link_length"].values
+    ops = []
+    for i in range(2):
+        op = make_op(src.size, 64800, w3["src_address"].values[i, :ll[i]], w3["dst_address"].values[i, :ll[i]],
+                     w3["remap_matrix"].values[i, :ll[i], 0])
+        imask = op.mask_apply(masks[i])
+        op.set_epilogue(imask, w3["dst_grid_frac"].values[i])
+        ops.append(op)
+    assert max(o.max_row_nnz for o in ops) > 32
+    grp = OperatorGroup(ops)
+    assert grp.plan_info()["tile_plan"] and grp.plan_info()["slices_per_block"] == 1
+    T = 3
+    x = np.full((T, 2, 1, src.size), 12.5)
+    for i in range(2):
+        x[:, i, 0, masks[i] == 0] = np.nan
+    y = grp.apply(to_device(x), np.array([0, 1], np.int32), np.array([1, 1], np.uint8), masked=True,
+                  remap_area_min=0.5, transpose=True).to_host()          # (T, 1, 2, D)
+    frac = w3["dst_grid_frac"].values
+    for i in range(2):
+        yi = y[:, 0, i, :]
+        valid = frac[i] >= 0.5
+        assert np.isnan(yi[:, ~valid]).all()
+        np.testing.assert_allclose(yi[:, valid], 12.5, rtol=1e-13)
+    ysell = grp.apply(to_device(x), np.array([0, 1], np.int32), np.array([1, 1], np.uint8), masked=True,
+                      remap_area_min=0.5, transpose=True, flags=_lib.APPLY_KERNEL_SELL).to_host()
+    assert_same(y, ysell, exact=True)
+    deep_only = grp.apply(to_device(x[:, 1:2]), np.array([1], np.int32), np.array([1, 1], np.uint8),
+                          masked=True, remap_area_min=0.5, transpose=True).to_host()
+    assert_same(deep_only[:, 0, 0, :], y[:, 0, 1, :], exact=True)
