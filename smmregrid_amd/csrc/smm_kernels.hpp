@@ -1,0 +1,439 @@
+// Device-side structures and HIP kernels of libsmmregrid_hip (gfx950).
+// Included once by smm_device.hip, which owns the handles, launch logic and the C ABI.
+//
+// Hot path of jhardenberg/smmregrid rebuilt for MI355X:
+//   regrid.py:545-547  fill of non-finite source values with 1e20     (fused, on load)
+//   regrid.py:550      tensordot(X(B,S), W(S,D))                      (CSR SpMM, HBM-bound)
+//   regrid.py:553-570  dst_imask / dst_frac / >1e19 -> NaN            (fused, on store)
+//   regrid.py:387-418  per-level loop, concat, transpose              (one grouped launch)
+//   weights.py:47-52   mask pre-compute                               (same kernel, B = 1)
+//
+// Summation order: links of a destination row are accumulated sequentially in
+// ascending source index with separate multiply and add (no FMA contraction),
+// exactly the order of the CPU oracle (oracle/), so f64 results are bit
+// identical to it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------ device structs
+
+struct LevelDesc {
+  const int64_t* slice_off;  // [n_slices + 1]
+  const int32_t* col;        // SELL slots (source cell index)
+  const double* val;         // SELL slots
+  const int32_t* rowlen;     // [n_slices * 64]
+  const uint8_t* imask;      // [n_dst] or null
+  const double* frac;        // [n_dst] or null
+  // LDS source-tile plan (null when not planned)
+  const int64_t* blk_chunk_off;  // [n_blocks + 1]
+  const int32_t* chunk_src;      // source chunk index per staged chunk
+  const int32_t* lcol;           // SELL slots (LDS element index)
+};
+
+struct ApplyArgs {
+  const LevelDesc* descs;     // device array
+  const int32_t* lev_map;     // device [n_lev] -> desc index, null = identity 0
+  const uint8_t* lev_masked;  // device [n_descs] per-desc mask switch, null = all
+  const void* x;
+  void* y;
+  int64_t xs_o, xs_l, xs_i;
+  int64_t ys_o, ys_l, ys_i;
+  int64_t n_j;       // n_outer * n_inner batch rows per level
+  int64_t n_inner;
+  int64_t n_dblocks; // destination blocks (4 slices each)
+  int64_t n_jtiles;
+  int64_t n_src, n_dst;
+  double area_min;
+  int masked;
+  int j_per_block;   // tile kernel: batch rows walked by one workgroup
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWavesPerBlock * 64;
+#ifndef SMM_CHUNK_ELEMS
+#define SMM_CHUNK_ELEMS 16
+#endif
+constexpr int kChunkElems = SMM_CHUNK_ELEMS;               // staged chunk: 128 B of f64, 64 B of f32
+constexpr int64_t kTileMaxChunks = 8192 / SMM_CHUNK_ELEMS;  // 64 KiB of f64 per staged batch row
+
+template <typename T>
+__device__ __forceinline__ double load_fixed(const T* __restrict__ p, bool fill) {
+  const T v = *p;
+  // numpy.ma.fix_invalid + filled (regrid.py:545-547): the fill value is the
+  // dtype's own cast of 1e20 (float32(1e20) for an f32 field).
+  const T f = (T)1e20;
+  return (double)((fill && !__builtin_isfinite(v)) ? f : v);
+}
+
+__device__ __forceinline__ double epilogue(double v, bool dead) {
+  // regrid.py:559, :563-565, :570 -- every branch yields NaN, so the order is immaterial
+  return (dead || v > 1e19) ? __builtin_nan("") : v;
+}
+
+// Row pointers of batch row j of level l.
+__device__ __forceinline__ int64_t row_off(int64_t j, int64_t l, int64_t n_inner, int64_t s_o,
+                                           int64_t s_l, int64_t s_i) {
+  const int64_t o = j / n_inner, i = j - o * n_inner;
+  return o * s_o + l * s_l + i * s_i;
+}
+
+// ------------------------------------------------------------------ kernel A
+// SELL-64, one destination row per lane, BT batch rows register-blocked so the
+// col/val stream is read once per BT outputs and BT independent gathers are in
+// flight per link.  Gathers hit X directly: neighbouring lanes read
+// neighbouring source cells, L1/L2 absorb the line reuse.
+template <typename XT, typename YT, int BT>
+__global__ __launch_bounds__(kThreads) void smm_apply_sell_kernel(ApplyArgs a, bool fill) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int64_t bid = blockIdx.x;
+  const int64_t db = bid % a.n_dblocks;
+  bid /= a.n_dblocks;
+  const int64_t jt = bid % a.n_jtiles;
+  const int64_t l = bid / a.n_jtiles;
+  const int di = a.lev_map ? a.lev_map[l] : 0;
+  const LevelDesc L = a.descs[di];
+
+  const int64_t slice = db * kWavesPerBlock + wave;
+  const int64_t d = slice * 64 + lane;
+  if (slice * 64 >= a.n_dst) return;
+
+  const int64_t j0 = jt * BT;
+  const XT* __restrict__ xr[BT];
+  YT* __restrict__ yr[BT];
+#pragma unroll
+  for (int t = 0; t < BT; ++t) {
+    int64_t j = j0 + t;
+    if (j > a.n_j - 1) j = a.n_j - 1;
+    xr[t] = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+    yr[t] = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+  }
+
+  const int64_t off = L.slice_off[slice];
+  const int nslots = (int)((L.slice_off[slice + 1] - off) >> 6);
+  const int len = L.rowlen[d];
+  const int32_t* __restrict__ cp = L.col + off + lane;
+  const double* __restrict__ vp = L.val + off + lane;
+
+  double acc[BT];
+#pragma unroll
+  for (int t = 0; t < BT; ++t) acc[t] = 0.0;
+
+  // Padded slots carry a valid column (the row's last one) and are masked out of the
+  // sum by a select, so the loop body is branch-free and two slots are in flight.
+#pragma unroll 2
+  for (int k = 0; k < nslots; ++k) {
+    const int32_t c = cp[(int64_t)k * 64];
+    const double w = vp[(int64_t)k * 64];
+    const bool on = k < len;
+    double xv[BT];
+#pragma unroll
+    for (int t = 0; t < BT; ++t) xv[t] = load_fixed(xr[t] + c, fill);
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+      const double p = w * xv[t];
+      const double s = acc[t] + p;
+      acc[t] = on ? s : acc[t];
+    }
+  }
+
+  if (d < a.n_dst) {
+    const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
+    bool dead = false;
+    if (use_mask && L.imask) dead = (L.imask[d] == 0);
+    if (a.area_min > 0.0 && L.frac) dead = dead || (L.frac[d] < a.area_min);
+#pragma unroll
+    for (int t = 0; t < BT; ++t) {
+      if (j0 + t < a.n_j) yr[t][d] = (YT)epilogue(acc[t], dead);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ kernel B
+// LDS source tile.  A workgroup owns 256 consecutive destination rows (4 SELL
+// slices) and walks j_per_block batch rows.  For each batch row it copies the
+// block's source chunks (whole 128-B lines, list order) into LDS with
+// 16-B-per-lane coalesced loads -- every needed HBM line is fetched exactly
+// once by a full-width access -- then each lane gathers its row's links from
+// LDS.
+//
+// Kernel B, pipelined form.  Each thread owns up to NP staging pieces whose row
+// offsets are computed once (they do not depend on the batch row), keeps the
+// next batch row's pieces in registers while the current one is consumed from
+// LDS, so the HBM latency of row j+1 overlaps the gather/store of row j and no
+// index load sits in front of a data load.  Every global / LDS load in the loop
+// is unconditional (clamped address + select): a load inside a per-lane branch
+// makes hipcc wait for it before the next one, which serialises the memory
+// round trips.  NT bit 0: non-temporal X loads (only when no staged line is
+// shared between blocks), bit 1: non-temporal Y stores.
+typedef u32x4 u32x4_u __attribute__((aligned(4)));  // 16-B piece that may start on any element
+
+// Rows with more than 16 links run one wave (64 destination rows) per workgroup: their source
+// tiles are large, and single-wave workgroups need no workgroup barrier, so the waves of a CU
+// drift apart and overlap each other's HBM waits.
+constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPerBlock : 1; }
+
+template <typename XT, typename YT, int MAXK, int NP, int NT>
+__global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
+  constexpr int WPB = tile_waves(MAXK);
+  constexpr int T = WPB * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  int64_t bid = blockIdx.x;
+  const int64_t db = bid % a.n_dblocks;
+  bid /= a.n_dblocks;
+  const int64_t jt = bid % a.n_jtiles;
+  const int64_t l = bid / a.n_jtiles;
+  const int di = a.lev_map ? a.lev_map[l] : 0;
+  const LevelDesc L = a.descs[di];
+
+  const int64_t slice = db * WPB + wave;
+  const int64_t d = slice * 64 + lane;
+  const bool row_live = d < a.n_dst;
+  const bool slice_live = slice * 64 < a.n_dst;
+
+  // MAXK > 0: the row's links live in registers across batch rows (LDS indices are
+  // < 8192, two per register); MAXK == 0 (rows longer than 48 links): re-read per row.
+  constexpr int KREG = MAXK > 0 ? MAXK : 2;
+  int len = 0, nslots = 0;
+  uint32_t lc2[KREG / 2];
+  double w[KREG];
+  int64_t soff = 0;
+  if (slice_live) {
+    soff = L.slice_off[slice];
+    nslots = (int)((L.slice_off[slice + 1] - soff) >> 6);
+    len = L.rowlen[d];
+  }
+  const int32_t* __restrict__ cp = L.lcol + soff + lane;   // global pointers on every path
+  const double* __restrict__ vp = L.val + soff + lane;
+  if (MAXK > 0 && nslots > 0) {  // wave-uniform; loads unconditional, slots past the slice clamp
+#pragma unroll
+    for (int k = 0; k < KREG; k += 2) {
+      const int k0 = min(k, nslots - 1), k1 = min(k + 1, nslots - 1);
+      const uint32_t c0 = (uint32_t)cp[(int64_t)k0 * 64];
+      const uint32_t c1 = (uint32_t)cp[(int64_t)k1 * 64];
+      lc2[k / 2] = (k < len ? c0 : 0u) | ((k + 1 < len ? c1 : 0u) << 16);
+      w[k] = vp[(int64_t)k0 * 64];
+      w[k + 1] = vp[(int64_t)k1 * 64];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KREG; k += 2) {
+      lc2[k / 2] = 0u;
+      w[k] = 0.0;
+      w[k + 1] = 0.0;
+    }
+  }
+  // wave-uniform trip count: longest row of this wave
+  int wmax = len;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
+  wmax = __builtin_amdgcn_readfirstlane(wmax);
+
+  bool dead = false;
+  if (row_live) {
+    const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
+    if (use_mask && L.imask) dead = (L.imask[d] == 0);
+    if (a.area_min > 0.0 && L.frac) dead = dead || (L.frac[d] < a.area_min);
+  }
+
+  const int64_t c0 = L.blk_chunk_off[db];
+  const int nch = (int)(L.blk_chunk_off[db + 1] - c0);
+  const int32_t* __restrict__ chunk_src = L.chunk_src + c0;
+  constexpr int kElemsPerPiece = 16 / (int)sizeof(XT);
+  constexpr int pieces_per_chunk = kChunkElems / kElemsPerPiece;
+  const int npieces = nch * pieces_per_chunk;
+  const XT* lds_x = (const XT*)smem;
+
+  // Pieces [wave*64 + k*256, +64) belong to this wave in round k.  poff = element offset of
+  // the piece inside a batch row (clamped so that the 16-B load stays inside the row),
+  // shift = elements by which the clamp moved it (non-zero only for the row's last piece),
+  // pvalid bit k = the piece exists.
+  const int np_w = __builtin_amdgcn_readfirstlane(
+      npieces > wave * 64 ? (npieces - wave * 64 + T - 1) / T : 0);
+  int32_t poff[NP];
+  unsigned pvalid = 0, shifted = 0;
+  int shift_amt = 0;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int p = tid + k * T;
+    poff[k] = 0;
+    if (k < np_w) {
+      const int pc = min(p, npieces - 1);
+      const int ch = pc / pieces_per_chunk;
+      const int sub = pc - ch * pieces_per_chunk;
+      int64_t e0 = (int64_t)chunk_src[ch] * kChunkElems + (int64_t)sub * kElemsPerPiece;
+      if (p < npieces && e0 < a.n_src) {
+        pvalid |= 1u << k;
+        if (e0 + kElemsPerPiece > a.n_src) {
+          const int64_t e1 = a.n_src >= kElemsPerPiece ? a.n_src - kElemsPerPiece : 0;
+          shifted |= 1u << k;
+          shift_amt = (int)(e0 - e1);
+          e0 = e1;
+        }
+        poff[k] = (int32_t)e0;
+      }
+    }
+  }
+  const bool tiny_row = a.n_src < kElemsPerPiece;  // cannot happen with a planned operator of >= 1 chunk
+
+  const int64_t j_begin = jt * a.j_per_block;
+  int64_t j_end = j_begin + a.j_per_block;
+  if (j_end > a.n_j) j_end = a.n_j;
+  if (j_begin >= j_end) return;
+
+  if (npieces == 0) {
+    // no destination row of this block has a link (land-only block): nothing to stage,
+    // no barrier needed -- every batch row gets epilogue(0)
+    if (row_live) {
+      const YT out = (YT)epilogue(0.0, dead);
+      for (int64_t j = j_begin; j < j_end; ++j) {
+        YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+        if (NT & 2)
+          __builtin_nontemporal_store(out, yrow + d);
+        else
+          yrow[d] = out;
+      }
+    }
+    return;
+  }
+
+  u32x4 v[NP];
+  auto load_row = [&](int64_t j) {
+    const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
+        const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
+        v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      if (k < np_w) {
+        u32x4 piece = v[k];
+        if ((shifted >> k) & 1u) {  // last piece of the row: move the valid tail to the front
+          XT tmp[2 * kElemsPerPiece];
+          __builtin_memcpy(tmp, &piece, 16);
+#pragma unroll
+          for (int e = 0; e < kElemsPerPiece; ++e) tmp[kElemsPerPiece + e] = (XT)0;
+          XT out[kElemsPerPiece];
+#pragma unroll
+          for (int e = 0; e < kElemsPerPiece; ++e) {
+            XT val = (XT)0;
+#pragma unroll
+            for (int q = 0; q < kElemsPerPiece; ++q)
+              if (q == e + shift_amt) val = tmp[q];
+            out[e] = val;
+          }
+          __builtin_memcpy(&piece, out, 16);
+        }
+        if ((pvalid >> k) & 1u) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = piece;
+      }
+    }
+  };
+
+#ifndef SMM_EXP_SKIP_STAGE
+  if (!tiny_row) load_row(j_begin);
+#else
+#pragma unroll
+  for (int k = 0; k < NP; ++k) v[k] = u32x4{0, 0, 0, 0};
+#endif
+  for (int64_t j = j_begin; j < j_end; ++j) {
+    store_tile();
+    __syncthreads();
+#ifndef SMM_EXP_SKIP_STAGE
+    if (j + 1 < j_end && !tiny_row) load_row(j + 1);
+#endif
+    if (slice_live) {
+      double acc = 0.0;
+#ifdef SMM_EXP_SKIP_COMPUTE
+      if (false) {
+#else
+      if (MAXK > 0) {
+#endif
+#pragma unroll
+        for (int k0 = 0; k0 < KREG; k0 += 4) {
+          if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static
+            double xv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int k = k0 + kk;
+              const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
+                                          : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
+              xv[kk] = load_fixed(lds_x + li, fill);  // unconditional: index 0 for unused slots
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int k = k0 + kk;
+              if (k < KREG) {
+                const double p = w[k] * xv[kk];
+                const double sum = acc + p;
+                acc = (k < len) ? sum : acc;
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int k = 0; k < wmax; ++k) {
+          const int kc = min(k, nslots - 1);
+          const bool on = k < len;
+          const int32_t li = cp[(int64_t)kc * 64];
+          const double xv = load_fixed(lds_x + (on ? li : 0), fill);
+          const double p = vp[(int64_t)kc * 64] * xv;
+          const double sum = acc + p;
+          acc = on ? sum : acc;
+        }
+      }
+      if (row_live) {
+        YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+        const YT out = (YT)epilogue(acc, dead);
+        if (NT & 2)
+          __builtin_nontemporal_store(out, yrow + d);
+        else
+          yrow[d] = out;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// counter-based synthetic field: splitmix64 -> two uniforms -> Box-Muller
+template <typename T>
+__global__ void smm_fill_random_kernel(T* __restrict__ dst, int64_t n, uint64_t seed, double mean,
+                                       double sigma) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    const float u1 = ((float)((z >> 40) + 1)) * (1.0f / 16777217.0f);      // (0, 1)
+    const float u2 = (float)((z >> 8) & 0xFFFFFF) * (1.0f / 16777216.0f);  // [0, 1)
+    const float r = sqrtf(-2.0f * __logf(u1));
+    const float g = r * __cosf(6.28318530718f * u2);
+    dst[i] = (T)(mean + sigma * (double)g);
+  }
+}
+
+// dst_imask[d] = y[d] < 0.5 ? 0 : 1      (weights.py:51)
+__global__ void smm_mask_threshold_kernel(const double* __restrict__ y, int32_t* __restrict__ m,
+                                          int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) m[i] = (y[i] < 0.5) ? 0 : 1;
+}
+
+}  // namespace
