@@ -40,8 +40,8 @@ WORKLOADS = {
     "cfg2": ("bil", "r1440x721", "r360x180", 3600, "f64"),
     "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
     "cfg1": ("bil", "r180x90", "r90x45", 1, "f64"),
-    # config-4 geometry (n1280-like regular Gaussian 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch
-    "cfg4s": ("bil", "r5120x2560", "hp1024", 128, "f32"),
+    # config-4 geometry (regular Gaussian n1280 = 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch
+    "cfg4s": ("bil", "n1280", "hp1024", 128, "f32"),
     # one masked level of config 3 as a 2-D problem (ocean fraction in the name), for kernel tuning
     "cfg3L66": ("conmask", (1442, 1021, 0.66), "r360x180", 1024, "f64"),
     "cfg3L35": ("conmask", (1442, 1021, 0.35), "r360x180", 1024, "f64"),

@@ -8,8 +8,8 @@ regrid.py:500-515, cdogenerate.py:320-343): 1-based ``src_address`` /
 ``dst_address``, ``remap_matrix[num_links, num_wgts]``, grid sizes, dims,
 masks, ``dst_grid_frac``, centre coordinates in radians.
 
-Supported: global regular lon/lat grids ``r<NX>x<NY>`` (CDO naming,
-cdogrid.py:15), explicit regular grids, HEALPix targets ``hp<NSIDE>[_nested|_ring]``
+Supported: global regular lon/lat grids ``r<NX>x<NY>`` / ``global_<res>``, regular
+Gaussian grids ``F<N>`` / ``n<N>`` (CDO naming, cdogrid.py:11-22), explicit regular grids, HEALPix targets ``hp<NSIDE>[_nested|_ring]``
 (cdogrid.py:18-19); methods ``bil`` (4-point bilinear), ``nn`` (nearest
 neighbour) and ``con`` (first-order conservative, `fracarea` normalisation,
 regular -> regular).
@@ -151,8 +151,23 @@ def healpix_centers(nside, nested=True):
     return lon, lat
 
 
+def gaussian_grid(n, name=None):
+    """Regular Gaussian grid F<N> / n<N>: 4N longitudes from 0, 2N Gauss-Legendre latitudes
+    (south to north here; cell bounds at mid-points, clipped at the poles)."""
+    x, _ = np.polynomial.legendre.leggauss(2 * n)
+    lat = np.degrees(np.arcsin(x))
+    lon = np.arange(4 * n) * (360.0 / (4 * n))
+    g = regular_grid_from_centers(lon, lat, name=name or f"F{n}")
+    g.lat_b[0], g.lat_b[-1] = -90.0, 90.0       # the first/last cells reach the poles
+    g.cdo_type = "gaussian"
+    return g
+
+
 _R_GRID = re.compile(r"^r(\d+)x(\d+)$")
 _HP_GRID = re.compile(r"^hp(\d+)(_nested|_ring)?$")
+_HPZ_GRID = re.compile(r"^hpz(\d+)$")
+_GAUSS_GRID = re.compile(r"^[Fn](\d+)$")
+_GLOBAL_GRID = re.compile(r"^global_(\d+(?:\.\d+)?)$")
 
 
 def parse_grid(spec):
@@ -167,6 +182,20 @@ def parse_grid(spec):
         nside = int(m.group(1))
         lon, lat = healpix_centers(nside, nested=(m.group(2) != "_ring"))
         return Grid("points", lon, lat, name=spec, cdo_type="healpix")
+    m = _HPZ_GRID.match(spec)
+    if m:
+        lon, lat = healpix_centers(2 ** int(m.group(1)), nested=True)
+        return Grid("points", lon, lat, name=spec, cdo_type="healpix")
+    m = _GAUSS_GRID.match(spec)
+    if m:
+        return gaussian_grid(int(m.group(1)), name=spec)
+    m = _GLOBAL_GRID.match(spec)
+    if m:
+        res = float(m.group(1))
+        nx, ny = int(round(360.0 / res)), int(round(180.0 / res))
+        lon = -180.0 + res * (np.arange(nx) + 0.5)          # CDO global_<res>: cell-centred from -180
+        lat = -90.0 + res * (np.arange(ny) + 0.5)
+        return regular_grid_from_centers(lon, lat, name=spec)
     raise ValueError(f"grid '{spec}' is not supported by the native weight generator")
 
 

@@ -135,3 +135,19 @@ def test_weights_file_roundtrip_npz_and_netcdf3(tmp_path, rng):
     csr_a = oracle.coo_to_csr(648, 72, w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values)
     csr_b = oracle.coo_to_csr(648, 72, r2["src_address"].values, r2["dst_address"].values, r2["remap_matrix"].values)
     assert all(np.array_equal(a, b) for a, b in zip(csr_a, csr_b))
+
+
+def test_gaussian_and_other_cdo_grid_names():
+    g = gridgen.parse_grid("F128")                              # basic_test.py:85: F128 -> 256 * 512 cells
+    assert g.size == 256 * 512 and g.cdo_type == "gaussian"
+    assert g.lat_b[0] == -90.0 and g.lat_b[-1] == 90.0 and (np.diff(g.lat) > 0).all()
+    np.testing.assert_allclose(g.lat[-1], 89.46282157, atol=1e-7)
+    assert gridgen.parse_grid("n32").size == 128 * 64
+    assert gridgen.parse_grid("hpz3").size == 768
+    assert gridgen.parse_grid("global_2.5").size == 144 * 72
+    w = gridgen.generate_weights("F32", "r24x12", method="con")
+    rows = np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0])
+    np.testing.assert_allclose(rows, 1.0, rtol=1e-12)
+    np.testing.assert_allclose(w["dst_grid_frac"].values, 1.0, rtol=1e-12)
+    wb = gridgen.generate_weights("F32", "hp4", method="bil")
+    assert wb.sizes["num_links"] == 4 * 192 and wb.attrs["source_grid"] == "gaussian"
