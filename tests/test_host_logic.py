@@ -19,7 +19,7 @@ def test_cdo_grid_names():
     hp = gridgen.parse_grid("hp32")
     assert hp.kind == "points" and hp.size == 12288          # basic_test.py:86 'hp32' -> 12288 cells
     with pytest.raises(ValueError):
-        gridgen.parse_grid("n128")
+        gridgen.parse_grid("gme30")                            # icosahedral: needs cdo
 
 
 def test_healpix_centres_known_values():
