@@ -87,7 +87,11 @@ class Regridder(object):
             self.grids = self._gridtype_from_data(source_grid_array)
             if len(self.grids) == 0:
                 raise ValueError('Cannot find any gridtype in your data, aborting!')
-            for gridtype in self.grids:
+            for index, gridtype in enumerate(self.grids):
+                if check_nan:
+                    # NaN pattern varying along a non-time dimension -> that dimension is masked
+                    gridtype = self._check_nan_variation(source_grid_array, gridtype)
+                    self.grids[index] = gridtype
                 generator = CdoGenerate(source_grid_array, target_grid, cdo=cdo,
                                         cdo_options=cdo_options, cdo_extra=cdo_extra,
                                         loglevel=loglevel)
@@ -140,6 +144,32 @@ class Regridder(object):
             gridtype.mask_dim = list(weights.coords)[0]
         self.extra_dims['mask'] = [gridtype.mask_dim]
         return [gridtype]
+
+    def _check_nan_variation(self, source_grid, gridtype):
+        """regrid.py:630-653 + util.py:56-85: if the NaN mask of the first variable (first time
+        step) changes along one of the unclassified dimensions, treat it as the masked dimension."""
+        if gridtype.mask_dim:
+            return gridtype
+        arrays = list(source_grid.data_vars.values()) if isinstance(source_grid, Dataset) else [source_grid]
+        arr = next((a for a in arrays if isinstance(a, DataArray)
+                    and GridType(a.dims, extra_dims=self.extra_dims) == gridtype), None)
+        if arr is None or not gridtype.other_dims:
+            return gridtype
+        if gridtype.time_dims and gridtype.time_dims[0] in arr.dims:
+            arr = arr.isel(**{gridtype.time_dims[0]: 0})
+        vals = arr.values
+        if not np.issubdtype(vals.dtype, np.floating):
+            return gridtype
+        nan_mask = np.isnan(vals)
+        nan_dims = [d for d in gridtype.other_dims if d in arr.dims
+                    and np.diff(nan_mask.astype(np.int8), axis=arr.dims.index(d)).astype(bool).any()]
+        if not nan_dims:
+            return gridtype
+        self.loggy.warning('Found NaN variation in dimensions: %s', nan_dims)
+        self.extra_dims['mask'] = nan_dims
+        new = GridType(dims=gridtype.dims + gridtype.other_dims + (gridtype.time_dims or []),
+                       extra_dims=self.extra_dims)
+        return new
 
     def _gridtype_from_data(self, data):
         grids = []

@@ -189,3 +189,30 @@ def test_sharded_regrid_single_rank_gloo(hip, rng):
         assert_same(out, oracle.apply_c(op.export_csr(), x), exact=True)
     finally:
         dist.destroy_process_group()
+
+
+def test_check_nan_auto_mask_dim(hip, rng):
+    """basic_test.py:95-102: check_nan=True finds the dimension along which the NaN pattern
+    varies (a pressure-level axis that is not a default mask name) and builds per-level weights;
+    NaN counts per level follow the per-level unmasked fraction."""
+    g = gridgen.parse_grid("r72x36")
+    nlev = 5
+    masks = gridgen.synthetic_ocean_masks(72, 36, nlev, top=0.7, bottom=1.0 - 1e-9)   # topography: fewer gaps higher up
+    masks[-1] = 1                                                                        # top level: no missing values
+    x = 3.0 + rng.standard_normal((2, nlev, 36, 72))
+    for l in range(nlev):
+        x[:, l].reshape(2, -1)[:, masks[l] == 0] = np.nan
+    field = DataArray(x, dims=("time", "plev", "lat", "lon"),
+                      coords={"time": np.arange(2), "plev": np.linspace(1000e2, 100e2, nlev), "lat": g.lat,
+                              "lon": g.lon}, name="ua")
+    rg = Regridder(source_grid=Dataset({"ua": field}), target_grid="r24x12", check_nan=True)
+    assert rg.grids[0].mask_dim == "plev"
+    out = rg.regrid(field.isel(time=0))
+    assert out.dims == ("plev", "lat", "lon")
+    count = np.isnan(out.values).reshape(nlev, -1).sum(axis=1)
+    cl = gridgen.ConservativeLevels(g, "r24x12")
+    expect = [int((cl.level(masks[l])["dst_grid_frac"].values < 0.5).sum()) for l in range(nlev)]
+    assert count.tolist() == expect and count[-1] == 0 and count[0] > 0
+    # without check_nan the axis is just a batch dimension: one set of weights from level 0's mask
+    rg2 = Regridder(source_grid=Dataset({"ua": field}), target_grid="r24x12")
+    assert rg2.grids[0].mask_dim is None
