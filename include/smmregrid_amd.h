@@ -217,6 +217,28 @@ int smm_group_apply_host(smm_group_t g,
                          const int32_t* level_index, const uint8_t* masked_levels,
                          double remap_area_min, unsigned flags, int64_t chunk_outer);
 
+/* ------------------------------------------------- multi-GPU exchange (RCCL over xGMI) */
+
+/*
+ * One process per GPU; batch rows are sharded over the ranks with no collective on the data
+ * path; these calls move the Y shards afterwards.  Rank 0 obtains an id with
+ * smm_comm_unique_id, distributes its SMM_COMM_ID_BYTES bytes to the other ranks by any
+ * host channel, then every rank (after smm_set_device) calls smm_comm_create.  librccl is
+ * bound at run time; SMM_ERR_UNSUPPORTED if it cannot be loaded.
+ *   gather   : root's recv_dev holds n_ranks * count elements, rank r's shard at r * count
+ *   allgather: every rank's recv_dev holds n_ranks * count elements
+ * Both are asynchronous on `stream`.
+ */
+#define SMM_COMM_ID_BYTES 128
+typedef struct smm_comm* smm_comm_t;
+int smm_comm_unique_id(void* id_out);
+int smm_comm_create(const void* id, int n_ranks, int rank, smm_comm_t* out);
+int smm_comm_destroy(smm_comm_t c);
+int smm_comm_gather(smm_comm_t c, const void* send_dev, void* recv_dev, int64_t count, int dtype,
+                    int root, void* stream);
+int smm_comm_allgather(smm_comm_t c, const void* send_dev, void* recv_dev, int64_t count, int dtype,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

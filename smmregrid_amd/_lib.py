@@ -86,6 +86,11 @@ SIGNATURES = {
     "smm_group_apply": [_p, _p, _int, _i64, _i64, _i64, _p, _int, _i64, _i64, _i64,
                         _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
     "smm_group_apply_host": [_p, _p, _int, _p, _int, _i64, _i64, _i64, _int, _p, _p, _dbl, _uint, _i64],
+    "smm_comm_unique_id": [_p],
+    "smm_comm_create": [_p, _int, _int, _pp],
+    "smm_comm_destroy": [_p],
+    "smm_comm_gather": [_p, _p, _p, _i64, _int, _int, _p],
+    "smm_comm_allgather": [_p, _p, _p, _i64, _int, _p],
 }
 SPECIAL = {"smm_abi_version": (_int, []), "smm_last_error": (ctypes.c_char_p, [])}
 

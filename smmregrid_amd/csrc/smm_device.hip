@@ -44,6 +44,14 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 
+}  // namespace
+
+namespace smm {
+int fail_msg(int code, const std::string& msg) { return fail(code, msg); }  // for smm_comm.cpp
+}
+
+namespace {
+
 #define SMM_HIP(call)                                                                   \
   do {                                                                                  \
     hipError_t e_ = (call);                                                             \

@@ -216,3 +216,27 @@ def test_check_nan_auto_mask_dim(hip, rng):
     # without check_nan the axis is just a batch dimension: one set of weights from level 0's mask
     rg2 = Regridder(source_grid=Dataset({"ua": field}), target_grid="r24x12")
     assert rg2.grids[0].mask_dim is None
+
+
+def test_native_rccl_comm_single_rank(hip):
+    """smm_comm_* (RCCL bound at run time, no torch): a world of one rank gathers to itself.
+    Runs in a fresh process: a process uses either torch.distributed or smm_comm, not both
+    (torch bundles its own RCCL build).  Multi-rank use needs one GPU per rank."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from smmregrid_amd import to_device\n"
+        "from smmregrid_amd.comm import Comm\n"
+        "from smmregrid_amd.device import synchronize, set_device\n"
+        "set_device(0)\n"
+        "comm = Comm(0, 1)\n"
+        "x = np.random.default_rng(1).standard_normal((5, 300))\n"
+        "shard = to_device(x)\n"
+        "g = comm.gather(shard); a = comm.allgather(shard); synchronize()\n"
+        "assert g.shape == (1, 5, 300) and np.array_equal(g.to_host()[0], x)\n"
+        "assert np.array_equal(a.to_host()[0], x)\n"
+        "comm.close(); print('native-comm-ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "native-comm-ok" in out.stdout, out.stderr[-2000:]
