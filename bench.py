@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--jpb", type=int, default=0, help="tile kernel: batch rows per workgroup")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
                     help="N>1: also time the steps followed by the RCCL gather of the Y shards to rank 0")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="N>1 plumbing: torch.distributed (nccl == RCCL) or the library's smm_comm_* (no torch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -239,6 +241,84 @@ class ProblemLevels:
                           f"{avail} visible), {spent:.1f} s"}
 
 
+class TorchDist:
+    """torch.distributed over RCCL; torch owns the Y buffers so the collective can move them."""
+
+    def __init__(self, local_rank):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.dev = torch, dist, f"cuda:{local_rank}"
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.y_t = self.parts = None
+
+    def alloc_y(self, shape):
+        from smmregrid_amd.device import DeviceArray
+        self.y_t = self.torch.empty(shape, dtype=self.torch.float64, device=self.dev)
+        return DeviceArray(shape, np.float64, ptr=self.y_t.data_ptr())
+
+    def prepare_gather(self, y, root=0):
+        self.root = root
+        if self.rank == root:
+            self.parts = [self.torch.empty_like(self.y_t) for _ in range(self.world)]
+
+    def gather(self):
+        self.dist.gather(self.y_t, self.parts, dst=self.root)
+
+    def barrier(self):
+        self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max(self, value):
+        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class NativeDist:
+    """The library's RCCL communicator (smm_comm_*): id exchange over TCP, no torch."""
+
+    def __init__(self, rank, world):
+        from smmregrid_amd.comm import Comm
+        from smmregrid_amd.device import DeviceArray
+        self.rank, self.world = rank, world
+        self.comm = Comm(rank, world)
+        self.scalar = DeviceArray((1,), np.float64)
+        self.scalars = DeviceArray((world, 1), np.float64)
+        self.y = self.out = None
+
+    def alloc_y(self, shape):
+        from smmregrid_amd.device import DeviceArray
+        self.y = DeviceArray(shape, np.float64)
+        return self.y
+
+    def prepare_gather(self, y, root=0):
+        from smmregrid_amd.device import DeviceArray
+        self.root = root
+        if self.rank == root:
+            self.out = DeviceArray((self.world,) + tuple(y.shape), np.float64)
+
+    def gather(self):
+        self.comm.gather(self.y, root=self.root, out=self.out)   # on the null stream, after the kernel
+
+    def max(self, value):
+        from smmregrid_amd.device import synchronize
+        self.scalar.copy_from_host(np.array([value]))
+        self.comm.allgather(self.scalar, out=self.scalars)
+        synchronize()
+        return float(self.scalars.to_host().max())
+
+    def barrier(self):
+        self.max(0.0)
+
+    def close(self):
+        self.comm.close()
+
+
 def cpu_threads():
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return int(os.environ.get("SMM_CPU_THREADS", min(avail, 16))), avail  # 16 = one GPU's CPU share
@@ -256,26 +336,21 @@ def main():
     from smmregrid_amd import _lib
     from smmregrid_amd.device import DeviceArray, Event, device_name, set_device, synchronize
 
-    dist = torch = None
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # multi-process plumbing: torch.distributed (backend nccl == RCCL) by default, or the library's
+    # own RCCL communicator (--comm native: no torch in the process at all)
+    comm = None
+    if use_dist and args.comm == "torch":
+        comm = TorchDist(local_rank)
     set_device(local_rank)
+    if use_dist and args.comm == "native":
+        comm = NativeDist(rank, world)
 
     cls = ProblemLevels if WORKLOADS[args.workload][0] == "con3d" else Problem2D
     prob = cls(args.workload, local_rank, rank, batch=args.batch)
 
-    # with N > 1 torch owns the Y buffer so RCCL can move it
-    y_t = gathered = None
-    if use_dist:
-        y_t = torch.empty(prob.y_shape, dtype=torch.float64, device=f"cuda:{local_rank}")
-        y = DeviceArray(prob.y_shape, np.float64, ptr=y_t.data_ptr())
-        if args.gather == "root" and rank == 0:
-            gathered = [torch.empty_like(y_t) for _ in range(world)]
-    else:
-        y = DeviceArray(prob.y_shape, np.float64)
+    y = comm.alloc_y(prob.y_shape) if comm else DeviceArray(prob.y_shape, np.float64)
+    if comm and args.gather == "root":
+        comm.prepare_gather(y, root=0)
 
     flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
     flags |= (args.variant << 16) | (args.jpb << 20)
@@ -283,17 +358,16 @@ def main():
     def step(events=None, gather=False):
         if events:
             events[0].record()
-        prob.run(y, flags)            # launches on the null stream, which torch's stream orders with
+        prob.run(y, flags)            # launches on the null stream, which the collective is ordered after
         if events:
             events[1].record()
         if gather:
-            dist.gather(y_t, gathered, dst=0)
+            comm.gather()
 
     def barrier():
         synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
+        if comm:
+            comm.barrier()
 
     def timed(gather):
         """W warm-up steps, then exactly K steps between barriers; MAX over ranks."""
@@ -306,10 +380,8 @@ def main():
             step(ev[k], gather=gather)
         barrier()
         dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        if comm:
+            dt = comm.max(dt)
         return dt, [a.elapsed_ms(b) for a, b in ev]
 
     # the measured job: every rank regrids its shard, Y shards stay resident on their GPUs
@@ -317,7 +389,7 @@ def main():
     # the same job followed by the RCCL gather of the Y shards to rank 0 (north star's exchange
     # step), reported beside it: xGMI-link bound, see DESIGN.md "Multi-GPU"
     with_gather = None
-    if use_dist and args.gather == "root":
+    if comm and args.gather == "root":
         try:
             g_elapsed, _ = timed(gather=True)
             with_gather = {"value": prob.cells() * world * args.steps / g_elapsed, "unit": "cells/s",
@@ -335,7 +407,7 @@ def main():
             key = f"{args.workload}/{args.batch or 'default'}/{args.kernel}/{args.variant}"
             traffic = json.load(open(args.traffic_json)).get(key, {}).get("hbm_bytes_per_launch")
         cfg = {"workload": prob.desc, "kernel": args.kernel,
-               "gather": args.gather if use_dist else "n/a", "device": device_name(local_rank)}
+               "gather": args.gather if comm else "n/a", "comm": args.comm if comm else "n/a", "device": device_name(local_rank)}
         cfg.update(prob.meta)
         out = {
             "metric": "regridded cells/sec (dst_pts x time x lev)",
@@ -366,9 +438,9 @@ def main():
             out["cpu_baseline"] = prob.cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":
