@@ -483,3 +483,19 @@ def test_config3_geometry_masked_levels(hip, rng):
     deep_only = grp.apply(to_device(x[:, 1:2]), np.array([1], np.int32), np.array([1, 1], np.uint8),
                           masked=True, remap_area_min=0.5, transpose=True).to_host()
     assert_same(deep_only[:, 0, 0, :], y[:, 0, 1, :], exact=True)
+
+
+@pytest.mark.parametrize("tag", ["float64", "float32"])
+def test_hip_matches_reference_dask_statements(hip, tag):
+    """The HIP path against outputs of the reference's own dask statement sequence
+    (regrid.py:545-570 run with dask.array, tests/golden/make_dask_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "dask_statements.npz"))
+    op = make_op(int(z["n_src"]), int(z["n_dst"]), z["src_address"], z["dst_address"], z["remap_matrix"])
+    op.set_epilogue(z["dst_imask"], z["dst_frac"])
+    x = z["x_" + tag]
+    for masked, amin in ((False, 0.0), (True, 0.0), (True, 0.5), (False, 0.9)):
+        ref = z["y_%s_m%d_a%d" % (tag, int(masked), int(amin * 10))]
+        for flags in (_lib.APPLY_KERNEL_SELL, 0):
+            y = run(op, x.reshape(-1, x.shape[-1]), masked, amin, flags)
+            assert_same(y.reshape(ref.shape), ref, rtol=RTOL)          # north-star tolerance
+            assert_same(y.reshape(ref.shape), ref, rtol=1e-12)         # and in fact to rounding

@@ -224,3 +224,25 @@ def test_oracle_reproduces_golden(name):
         y = oracle.apply_c(csr, z["x"], bool(z["masked"]), z["dst_imask"], z["dst_frac"],
                            float(z["area_min"]))
     assert_same(y, z["y"], exact=True)
+
+
+# ----------------------------------------------------------------- the reference's own dask statements
+
+@pytest.mark.parametrize("tag", ["float64", "float32"])
+def test_oracle_matches_reference_dask_statements(tag):
+    """tests/golden/dask_statements.npz holds outputs of the reference's statement sequence
+    regrid.py:545-570 executed verbatim with dask.array 2021.10 (ma.fix_invalid / filled /
+    tensordot / where) on a dense copy of the weights (make_dask_golden.py): NaN positions must
+    match exactly, values to 1e-12 (dense BLAS vs sparse summation order)."""
+    z = np.load(os.path.join(GOLDEN, "dask_statements.npz"))
+    csr = oracle.coo_to_csr_c(int(z["n_src"]), int(z["n_dst"]), z["src_address"], z["dst_address"],
+                              z["remap_matrix"])
+    x = z["x_" + tag]
+    for masked, amin in ((False, 0.0), (True, 0.0), (True, 0.5), (False, 0.9)):
+        ref = z["y_%s_m%d_a%d" % (tag, int(masked), int(amin * 10))]
+        for fn in (oracle.apply_c, oracle.apply):
+            y = fn(csr, x.reshape(-1, x.shape[-1]), masked, z["dst_imask"], z["dst_frac"], amin)
+            assert_same(y.reshape(ref.shape), ref, rtol=1e-12)
+    # the float32 field was filled with float32(1e20), not 1e20: a 0.05-weight link to a missing
+    # value stays finite and carries exactly that constant
+    assert np.isfinite(z["y_float32_m0_a0"]).any()
