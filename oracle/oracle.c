@@ -12,7 +12,9 @@
  * un-vendored dependencies (pydata/sparse COO, dask.array.tensordot; both
  * unpinned in pyproject.toml:23-33) compute, and is cross-checked in
  * tests/test_oracle.py against an independent numpy/scipy.sparse restatement
- * (oracle/oracle.py) and analytic known answers.
+ * (oracle/oracle.py), analytic known answers, and outputs of the reference's
+ * statement sequence regrid.py:545-570 executed with dask.array on dense weights
+ * (tests/golden/dask_statements.npz).
  *
  * Reference lines followed:
  *   weights.py:31-39   src/dst_address - 1, remap_matrix[:,0], COO((src,dst), w, (S,D))

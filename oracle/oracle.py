@@ -14,7 +14,11 @@ pyproject.toml:23-33), and is pinned by
 * two independent implementations that must agree bit for bit on indices and
   to 1e-13 on values: numpy/scipy.sparse (this file) and sequential C
   (oracle.c);
-* analytic known answers mirroring the reference's tests (tests/test_oracle.py).
+* analytic known answers mirroring the reference's tests (tests/test_oracle.py);
+* tests/golden/dask_statements.npz: outputs of the reference's statement sequence
+  regrid.py:545-570 executed verbatim with dask.array (fill, tensordot, where's) on a
+  dense copy of the weights -- only the sparse.COO constructor / summation order of the
+  product remain unpinned.
 
 Reference lines followed (paths relative to /root/reference/smmregrid):
   weights.py:25-44    compute_weights_matrix   -> coo_to_csr
