@@ -76,6 +76,13 @@ def main():
                 else:
                     out[key] = y
         assert out["y_%s_m0_a0" % tag].dtype == numpy.float64     # result_type(x, f64)
+    # --- weights.py:47-52 mask_tensordot, verbatim, with int32 source masks
+    for i in range(3):
+        src_mask = (rng.random(S) > 0.3 * (i + 1) / 3).astype(numpy.int32)
+        target_mask = dask.array.tensordot(src_mask, dense, axes=1)
+        target_mask = dask.array.where(target_mask < 0.5, 0, 1)
+        out["src_imask_%d" % i] = src_mask
+        out["mask_tensordot_%d" % i] = numpy.asarray(target_mask.compute())
     out["versions"] = numpy.array("dask %s, numpy %s" % (dask.__version__, numpy.__version__))
     numpy.savez_compressed(os.path.join(HERE, "dask_statements.npz"), **out)
     print("written", out["versions"])

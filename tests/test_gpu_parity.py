@@ -499,3 +499,5 @@ def test_hip_matches_reference_dask_statements(hip, tag):
             y = run(op, x.reshape(-1, x.shape[-1]), masked, amin, flags)
             assert_same(y.reshape(ref.shape), ref, rtol=RTOL)          # north-star tolerance
             assert_same(y.reshape(ref.shape), ref, rtol=1e-12)         # and in fact to rounding
+    for i in range(3):          # weights.py:47-52 executed with dask.array
+        assert np.array_equal(op.mask_apply(z["src_imask_%d" % i]), z["mask_tensordot_%d" % i])

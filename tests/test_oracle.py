@@ -243,6 +243,9 @@ def test_oracle_matches_reference_dask_statements(tag):
         for fn in (oracle.apply_c, oracle.apply):
             y = fn(csr, x.reshape(-1, x.shape[-1]), masked, z["dst_imask"], z["dst_frac"], amin)
             assert_same(y.reshape(ref.shape), ref, rtol=1e-12)
+    for i in range(3):          # weights.py:47-52 executed with dask.array
+        assert np.array_equal(oracle.mask_apply_c(csr, z["src_imask_%d" % i]), z["mask_tensordot_%d" % i])
+        assert np.array_equal(oracle.mask_apply(csr, z["src_imask_%d" % i]), z["mask_tensordot_%d" % i])
     # the float32 field was filled with float32(1e20), not 1e20: a 0.05-weight link to a missing
     # value stays finite and carries exactly that constant
     assert np.isfinite(z["y_float32_m0_a0"]).any()
