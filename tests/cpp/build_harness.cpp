@@ -1,0 +1,78 @@
+// Host-only harness around smm_build.cpp (COO -> CSR -> SELL-64 -> LDS tile plans), compiled
+// with g++ -fsanitize=address,undefined by tests/test_build_sanitized.py.
+// stdin : n_src n_dst nnz, then nnz lines "src1 dst1 w"
+// stdout: the canonical CSR and invariants of the SELL / tile-plan structures.
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../smmregrid_amd/csrc/smm_internal.h"
+
+int main() {
+  long long n_src, n_dst, nnz;
+  if (scanf("%lld %lld %lld", &n_src, &n_dst, &nnz) != 3) return 2;
+  std::vector<int32_t> src((size_t)nnz), dst((size_t)nnz);
+  std::vector<double> w((size_t)nnz);
+  for (long long k = 0; k < nnz; ++k)
+    if (scanf("%d %d %lf", &src[(size_t)k], &dst[(size_t)k], &w[(size_t)k]) != 3) return 2;
+  smm::HostCsr csr;
+  std::string err;
+  if (!smm::build_csr(n_src, n_dst, nnz, src.data(), dst.data(), w.data(), csr, err)) {
+    printf("ERROR %s\n", err.c_str());
+    return 0;
+  }
+  smm::HostSell sell;
+  smm::build_sell(csr, sell);
+  printf("CSR %lld %lld %lld %lld\n", (long long)csr.nnz, (long long)csr.n_used_src,
+         (long long)csr.max_row_nnz, (long long)sell.n_slots);
+  for (int64_t d = 0; d <= csr.n_dst; ++d) printf("%lld ", (long long)csr.rowptr[(size_t)d]);
+  printf("\n");
+  for (int64_t p = 0; p < csr.nnz; ++p) printf("%d ", csr.col[(size_t)p]);
+  printf("\n");
+  for (int64_t p = 0; p < csr.nnz; ++p) printf("%.17g ", csr.val[(size_t)p]);
+  printf("\n");
+  // SELL invariants: every link sits at slice_off + k*64 + lane, padding repeats the last column
+  long long bad = 0;
+  for (int64_t d = 0; d < csr.n_dst; ++d) {
+    const int64_t s = d >> 6, r = d & 63;
+    const int64_t base = sell.slice_off[(size_t)s] + r;
+    const int64_t nslots = (sell.slice_off[(size_t)s + 1] - sell.slice_off[(size_t)s]) / 64;
+    const int32_t len = sell.rowlen[(size_t)d];
+    if (len != csr.rowptr[(size_t)d + 1] - csr.rowptr[(size_t)d] || len > nslots) ++bad;
+    for (int64_t k = 0; k < nslots; ++k) {
+      const int32_t c = sell.col[(size_t)(base + k * 64)];
+      const double v = sell.val[(size_t)(base + k * 64)];
+      if (k < len) {
+        if (c != csr.col[(size_t)(csr.rowptr[(size_t)d] + k)] || v != csr.val[(size_t)(csr.rowptr[(size_t)d] + k)]) ++bad;
+      } else {
+        if (v != 0.0 || c < 0 || (n_src > 0 && c >= n_src)) ++bad;
+      }
+    }
+  }
+  // both tile-plan shapes: every link's LDS index must resolve to its source column
+  for (int spb : {4, 1}) {
+    smm::HostTilePlan plan;
+    smm::build_tile_plan(csr, sell, spb, 16, 512 * spb / 4, plan);
+    long long pbad = 0;
+    if (plan.valid) {
+      const int64_t rows_per_block = (int64_t)spb * 64;
+      for (int64_t d = 0; d < csr.n_dst; ++d) {
+        const int64_t b = d / rows_per_block, s = d >> 6, r = d & 63;
+        const int64_t c0 = plan.blk_chunk_off[(size_t)b];
+        const int64_t base = sell.slice_off[(size_t)s] + r;
+        for (int32_t k = 0; k < sell.rowlen[(size_t)d]; ++k) {
+          const int32_t li = plan.lcol[(size_t)(base + (int64_t)k * 64)];
+          const int64_t ch = li / 16, e = li % 16;
+          if (c0 + ch >= plan.blk_chunk_off[(size_t)b + 1]) { ++pbad; continue; }
+          const int64_t col = (int64_t)plan.chunk_src[(size_t)(c0 + ch)] * 16 + e;
+          if (col != csr.col[(size_t)(csr.rowptr[(size_t)d] + k)]) ++pbad;
+        }
+      }
+    }
+    printf("PLAN %d %d %lld %lld %lld %lld\n", spb, (int)plan.valid, (long long)plan.max_block_chunks,
+           (long long)plan.total_chunks, (long long)plan.distinct_chunks, pbad);
+  }
+  printf("SELLBAD %lld\n", bad);
+  return 0;
+}
