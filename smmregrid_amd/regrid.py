@@ -92,7 +92,9 @@ class Regridder(object):
                     # NaN pattern varying along a non-time dimension -> that dimension is masked
                     gridtype = self._check_nan_variation(source_grid_array, gridtype)
                     self.grids[index] = gridtype
-                generator = CdoGenerate(source_grid_array, target_grid, cdo=cdo,
+                # weights are generated from one variable of this gridtype (regrid.py:171-177)
+                sample = next(iter(gridtype.variables.values()), source_grid_array)
+                generator = CdoGenerate(sample, target_grid, cdo=cdo,
                                         cdo_options=cdo_options, cdo_extra=cdo_extra,
                                         loglevel=loglevel)
                 gridtype.weights = generator.weights(method=method, mask_dim=gridtype.mask_dim)
@@ -169,6 +171,7 @@ class Regridder(object):
         self.extra_dims['mask'] = nan_dims
         new = GridType(dims=gridtype.dims + gridtype.other_dims + (gridtype.time_dims or []),
                        extra_dims=self.extra_dims)
+        new.variables = gridtype.variables
         return new
 
     def _gridtype_from_data(self, data):
@@ -181,8 +184,13 @@ class Regridder(object):
             if any(s in name for s in ("bnds", "bounds", "vertices")):
                 continue
             gt = GridType(dims=arr.dims, extra_dims=self.extra_dims)
-            if gt.horizontal_dims and gt not in grids:
+            if not gt.horizontal_dims:
+                continue
+            known = next((g for g in grids if g == gt), None)
+            if known is None:
                 grids.append(gt)
+                known = gt
+            known.variables[name] = arr          # gridinspector.py: variables living on this grid
         return grids
 
     # ------------------------------------------------------------------ public API

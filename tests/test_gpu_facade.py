@@ -240,3 +240,21 @@ def test_native_rccl_comm_single_rank(hip):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "native-comm-ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_two_gridtypes_in_one_dataset(hip, rng):
+    """multigrid_test.py:13-31: a Dataset with variables on two different grids gets one set of
+    weights per gridtype when initialised from grids; initialising from weights refuses it."""
+    a = tas_field(rng, src="r96x48", nt=2)
+    g2 = gridgen.parse_grid("r72x36")
+    b = DataArray(rng.standard_normal((2, 3, 36, 72)), dims=("time", "lev", "lat", "lon"),
+                  coords={"time": np.arange(2), "lev": [1.0, 2.0, 3.0], "lat": g2.lat, "lon": g2.lon}, name="so")
+    ds = Dataset({"tas": a, "so": b})
+    rg = Regridder(source_grid=ds, target_grid="r24x12", method="bil")
+    assert len(rg.grids) == 2 and {g.mask_dim for g in rg.grids} == {None, "lev"}
+    out = rg.regrid(ds)
+    assert out["tas"].shape == (2, 12, 24) and out["so"].shape == (2, 3, 12, 24)
+    w = CdoGenerate("r96x48", "r24x12").weights(method="bil")
+    assert_same(out["tas"].values.reshape(2, -1), oracle_2d(w, a.values.reshape(2, -1)), exact=True)
+    with pytest.raises(ValueError):
+        Regridder(weights=w).regrid(ds)                        # regrid.py:258-259
