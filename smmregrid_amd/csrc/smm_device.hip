@@ -998,6 +998,11 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
         (void)hipFree(d_cfg);
         return fail(SMM_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
       }
+      if (g->cfg_cache.size() >= 64) {  // bound the cache: callers cycle through a few level subsets
+        SMM_HIP(hipDeviceSynchronize());
+        for (auto& kv : g->cfg_cache) (void)hipFree(kv.second);
+        g->cfg_cache.clear();
+      }
       g->cfg_cache.emplace(std::move(key), d_cfg);
     }
   }
