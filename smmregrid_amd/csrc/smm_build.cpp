@@ -134,6 +134,7 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_pe
   const int64_t n_blocks = (csr.n_dst + rows_per_block - 1) / rows_per_block;
   plan.n_blocks = n_blocks;
   plan.blk_chunk_off.assign((size_t)n_blocks + 1, 0);
+  plan.blk_direct.assign((size_t)n_blocks, 0);
   plan.lcol.assign((size_t)sell.n_slots, 0);
 
   std::vector<int32_t> chunks, cols;
@@ -150,8 +151,12 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_pe
       if (chunks.empty() || chunks.back() != ch) chunks.push_back(ch);
     }
     if ((int64_t)chunks.size() > max_chunks_per_block) {
-      plan.valid = false;
-      return;
+      // too wide for LDS (polar caps of HEALPix targets, folds of tripolar grids ...): the kernel
+      // gathers this block's links straight from X
+      plan.blk_direct[(size_t)b] = 1;
+      plan.direct_links += csr.rowptr[(size_t)d1] - csr.rowptr[(size_t)d0];
+      plan.blk_chunk_off[(size_t)b + 1] = (int64_t)plan.chunk_src.size();
+      continue;
     }
     plan.max_block_chunks = std::max(plan.max_block_chunks, (int64_t)chunks.size());
     const int64_t base = (int64_t)plan.chunk_src.size();
@@ -179,7 +184,7 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_pe
     std::sort(all.begin(), all.end());
     plan.distinct_chunks = (int64_t)(std::unique(all.begin(), all.end()) - all.begin());
   }
-  plan.valid = true;
+  plan.valid = plan.direct_links * 4 <= csr.nnz;
 }
 
 }  // namespace smm

@@ -138,6 +138,7 @@ struct smm_operator {
     int64_t* d_blk_chunk_off = nullptr;
     int32_t* d_chunk_src = nullptr;
     int32_t* d_lcol = nullptr;
+    uint8_t* d_blk_direct = nullptr;
   } plan[2];
   smm::HostSell sell_shape;  // slice_off / rowlen only (col/val dropped after upload)
   std::mutex plan_mu;
@@ -156,6 +157,7 @@ struct smm_operator {
     L.blk_chunk_off = plan[which].d_blk_chunk_off;
     L.chunk_src = plan[which].d_chunk_src;
     L.lcol = plan[which].d_lcol;
+    L.blk_direct = plan[which].d_blk_direct;
     return L;
   }
 };
@@ -226,6 +228,7 @@ void release(smm_operator* op) {
     (void)hipFree(pl.d_blk_chunk_off);
     (void)hipFree(pl.d_chunk_src);
     (void)hipFree(pl.d_lcol);
+    (void)hipFree(pl.d_blk_direct);
   }
   (void)hipFree(op->d_desc);
   delete op;
@@ -244,7 +247,7 @@ int ensure_plan(smm_operator* op, int which) {
   if (!hp.valid) return SMM_OK;
   int rc = SMM_OK;
   if ((rc = upload(&pl.d_blk_chunk_off, hp.blk_chunk_off)) || (rc = upload(&pl.d_chunk_src, hp.chunk_src)) ||
-      (rc = upload(&pl.d_lcol, hp.lcol)))
+      (rc = upload(&pl.d_lcol, hp.lcol)) || (rc = upload(&pl.d_blk_direct, hp.blk_direct)))
     return rc;
   pl.valid = true;
   pl.max_chunks = hp.max_block_chunks;

@@ -56,11 +56,14 @@ struct HostTilePlan {
   int64_t total_chunks = 0;           // sum over blocks = staged lines per batch row
   int64_t total_distinct = 0;         // sum over blocks of distinct source cells referenced
   int64_t distinct_chunks = 0;        // distinct source chunks over the whole operator
+  int64_t direct_links = 0;           // links of blocks too wide to stage (gathered from X directly)
+  std::vector<uint8_t> blk_direct;    // n_blocks: 1 = footprint beyond the LDS budget, no chunks listed
   std::vector<int64_t> blk_chunk_off; // n_blocks + 1 -> index into chunk_src
   std::vector<int32_t> chunk_src;     // source chunk index (element = idx * chunk_elems)
   std::vector<int32_t> lcol;          // per SELL slot: LDS element index (layout of HostSell.col)
 };
-// Leaves plan.valid == false when a block needs more than max_chunks_per_block chunks.
+// Blocks needing more than max_chunks_per_block chunks are marked direct; plan.valid == false when
+// they carry more than a quarter of the links (then the SELL kernel serves the operator better).
 void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_per_block,
                      int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan);
 

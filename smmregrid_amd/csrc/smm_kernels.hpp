@@ -35,6 +35,7 @@ struct LevelDesc {
   const int64_t* blk_chunk_off;  // [n_blocks + 1]
   const int32_t* chunk_src;      // source chunk index per staged chunk
   const int32_t* lcol;           // SELL slots (LDS element index)
+  const uint8_t* blk_direct;     // [n_blocks] 1 = block not staged, links gathered from X directly
 };
 
 struct ApplyArgs {
@@ -292,6 +293,30 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   if (j_end > a.n_j) j_end = a.n_j;
   if (j_begin >= j_end) return;
 
+  if (L.blk_direct[db]) {
+    // footprint beyond the LDS budget: gather this block's links straight from X (SELL arrays
+    // hold the global columns), one batch row at a time; no LDS, no barrier
+    if (slice_live) {
+      const int32_t* __restrict__ gcp = L.col + soff + lane;
+      for (int64_t j = j_begin; j < j_end; ++j) {
+        const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+        double acc = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < wmax; ++k) {
+          const int kc = min(k, nslots - 1);
+          const double xv = load_fixed(xrow + gcp[(int64_t)kc * 64], fill);   // padding repeats a valid column
+          const double p = vp[(int64_t)kc * 64] * xv;
+          const double sum = acc + p;
+          acc = (k < len) ? sum : acc;
+        }
+        if (row_live) {
+          YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+          yrow[d] = (YT)epilogue(acc, dead);
+        }
+      }
+    }
+    return;
+  }
   if (npieces == 0) {
     // no destination row of this block has a link (land-only block): nothing to stage,
     // no barrier needed -- every batch row gets epilogue(0)

@@ -59,6 +59,7 @@ int main() {
       const int64_t rows_per_block = (int64_t)spb * 64;
       for (int64_t d = 0; d < csr.n_dst; ++d) {
         const int64_t b = d / rows_per_block, s = d >> 6, r = d & 63;
+        if (plan.blk_direct[(size_t)b]) continue;  // gathered from X directly, no LDS indices
         const int64_t c0 = plan.blk_chunk_off[(size_t)b];
         const int64_t base = sell.slice_off[(size_t)s] + r;
         for (int32_t k = 0; k < sell.rowlen[(size_t)d]; ++k) {
@@ -70,8 +71,9 @@ int main() {
         }
       }
     }
-    printf("PLAN %d %d %lld %lld %lld %lld\n", spb, (int)plan.valid, (long long)plan.max_block_chunks,
-           (long long)plan.total_chunks, (long long)plan.distinct_chunks, pbad);
+    if (plan.max_block_chunks > 512 * spb / 4) ++pbad;  // staged blocks respect the LDS budget
+    printf("PLAN %d %d %lld %lld %lld %lld %lld\n", spb, (int)plan.valid, (long long)plan.max_block_chunks,
+           (long long)plan.total_chunks, (long long)plan.distinct_chunks, (long long)plan.direct_links, pbad);
   }
   printf("SELLBAD %lld\n", bad);
   return 0;
