@@ -319,6 +319,27 @@ class NativeDist:
         self.comm.close()
 
 
+def stream_copy_gbs(nbytes=2 << 30, reps=5):
+    """Measured device-to-device copy rate of this GPU (read + write bytes per second): the
+    practical HBM ceiling to hold the kernel's PMC traffic rate against."""
+    import ctypes
+    from smmregrid_amd import _lib
+    from smmregrid_amd.device import DeviceArray, Event
+    a = DeviceArray((nbytes // 8,), np.float64).fill_bytes(1)
+    b = DeviceArray((nbytes // 8,), np.float64)
+    _lib.call("smm_memcpy_d2d", ctypes.c_void_p(b.ptr), ctypes.c_void_p(a.ptr), nbytes, None)
+    e0, e1 = Event(), Event()
+    e0.record()
+    for _ in range(reps):
+        _lib.call("smm_memcpy_d2d", ctypes.c_void_p(b.ptr), ctypes.c_void_p(a.ptr), nbytes, None)
+    e1.record()
+    e1.synchronize()
+    gbs = 2.0 * nbytes * reps / (e0.elapsed_ms(e1) * 1e-3) / 1e9
+    a.free()
+    b.free()
+    return gbs
+
+
 def cpu_threads():
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return int(os.environ.get("SMM_CPU_THREADS", min(avail, 16))), avail  # 16 = one GPU's CPU share
@@ -430,7 +451,8 @@ def main():
                          "line_granular_bytes": prob.line_bytes(),
                          "line_granular_frac": (prob.line_bytes() / k_avg / 1e9 / HBM_PEAK_GBS)
                          if prob.line_bytes() else None,
-                         "traffic_GBs": (traffic / k_avg / 1e9) if traffic else None},
+                         "traffic_GBs": (traffic / k_avg / 1e9) if traffic else None,
+                         "stream_copy_GBs": stream_copy_gbs()},
         }
         if with_gather is not None:
             out["with_gather"] = with_gather
