@@ -1,0 +1,90 @@
+"""Seeded fuzz of the apply path against the CPU oracle: random sizes, link patterns, batch
+shapes, dtypes, masks, thresholds, kernels and level groups -- all compared bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from smmregrid_amd import OperatorGroup, SparseOperator, _lib, to_device
+from tests.helpers import assert_same, field, ragged_links, random_links
+
+pytestmark = pytest.mark.gpu
+
+
+def make_links(rng, kind, n_src, n_dst):
+    if kind == "random":
+        return random_links(rng, n_src, n_dst, int(rng.integers(0, 6 * n_dst + 1)), dup_frac=0.1)
+    if kind == "ragged":
+        return ragged_links(rng, n_src, n_dst, max_len=int(rng.integers(1, 70)))
+    # banded stencil: k consecutive columns per row (structured grids), some rows empty
+    k = int(rng.integers(1, 20))
+    step = max(1, (n_src - k) // max(n_dst, 1))
+    rows = np.flatnonzero(rng.random(n_dst) > 0.1)
+    src = (rows[:, None] * step + np.arange(k)[None, :]) % n_src
+    dst = np.repeat(rows, k)
+    w = rng.uniform(-0.2, 1.0, size=src.size)
+    perm = rng.permutation(src.size)
+    return (src.ravel()[perm] + 1).astype(np.int32), (dst[perm] + 1).astype(np.int32), w[perm]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_2d(hip, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_src = int(rng.integers(1, 6000)) * (2 if seed % 3 else 1)
+    n_dst = int(rng.integers(1, 1500))
+    kind = ["random", "ragged", "banded"][seed % 3]
+    src, dst, w = make_links(rng, kind, n_src, n_dst)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    csr = op.export_csr()
+    ref_csr = oracle.coo_to_csr(n_src, n_dst, src, dst, w)
+    assert np.array_equal(csr[0], ref_csr[0]) and np.array_equal(csr[1], ref_csr[1])
+    imask = (rng.random(n_dst) > 0.3).astype(np.int32)
+    frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    dtype = np.float32 if seed % 2 else np.float64
+    n_batch = int(rng.integers(1, 40))
+    x = field(rng, n_batch, n_src, dtype=dtype, nan_frac=0.03, inf_frac=0.005)
+    masked = bool(seed % 2)
+    amin = float(rng.choice([0.0, 0.25, 0.5, 0.9]))
+    ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
+    kernels = [0, _lib.APPLY_KERNEL_SELL]
+    if op.plan_info()["tile_plan"] and (n_src * x.itemsize) % 16 == 0:
+        kernels.append(_lib.APPLY_KERNEL_TILE)
+    for fl in kernels:
+        y = op.apply(to_device(x), masked=masked, remap_area_min=amin, flags=fl).to_host()
+        assert_same(y, ref, exact=True)
+    yh = op.apply_host(x, masked=masked, remap_area_min=amin, chunk_rows=int(rng.integers(0, 9)))
+    assert_same(yh, ref, exact=True)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_levels(hip, seed):
+    rng = np.random.default_rng(5000 + seed)
+    n_src = int(rng.integers(16, 3000)) * 2
+    n_dst = int(rng.integers(1, 700))
+    n_ops = int(rng.integers(1, 6))
+    ops, csrs = [], []
+    imask = (rng.random((n_ops, n_dst)) > 0.3).astype(np.int32)
+    frac = rng.random((n_ops, n_dst))
+    for i in range(n_ops):
+        src, dst, w = make_links(rng, ["random", "ragged", "banded"][(seed + i) % 3], n_src, n_dst)
+        op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+        op.set_epilogue(imask[i], frac[i])
+        ops.append(op)
+        csrs.append(op.export_csr())
+    grp = OperatorGroup(ops)
+    n_lev = int(rng.integers(1, 7))
+    level_index = rng.integers(0, n_ops, size=n_lev).astype(np.int32)
+    masked_levels = (rng.random(n_ops) > 0.4).astype(np.uint8)
+    n_outer, n_inner = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+    x = field(rng, n_outer * n_lev * n_inner, n_src, nan_frac=0.02).reshape(n_outer, n_lev, n_inner, n_src)
+    amin = float(rng.choice([0.0, 0.5]))
+    for transpose in (True, False):
+        ref = oracle.apply_levels(csrs, x, 1, level_index, masked_levels.astype(bool), imask, frac, amin, transpose)
+        flags = [0, _lib.APPLY_KERNEL_SELL] + ([_lib.APPLY_KERNEL_TILE] if grp.plan_info()["tile_plan"] else [])
+        for fl in flags:
+            y = grp.apply(to_device(x), level_index, masked_levels, masked=True, remap_area_min=amin,
+                          transpose=transpose, flags=fl).to_host()
+            assert_same(y, ref, exact=True)
+        yh = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=amin, transpose=transpose,
+                            chunk_outer=int(rng.integers(0, 4)))
+        assert_same(yh, ref, exact=True)
