@@ -40,6 +40,8 @@ WORKLOADS = {
     "cfg2": ("bil", "r1440x721", "r360x180", 3600, "f64"),
     "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
     "cfg1": ("bil", "r180x90", "r90x45", 1, "f64"),
+    # config-2 links with the source cells randomly renumbered (unstructured source, no locality): SELL path
+    "scatter": ("bilperm", "r1440x721", "r360x180", 1024, "f64"),
     # config-4 geometry (regular Gaussian n1280 = 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch
     "cfg4s": ("bil", "n1280", "hp1024", 128, "f32"),
     # one masked level of config 3 as a 2-D problem (ocean fraction in the name), for kernel tuning
@@ -92,6 +94,10 @@ class Problem2D:
             mask = gridgen.synthetic_ocean_masks(nx, ny, 1, top=frac)[0]
             self.weights = gridgen.conservative_weights(gridgen.regular_grid(nx, ny), tgrid, src_mask=mask)
             sgrid = f"{nx}x{ny} ocean {frac}"
+        elif method == "bilperm":
+            self.weights = gridgen.generate_weights(sgrid, tgrid, method="bil")
+            perm = np.random.default_rng(7).permutation(self.weights.sizes["src_grid_size"]).astype(np.int32)
+            self.weights["src_address"].data = perm[self.weights["src_address"].values - 1] + 1
         else:
             self.weights = gridgen.generate_weights(sgrid, tgrid, method=method)
         w = self.weights

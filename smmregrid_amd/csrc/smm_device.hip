@@ -259,7 +259,7 @@ int ensure_plan(smm_operator* op, int which) {
 }
 
 template <typename XT, typename YT>
-int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, hipStream_t s) {
+int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, unsigned flags, hipStream_t s) {
   ApplyArgs args = a;
   auto go = [&](auto bt_tag) -> int {
     constexpr int BT = decltype(bt_tag)::value;
@@ -272,8 +272,9 @@ int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, hipStream_t s) {
     SMM_HIP(hipGetLastError());
     return SMM_OK;
   };
-  if (a.n_j >= 8) return go(std::integral_constant<int, 8>());
-  if (a.n_j >= 4) return go(std::integral_constant<int, 4>());
+  const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;  // tuning: 1 -> 4 rows, 2 -> 2 rows
+  if (a.n_j >= 8 && variant == 0) return go(std::integral_constant<int, 8>());
+  if (a.n_j >= 4 && variant <= 1) return go(std::integral_constant<int, 4>());
   if (a.n_j >= 2) return go(std::integral_constant<int, 2>());
   return go(std::integral_constant<int, 1>());
 }
@@ -414,7 +415,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
   }
   if (use_tile)
     return SMM_DISPATCH(launch_tile, a, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_reuse, fill, flags, s);
-  return SMM_DISPATCH(launch_sell, a, n_lev, fill, s);
+  return SMM_DISPATCH(launch_sell, a, n_lev, fill, flags, s);
 #undef SMM_DISPATCH
 }
 

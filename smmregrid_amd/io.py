@@ -52,4 +52,42 @@ def open_weights(path):
         import xarray
         from .xrlite import from_xarray
         return from_xarray(xarray.open_dataset(path))
-    raise OSError(f"{path}: HDF5-based NetCDF-4 cannot be read without xarray/netCDF4")
+    try:
+        import h5py
+    except ImportError:
+        raise OSError(f"{path}: HDF5-based NetCDF-4 needs xarray, netCDF4 or h5py")
+    return _open_netcdf4_h5py(h5py, path)
+
+
+def _open_netcdf4_h5py(h5py, path):
+    """NetCDF-4 (HDF5) weights through h5py: variables, their dimension names (from the
+    dimension scales netCDF attaches), global and variable attributes."""
+    def text(v):
+        if isinstance(v, bytes):
+            return v.decode()
+        if isinstance(v, np.ndarray) and v.dtype.kind in "SO" and v.size == 1:
+            return text(v.ravel()[0])
+        return v
+
+    skip = {"DIMENSION_LIST", "REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates",
+            "_NCProperties"}
+    with h5py.File(path, "r") as f:
+        ds = Dataset(attrs={k: text(v) for k, v in f.attrs.items() if k not in skip})
+        for name, var in f.items():
+            if not isinstance(var, h5py.Dataset):
+                continue
+            is_scale = var.attrs.get("CLASS", b"") == b"DIMENSION_SCALE"
+            if is_scale and str(text(var.attrs.get("NAME", b""))).startswith("This is a netCDF dimension"):
+                continue                       # a dimension without coordinate variable
+            dims = []
+            for i in range(var.ndim):
+                has_scale = len(var.dims[i]) > 0
+                dims.append(var.dims[i][0].name.split("/")[-1] if has_scale
+                            else (name if is_scale else f"{name}_dim{i}"))
+            arr = DataArray(np.asarray(var[...]), dims=dims, name=name,
+                            attrs={k: text(v) for k, v in var.attrs.items() if k not in skip})
+            if is_scale and dims == [name]:
+                ds.coords[name] = arr
+            else:
+                ds[name] = arr
+    return ds

@@ -35,6 +35,10 @@ def main():
         nx, ny, frac = sgrid
         mask = gridgen.synthetic_ocean_masks(nx, ny, 1, top=frac)[0]
         w = gridgen.conservative_weights(gridgen.regular_grid(nx, ny), tgrid, src_mask=mask)
+    elif method == "bilperm":
+        w = gridgen.generate_weights(sgrid, tgrid, method="bil")
+        perm = np.random.default_rng(7).permutation(w.sizes["src_grid_size"]).astype(np.int32)
+        w["src_address"].data = perm[w["src_address"].values - 1] + 1
     else:
         w = gridgen.generate_weights(sgrid, tgrid, method=method)
     n_src, n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
