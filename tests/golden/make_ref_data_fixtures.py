@@ -1,0 +1,24 @@
+"""Data fixture from a file of the reference's own test suite (data only, no code):
+
+    /opt/conda/bin/python3.9 tests/golden/make_ref_data_fixtures.py
+
+tests/data/ua-ipsl.nc (used by the reference's tests/basic_test.py:95-102) -> first time step of
+`ua` (19 pressure levels x 143 x 144, float32, missing values below the topography) with its
+coordinates, as a compressed .npz.  Read with h5py because the file is HDF5-based NetCDF-4.
+"""
+import os
+
+import h5py
+import numpy as np
+
+SRC = "/root/reference/tests/data/ua-ipsl.nc"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+with h5py.File(SRC, "r") as f:
+    ua = f["ua"][0]
+    fill = f["ua"].attrs["_FillValue"][0]
+    ua = np.where(ua == fill, np.float32(np.nan), ua).astype(np.float32)     # what xarray's decoding yields
+    np.savez_compressed(os.path.join(HERE, "ua_ipsl_t0.npz"), ua=ua,
+                        lat=f["lat"][:].astype(np.float64), lon=f["lon"][:].astype(np.float64),
+                        plev=f["plev"][:].astype(np.float64))
+print("missing per level:", np.isnan(ua).reshape(19, -1).sum(axis=1))
