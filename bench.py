@@ -40,6 +40,8 @@ WORKLOADS = {
     "cfg2": ("bil", "r1440x721", "r360x180", 3600, "f64"),
     "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
     "cfg1": ("bil", "r180x90", "r90x45", 1, "f64"),
+    # odd source size: f64 batch rows start on 8-byte boundaries only
+    "cfg2odd": ("bil", "r1441x721", "r360x180", 1024, "f64"),
     # config-2 links with the source cells randomly renumbered (unstructured source, no locality): SELL path
     "scatter": ("bilperm", "r1440x721", "r360x180", 1024, "f64"),
     # config-4 geometry (regular Gaussian n1280 = 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch

@@ -29,7 +29,7 @@ def make_links(rng, kind, n_src, n_dst):
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_2d(hip, seed):
     rng = np.random.default_rng(1000 + seed)
-    n_src = int(rng.integers(1, 6000)) * (2 if seed % 3 else 1)
+    n_src = int(rng.integers(1, 6000))
     n_dst = int(rng.integers(1, 1500))
     kind = ["random", "ragged", "banded"][seed % 3]
     src, dst, w = make_links(rng, kind, n_src, n_dst)
@@ -47,7 +47,7 @@ def test_fuzz_2d(hip, seed):
     amin = float(rng.choice([0.0, 0.25, 0.5, 0.9]))
     ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
     kernels = [0, _lib.APPLY_KERNEL_SELL]
-    if op.plan_info()["tile_plan"] and (n_src * x.itemsize) % 16 == 0:
+    if op.plan_info()["tile_plan"]:
         kernels.append(_lib.APPLY_KERNEL_TILE)
     for fl in kernels:
         y = op.apply(to_device(x), masked=masked, remap_area_min=amin, flags=fl).to_host()

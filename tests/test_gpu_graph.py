@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_apply_is_graph_capturable(hip, rng):
-    hiprt = ctypes.CDLL("libamdhip64.so")
+    hiprt = ctypes.CDLL("libamdhip64.so.7")          # by SONAME: the copy the library itself is bound to
     w = gridgen.bilinear_weights("r144x72", "r48x24")
     S, D = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
     op = SparseOperator(S, D, w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values, device=0)
