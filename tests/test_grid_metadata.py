@@ -1,0 +1,104 @@
+"""CdoGrid / GridType / GridInspector / GridDetector with the expectations of the reference's
+tests/cdogrid_test.py, tests/gridtype_test.py and tests/gridinspector_test.py (synthetic data)."""
+import numpy as np
+import pytest
+
+from smmregrid_amd import CdoGrid, DataArray, Dataset, GridDetector, GridInspector, GridType, gridgen
+
+
+@pytest.mark.parametrize("grid_str,expected", [
+    ("global_1.0", True), ("dcw:US", True), ("zonal_2.5", True), ("r360x180", True),
+    ("lon=-75.0/lat=40.0", True), ("F64", True), ("n400", True), ("gme10", True), ("hp1024", True),
+    ("hp32_ring", True), ("hpz4", True), ("random_string", False), ("/path/to/file.nc", False)])
+def test_is_cdo_grid(grid_str, expected):                       # cdogrid_test.py:5-23
+    assert bool(CdoGrid(grid_str).grid_kind) == expected
+
+
+def test_cdogrid_type_and_repr():                               # cdogrid_test.py:26-38
+    with pytest.raises(TypeError):
+        CdoGrid(12345)
+    grid = CdoGrid("global_1.0")
+    assert repr(grid) == "CDOGrid(grid_str='global_1.0', grid_kind='global_regular')"
+    assert CdoGrid("nope").grid_str == "Invalid"
+
+
+@pytest.mark.parametrize("definition,dims,other", [
+    (["lon", "lat"], ["lon", "lat"], []), (["lon", "lat", "lev", "time"], ["lon", "lat", "lev"], []),
+    (["i", "k"], ["i"], ["k"]), (["pix", "time", "papera"], ["pix"], ["papera"]),
+    (["time", "papera"], [], ["papera"])])
+def test_gridtype(definition, dims, other):                     # gridtype_test.py:7-20
+    grid = GridType(dims=definition)
+    assert set(grid.dims) == set(dims) and set(grid.other_dims) == set(other) and "GridType" in repr(grid)
+
+
+def test_gridtype_equality_and_extra_dims():                    # gridtype_test.py:23-66
+    assert GridType(["lon", "lat"]) != GridType(["i", "j"])
+    assert GridType(["lon", "lat"]) == GridType(["lon", "lat", "time", "plev"])
+    with pytest.raises(ValueError):
+        GridType(["lon", "lat", "lev", "nz1"])
+    with pytest.raises(TypeError):
+        GridType(["lon", "lat", "ciccio"], extra_dims=["horizontal"])
+    assert GridType(["lon", "lat", "ciccio"], extra_dims={"mask": ["ciccio"]}).mask_dim == "ciccio"
+    g = GridType(["alfa", "beta", "ciccio"], extra_dims={"horizontal": ["alfa", "beta"], "mask": ["ciccio"]},
+                 override=True)
+    assert g.mask_dim == "ciccio" and set(g.horizontal_dims) == {"alfa", "beta"} and g.time_dims is None
+
+
+def _field(dims, shape, coords, name, attrs=None):
+    return DataArray(np.zeros(shape), dims=dims, coords=coords, name=name, attrs=attrs)
+
+
+def test_inspector_groups_variables_by_grid():
+    g = gridgen.parse_grid("r12x6")
+    tas = _field(("time", "lat", "lon"), (2, 6, 12), {"lat": g.lat, "lon": g.lon}, "tas")
+    ua = _field(("time", "lev", "lat", "lon"), (2, 3, 6, 12), {"lat": g.lat, "lon": g.lon, "lev": [1, 2, 3]}, "ua")
+    va = _field(("time", "lev", "lat", "lon"), (2, 3, 6, 12), {"lat": g.lat, "lon": g.lon, "lev": [1, 2, 3]}, "va")
+    tb = _field(("time", "bnds"), (2, 2), {}, "time_bnds")
+    lb = _field(("lat", "bnds"), (6, 2), {}, "lat_bnds")
+    ds = Dataset({"tas": tas, "ua": ua, "va": va, "time_bnds": tb, "lat_bnds": lb})
+    grids = GridInspector(ds).get_gridtype()
+    assert len(grids) == 2
+    g2d = next(x for x in grids if x.mask_dim is None)
+    g3d = next(x for x in grids if x.mask_dim == "lev")
+    assert list(g2d.variables) == ["tas"] and sorted(g3d.variables) == ["ua", "va"]
+    assert "lat_bnds" in g2d.bounds and g2d.kind == "Regular"
+    assert len(GridInspector(tas).get_gridtype()) == 1
+    with pytest.raises(TypeError):
+        GridInspector(np.zeros(3))
+    with pytest.raises(FileNotFoundError):
+        GridInspector("/no/such/file.nc")
+
+
+def test_inspector_on_weights_takes_mask_dim_from_coords():
+    src = gridgen.parse_grid("r24x12")
+    masks = gridgen.synthetic_ocean_masks(24, 12, 2)
+    w3 = gridgen.ConservativeLevels(src, "r6x3").stack(masks, [5.0, 50.0], mask_dim="depth")
+    g = GridInspector(w3, cdo_weights=True, clean=False).get_gridtype()
+    assert len(g) == 1 and g[0].mask_dim == "depth" and g[0].weights is w3
+    w2 = gridgen.bilinear_weights("r24x12", "r6x3")
+    assert GridInspector(w2, cdo_weights=True, clean=False).get_gridtype()[0].mask_dim is None
+
+
+def test_grid_detector_kinds():
+    det = GridDetector()
+    r = gridgen.parse_grid("r12x6")
+    assert det.detect_grid(_field(("lat", "lon"), (6, 12), {"lat": r.lat, "lon": r.lon}, "t")) == "Regular"
+    f = gridgen.parse_grid("F8")
+    assert det.detect_grid(_field(("lat", "lon"), (16, 32), {"lat": f.lat, "lon": f.lon}, "t")) == "GaussianRegular"
+    lon2, lat2 = np.meshgrid(r.lon, r.lat)
+    curv = DataArray(np.zeros((6, 12)), dims=("y", "x"), name="t",
+                     coords={"lat": DataArray(lat2, dims=("y", "x")), "lon": DataArray(lon2, dims=("y", "x"))})
+    assert det.detect_grid(curv) == "Curvilinear"
+    assert det.detect_grid(_field(("time", "cell"), (2, 12 * 16), {}, "t")) == "HEALPix"
+    assert det.detect_grid(DataArray(np.zeros(5), dims=("x",), name="t", attrs={"grid_mapping": "healpix"})) == "HEALPix"
+    n = 50
+    uns = DataArray(np.zeros(n), dims=("nod2",), name="t",
+                    coords={"lat": DataArray(np.linspace(-80, 80, n), dims=("nod2",)),
+                            "lon": DataArray(np.linspace(0, 350, n), dims=("nod2",))})
+    assert det.detect_grid(uns) == "Unstructured"
+    lats = np.repeat([-60.0, -30.0, -10.0, 10.0, 30.0, 60.0], [3, 8, 12, 12, 8, 3])
+    red = DataArray(np.zeros(lats.size), dims=("values",), name="t",
+                    coords={"lat": DataArray(lats, dims=("values",)),
+                            "lon": DataArray(np.zeros(lats.size), dims=("values",))})
+    assert det.detect_grid(red) == "GaussianReduced"
+    assert det.detect_grid(_field(("a", "b"), (2, 3), {}, "t")) == "Unknown"
