@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Soak: many seeded random operators / fields through every kernel, compared bit for bit with the oracle."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.test_gpu_fuzz import make_links
+from tests.helpers import field
+from oracle import oracle
+from smmregrid_amd import SparseOperator, _lib, to_device
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+t0 = time.time(); bad = 0
+for seed in range(n):
+    rng = np.random.default_rng(900000 + seed)
+    n_src = int(rng.integers(1, 20000)); n_dst = int(rng.integers(1, 5000))
+    src, dst, w = make_links(rng, ["random", "ragged", "banded"][seed % 3], n_src, n_dst)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    csr = op.export_csr()
+    imask = (rng.random(n_dst) > 0.3).astype(np.int32); frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    dtype = np.float32 if seed % 2 else np.float64
+    x = field(rng, int(rng.integers(1, 70)), n_src, dtype=dtype, nan_frac=0.03, inf_frac=0.003)
+    amin = float(rng.choice([0.0, 0.5])); masked = bool(seed % 2)
+    ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
+    ks = [0, _lib.APPLY_KERNEL_SELL] + ([_lib.APPLY_KERNEL_TILE] if op.plan_info()["tile_plan"] else [])
+    dx = to_device(x)
+    for fl in ks:
+        for rep in range(3):
+            y = op.apply(dx, masked=masked, remap_area_min=amin, flags=fl).to_host()
+            same = np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])
+            if not same:
+                bad += 1; print("MISMATCH seed", seed, "flags", fl, "rep", rep, flush=True)
+    op.close()
+    if seed % 50 == 49: print(f"{seed+1} cases, {bad} mismatches, {time.time()-t0:.0f}s", flush=True)
+print("soak done:", n, "cases,", bad, "mismatches")
+sys.exit(1 if bad else 0)
