@@ -47,6 +47,7 @@ WORKLOADS = {
     "scatter": ("bilperm", "r1440x721", "r360x180", 1024, "f64"),
     # config-4 geometry (regular Gaussian n1280 = 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch
     "cfg4s": ("bil", "n1280", "hp1024", 128, "f32"),
+    "cfg4": ("bil", "n1280", "hp1024", 1095, "f32"),              # one GPU's share of config 4 (8760 / 8)
     # one masked level of config 3 as a 2-D problem (ocean fraction in the name), for kernel tuning
     "cfg3L66": ("conmask", (1442, 1021, 0.66), "r360x180", 1024, "f64"),
     "cfg3L35": ("conmask", (1442, 1021, 0.35), "r360x180", 1024, "f64"),
