@@ -45,9 +45,7 @@ class CdoGenerate:
                 if k in obj.coords:
                     lat = obj.coords[k].values
             if lon is not None and lat is not None and lon.ndim == 1 and lat.ndim == 1:
-                if lat[0] > lat[-1]:
-                    raise NotImplementedError("north-to-south latitude axes need `cdo`")
-                return gridgen.regular_grid_from_centers(lon, lat)
+                return gridgen.regular_grid_from_centers(lon, lat)   # either latitude direction
         raise NotImplementedError("native weight generation supports CDO grid names "
                                   "(r<NX>x<NY>, hp<N>) and regular lon/lat data only")
 

@@ -41,6 +41,9 @@ class Grid:
         self.lat_b = None if lat_b is None else np.asarray(lat_b, dtype=np.float64)
         self.name = name
         self.cdo_type = cdo_type
+        # regular grids are held south-to-north; a file that stores latitudes north-to-south (ERA5
+        # and friends) sets this flag and generate_weights renumbers cells to the file's order
+        self.lat_descending = False
 
     @property
     def dims(self):
@@ -86,7 +89,12 @@ def regular_grid_from_centers(lon, lat, name=None):
             b = np.clip(b, lo, hi)
         return b
 
-    return Grid("regular", lon, lat, bounds(lon), bounds(lat, -90.0, 90.0), name=name or "lonlat")
+    descending = lat.size > 1 and lat[0] > lat[-1]
+    if descending:
+        lat = lat[::-1]
+    g = Grid("regular", lon, lat, bounds(lon), bounds(lat, -90.0, 90.0), name=name or "lonlat")
+    g.lat_descending = bool(descending)
+    return g
 
 
 def healpix_centers(nside, nested=True):
@@ -342,17 +350,56 @@ def conservative_weights(src, dst, src_mask=None, norm="fracarea"):
                           dst_area=dst_area, norm=norm)
 
 
+def _flip_rows(values, nx):
+    """Reverse the latitude rows of a per-cell vector stored lon-fastest."""
+    v = np.asarray(values)
+    return v.reshape(-1, nx)[::-1].ravel()
+
+
+def _flip_address(addr, nx, ny):
+    a = np.asarray(addr, dtype=np.int64) - 1
+    return ((ny - 1 - a // nx) * nx + a % nx + 1).astype(np.int32)
+
+
 def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     """Dispatch on CDO method names (cdogenerate.py:73): con/ycon -> conservative,
-    bil -> bilinear, nn -> nearest."""
+    bil -> bilinear, nn -> nearest.  Grids whose latitude axis runs north-to-south are
+    computed south-to-north and renumbered to the file's cell order afterwards."""
+    src, dst = parse_grid(src), parse_grid(dst)
+    flip_s = src.kind == "regular" and src.lat_descending
+    flip_d = dst.kind == "regular" and dst.lat_descending
+    if flip_s and src_mask is not None:
+        src_mask = _flip_rows(np.asarray(src_mask).ravel(), src.lon.size)
     if method in ("con", "ycon"):
-        return conservative_weights(src, dst, src_mask=src_mask, norm=norm)
-    if method == "bil":
-        return bilinear_weights(src, dst)
-    if method == "nn":
-        return nearest_weights(src, dst)
-    raise ValueError(f"method '{method}' is not available without the cdo binary "
-                     "(native generator: con, ycon, bil, nn)")
+        ds = conservative_weights(src, dst, src_mask=src_mask, norm=norm)
+    elif method == "bil":
+        ds = bilinear_weights(src, dst)
+    elif method == "nn":
+        ds = nearest_weights(src, dst)
+    else:
+        raise ValueError(f"method '{method}' is not available without the cdo binary "
+                         "(native generator: con, ycon, bil, nn)")
+    if not (flip_s or flip_d):
+        return ds
+    src_addr, dst_addr = ds["src_address"].values, ds["dst_address"].values
+    w = ds["remap_matrix"].values
+    if flip_s:
+        nx, ny = src.lon.size, src.lat.size
+        src_addr = _flip_address(src_addr, nx, ny)
+        for name in ("src_grid_imask", "src_grid_center_lat", "src_grid_center_lon"):
+            ds[name] = (ds[name].dims, _flip_rows(ds[name].values, nx), ds[name].attrs)
+    if flip_d:
+        mx, my = dst.lon.size, dst.lat.size
+        dst_addr = _flip_address(dst_addr, mx, my)
+        for name in ("dst_grid_imask", "dst_grid_frac", "dst_grid_area", "dst_grid_center_lat",
+                     "dst_grid_center_lon"):
+            if name in ds:
+                ds[name] = (ds[name].dims, _flip_rows(ds[name].values, mx), ds[name].attrs)
+    order = np.lexsort((src_addr, dst_addr))
+    ds["src_address"] = (("num_links",), src_addr[order])
+    ds["dst_address"] = (("num_links",), dst_addr[order])
+    ds["remap_matrix"] = (("num_links", "num_wgts"), w[order])
+    return ds
 
 
 def stack_level_weights(weights_list, levels, mask_dim="lev", method="con"):

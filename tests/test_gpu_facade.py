@@ -284,3 +284,21 @@ def test_reference_test_data_ua_ipsl_check_nan(hip):
     ref = oracle.apply_levels(csrs, z["ua"].reshape(1, 19, S), 1, np.arange(19), np.asarray(rg.grids[0].masked),
                               w3["dst_grid_imask"].values, w3["dst_grid_frac"].values, 0.5, True)
     assert_same(rr.values.reshape(ref.shape), ref, exact=True)
+
+
+def test_era5_style_descending_latitudes(hip, rng):
+    """A field on a 2.5-degree grid with latitudes 90 ... -90 (the layout of ERA5 files and of the
+    reference's tests/data/2t-era5.nc): Regridder builds native weights for it and the output
+    latitudes follow the target grid."""
+    lon, lat = np.arange(0, 360, 2.5), np.arange(90, -90.1, -2.5)
+    x = (280 + 10 * rng.standard_normal((3, lat.size, lon.size))).astype(np.float32)
+    field = DataArray(x, dims=("time", "lat", "lon"), coords={"time": np.arange(3), "lat": lat, "lon": lon}, name="2t")
+    out = Regridder(source_grid=field, target_grid="r72x36", method="con").regrid(field)
+    assert out.shape == (3, 36, 72) and out.coords["lat"].values[0] == -87.5
+    flipped = DataArray(x[:, ::-1].copy(), dims=field.dims,
+                        coords={"time": np.arange(3), "lat": lat[::-1], "lon": lon}, name="2t")
+    out2 = Regridder(source_grid=flipped, target_grid="r72x36", method="con").regrid(flipped)
+    np.testing.assert_allclose(out.values, out2.values, rtol=1e-12)
+    # a constant field stays constant (rows of the conservative weights sum to one)
+    const = DataArray(np.full((1, lat.size, lon.size), 3.25), dims=field.dims, coords={"lat": lat, "lon": lon}, name="c")
+    np.testing.assert_allclose(Regridder(source_grid=const, target_grid="r72x36").regrid(const).values, 3.25, rtol=1e-13)

@@ -151,3 +151,34 @@ def test_gaussian_and_other_cdo_grid_names():
     np.testing.assert_allclose(w["dst_grid_frac"].values, 1.0, rtol=1e-12)
     wb = gridgen.generate_weights("F32", "hp4", method="bil")
     assert wb.sizes["num_links"] == 4 * 192 and wb.attrs["source_grid"] == "gaussian"
+
+
+@pytest.mark.parametrize("method", ["con", "bil", "nn"])
+def test_north_to_south_latitudes_give_the_same_regrid(rng, method):
+    """ERA5-style files store latitudes north-to-south: weights are computed south-to-north and
+    renumbered to the file's cell order, so the regridded field does not depend on the direction."""
+    lon, lat = np.arange(0, 360, 5.0), np.arange(87.5, -90, -5.0)
+    x = rng.standard_normal((lat.size, lon.size))
+    x[:5, :20] = np.nan
+    down = gridgen.regular_grid_from_centers(lon, lat)
+    up = gridgen.regular_grid_from_centers(lon, lat[::-1])
+    assert down.lat_descending and not up.lat_descending
+
+    def regrid(w, field2d):
+        csr = oracle.coo_to_csr(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                                w["dst_address"].values, w["remap_matrix"].values)
+        return oracle.apply(csr, field2d.reshape(1, -1), False, None, w["dst_grid_frac"].values, 0.5)
+
+    wd = gridgen.generate_weights(down, "r24x12", method=method, src_mask=np.isfinite(x).ravel())
+    wu = gridgen.generate_weights(up, "r24x12", method=method, src_mask=np.isfinite(x[::-1]).ravel())
+    a, b = regrid(wd, x), regrid(wu, x[::-1])
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    np.testing.assert_allclose(a[~np.isnan(a)], b[~np.isnan(b)], rtol=1e-12, atol=1e-14)
+    assert (np.diff(wd["dst_address"].values) >= 0).all()
+    # a north-to-south target: rows of the result come out in the target's own order
+    tgt = gridgen.regular_grid_from_centers(np.arange(0, 360, 15.0), np.arange(82.5, -90, -15.0))
+    wt = gridgen.generate_weights("r72x36", tgt, method=method)
+    wr = gridgen.generate_weights("r72x36", "r24x12", method=method)
+    xx = rng.standard_normal((1, 72 * 36))
+    np.testing.assert_allclose(regrid(wt, xx).reshape(12, 24)[::-1], regrid(wr, xx).reshape(12, 24), rtol=1e-12)
+    np.testing.assert_allclose(np.degrees(wt["dst_grid_center_lat"].values[:24]), 82.5)
