@@ -21,4 +21,10 @@ with h5py.File(SRC, "r") as f:
     np.savez_compressed(os.path.join(HERE, "ua_ipsl_t0.npz"), ua=ua,
                         lat=f["lat"][:].astype(np.float64), lon=f["lon"][:].astype(np.float64),
                         plev=f["plev"][:].astype(np.float64))
+with h5py.File("/root/reference/tests/data/2t-era5.nc", "r") as f:
+    # tests/data/2t-era5.nc (speed-evaluation.ipynb, identity tests): 12 x 73 x 144 float32 on a 2.5-degree
+    # grid that includes both poles
+    np.savez_compressed(os.path.join(HERE, "2t_era5.npz"), t2m=f["2t"][...].astype(np.float32),
+                        lat=f["lat"][:].astype(np.float64), lon=f["lon"][:].astype(np.float64),
+                        time=f["time"][:].astype(np.float64))
 print("missing per level:", np.isnan(ua).reshape(19, -1).sum(axis=1))

@@ -302,3 +302,24 @@ def test_era5_style_descending_latitudes(hip, rng):
     # a constant field stays constant (rows of the conservative weights sum to one)
     const = DataArray(np.full((1, lat.size, lon.size), 3.25), dims=field.dims, coords={"lat": lat, "lon": lon}, name="c")
     np.testing.assert_allclose(Regridder(source_grid=const, target_grid="r72x36").regrid(const).values, 3.25, rtol=1e-13)
+
+
+@pytest.mark.parametrize("method,target,shape", [("nn", "r360x180", (12, 180, 360)), ("con", "r180x90", (12, 90, 180)),
+                                                 ("bil", "hp16_nested", (12, 3072))])
+def test_reference_test_data_2t_era5(hip, method, target, shape):
+    """The reference's tests/data/2t-era5.nc (fixture: tests/golden/2t_era5.npz) with the call
+    pattern of basic_test.py:42-79: init from the data itself + a CDO target name, Dataset and
+    DataArray access, attrs kept, f32 in -> f64 out; values against the oracle."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "2t_era5.npz"))
+    field = DataArray(z["t2m"], dims=("time", "lat", "lon"),
+                      coords={"time": z["time"], "lat": z["lat"], "lon": z["lon"]},
+                      attrs={"units": "K", "test_attr": "test_value"}, name="2t")
+    rg = Regridder(source_grid=field, target_grid=target, method=method)
+    out = rg.regrid(field)
+    assert out.shape == shape and out.attrs["test_attr"] == "test_value" and out.values.dtype == np.float64
+    outds = rg.regrid(Dataset({"2t": field}))
+    assert outds["2t"].shape == shape
+    w = rg.grids[0].weights
+    ref = oracle_2d(w, z["t2m"].reshape(12, -1), masked=bool(np.asarray(rg.grids[0].masked).any()))
+    assert_same(out.values.reshape(12, -1), ref, exact=True)
+    assert 180.0 < np.nanmin(out.values) and np.nanmax(out.values) < 330.0      # Kelvin stays Kelvin
