@@ -466,7 +466,7 @@ def main():
         }
         if with_gather is not None:
             out["with_gather"] = with_gather
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = prob.cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
