@@ -52,7 +52,7 @@ class Regridder(object):
     def __init__(self, source_grid=None, target_grid=None, weights=None,
                  method='con', remap_area_min=DEFAULT_AREA_MIN, transpose=True, mask_dim=None,
                  vertical_dim=None, horizontal_dims=None, cdo_extra=None, cdo_options=None,
-                 check_nan=False, cdo='cdo', loglevel='WARNING', device=None):
+                 check_nan=False, cdo='cdo', loglevel='WARNING', device=None, out_dtype=np.float64):
         if (source_grid is None or target_grid is None) and (weights is None):
             raise ValueError("Either weights or source_grid/target_grid must be supplied")
 
@@ -66,6 +66,10 @@ class Regridder(object):
         self.loglevel = loglevel
         self.transpose = transpose
         self.device = device
+        # the reference always yields float64 (result_type(x, f64)); float32 is an opt-in narrowing store
+        self.out_dtype = np.dtype(out_dtype)
+        if self.out_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise ValueError('out_dtype must be float32 or float64')
         mask_dim = tolist(mask_dim)
         horizontal_dims = tolist(horizontal_dims)
         self.extra_dims = {'mask': mask_dim, 'horizontal': horizontal_dims}
@@ -307,7 +311,7 @@ class Regridder(object):
             x = src.reshape(n_batch, -1)
             if x.shape[1] != op.n_src:
                 raise ValueError(f"source grid has {x.shape[1]} cells, weights expect {op.n_src}")
-            y = op.apply(x, masked=masked, remap_area_min=self.remap_area_min)
+            y = op.apply(x, masked=masked, remap_area_min=self.remap_area_min, out_dtype=self.out_dtype)
             out_data = y.reshape(*(kept_shape + tgt_shape))
         else:
             host = np.asarray(src)
@@ -317,7 +321,8 @@ class Regridder(object):
             if host.shape[1] != op.n_src:
                 raise ValueError(f"source grid has {host.shape[1]} cells, weights expect {op.n_src}")
             # host field: chunks stream through the library's H2D / kernel / D2H pipeline
-            out = op.apply_host(host, masked=masked, remap_area_min=self.remap_area_min)
+            out = op.apply_host(host, masked=masked, remap_area_min=self.remap_area_min,
+                                out_dtype=self.out_dtype)
             out_data = out.reshape(kept_shape + tgt_shape)
 
         return self._finish(out_data, kept_dims + tgt_dims, source_data, kept_dims, weights,
@@ -376,7 +381,8 @@ class Regridder(object):
         if isinstance(src, DeviceArray):
             x = src.reshape(n_outer, n_lev, n_inner, -1)
             y = group.apply(x, level_index, masked_levels, masked=any_masked,
-                            remap_area_min=self.remap_area_min, transpose=self.transpose)
+                            remap_area_min=self.remap_area_min, transpose=self.transpose,
+                            out_dtype=self.out_dtype)
             out_data = y.reshape(*out_shape)
         else:
             host = np.asarray(src)
@@ -387,7 +393,8 @@ class Regridder(object):
                 raise ValueError(f"source grid has {host.shape[3]} cells, weights expect {S}")
             # host field: chunks of the outer axis stream through the group's pipeline
             out = group.apply_host(host, level_index, masked_levels, masked=any_masked,
-                                   remap_area_min=self.remap_area_min, transpose=self.transpose)
+                                   remap_area_min=self.remap_area_min, transpose=self.transpose,
+                                   out_dtype=self.out_dtype)
             out_data = out.reshape(out_shape)
 
         kept_for_coords = kept_dims

@@ -323,3 +323,13 @@ def test_reference_test_data_2t_era5(hip, method, target, shape):
     ref = oracle_2d(w, z["t2m"].reshape(12, -1), masked=bool(np.asarray(rg.grids[0].masked).any()))
     assert_same(out.values.reshape(12, -1), ref, exact=True)
     assert 180.0 < np.nanmin(out.values) and np.nanmax(out.values) < 330.0      # Kelvin stays Kelvin
+
+
+def test_out_dtype_float32_is_the_rounded_float64_result(hip, rng):
+    field = tas_field(rng, nt=3)
+    w = CdoGenerate("r96x48", "r36x18").weights(method="con")
+    y64 = Regridder(weights=w).regrid(field).values
+    y32 = Regridder(weights=w, out_dtype=np.float32).regrid(field).values
+    assert y32.dtype == np.float32 and np.array_equal(y32, y64.astype(np.float32))
+    with pytest.raises(ValueError):
+        Regridder(weights=w, out_dtype=np.int32)
