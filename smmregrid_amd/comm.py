@@ -11,7 +11,6 @@ import os
 import socket
 import time
 
-import numpy as np
 
 from . import _lib
 from .device import DeviceArray, dtype_code, _stream_handle

@@ -16,7 +16,6 @@ import os
 
 import numpy as np
 
-from . import _lib
 from .device import DeviceArray
 from .gridtype import GridType, tolist
 from .operator import OperatorGroup

@@ -2,7 +2,6 @@
 their cached host-pipeline buffers are destroyed."""
 import gc
 
-import numpy as np
 import pytest
 
 from smmregrid_amd import OperatorGroup, SparseOperator, gridgen, to_device
