@@ -286,15 +286,16 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       }
     }
   }
-  const bool tiny_row = a.n_src < kElemsPerPiece;  // cannot happen with a planned operator of >= 1 chunk
+  const bool tiny_row = a.n_src < kElemsPerPiece;  // a 16-B load would leave the row: gather directly
 
   const int64_t j_begin = jt * a.j_per_block;
   int64_t j_end = j_begin + a.j_per_block;
   if (j_end > a.n_j) j_end = a.n_j;
   if (j_begin >= j_end) return;
 
-  if (L.blk_direct[db]) {
-    // footprint beyond the LDS budget: gather this block's links straight from X (SELL arrays
+  if (L.blk_direct[db] || tiny_row) {
+    // footprint beyond the LDS budget (or a source row shorter than one 16-B piece): gather this
+    // block's links straight from X (SELL arrays
     // hold the global columns), one batch row at a time; no LDS, no barrier
     if (slice_live) {
       const int32_t* __restrict__ gcp = L.col + soff + lane;
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   };
 
 #ifndef SMM_EXP_SKIP_STAGE
-  if (!tiny_row) load_row(j_begin);
+  load_row(j_begin);
 #else
 #pragma unroll
   for (int k = 0; k < NP; ++k) v[k] = u32x4{0, 0, 0, 0};
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     store_tile();
     __syncthreads();
 #ifndef SMM_EXP_SKIP_STAGE
-    if (j + 1 < j_end && !tiny_row) load_row(j + 1);
+    if (j + 1 < j_end) load_row(j + 1);
 #endif
     if (slice_live) {
       double acc = 0.0;

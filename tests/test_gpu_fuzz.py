@@ -88,3 +88,21 @@ def test_fuzz_levels(hip, seed):
         yh = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=amin, transpose=transpose,
                             chunk_outer=int(rng.integers(0, 4)))
         assert_same(yh, ref, exact=True)
+
+
+@pytest.mark.parametrize("n_src", [1, 2, 3, 5])
+def test_source_rows_shorter_than_a_staging_piece(hip, n_src):
+    """S below one 16-B piece (4 f32 / 2 f64 elements): the tile kernel cannot stage such rows and
+    gathers them directly."""
+    rng = np.random.default_rng(n_src)
+    n_dst = 70
+    src = rng.integers(1, n_src + 1, size=150).astype(np.int32)
+    dst = rng.integers(1, n_dst + 1, size=150).astype(np.int32)
+    w = rng.random(150)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    for dtype in (np.float32, np.float64):
+        x = field(rng, 6, n_src, dtype=dtype)
+        ref = oracle.apply_c(op.export_csr(), x)
+        flags = [0, _lib.APPLY_KERNEL_SELL] + ([_lib.APPLY_KERNEL_TILE] if op.plan_info()["tile_plan"] else [])
+        for fl in flags:
+            assert_same(op.apply(to_device(x), flags=fl).to_host(), ref, exact=True)
