@@ -54,6 +54,16 @@ def test_fuzz_2d(hip, seed):
         assert_same(y, ref, exact=True)
     yh = op.apply_host(x, masked=masked, remap_area_min=amin, chunk_rows=int(rng.integers(0, 9)))
     assert_same(yh, ref, exact=True)
+    # mixed pinned / pageable buffers and the float32 narrowing store through the same pipeline
+    from smmregrid_amd import pinned_empty
+    xin = x
+    if seed % 4 < 2:
+        xin = pinned_empty(x.shape, x.dtype)
+        xin[...] = x
+    out_dtype = np.float32 if seed % 5 == 0 else np.float64
+    yout = pinned_empty((n_batch, n_dst), out_dtype) if seed % 4 in (1, 2) else np.empty((n_batch, n_dst), out_dtype)
+    op.apply_host(xin, out=yout, masked=masked, remap_area_min=amin, chunk_rows=int(rng.integers(0, 5)))
+    assert_same(np.array(yout), ref.astype(out_dtype), exact=(out_dtype == np.float64), rtol=0)
 
 
 @pytest.mark.parametrize("seed", range(8))
