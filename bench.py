@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--jpb", type=int, default=0, help="tile kernel: batch rows per workgroup")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
                     help="N>1: also time the steps followed by the RCCL gather of the Y shards to rank 0")
+    ap.add_argument("--gather-tiles", type=int, default=8,
+                    help="row tiles of the overlapped gather (tile k travels while tile k+1 is computed)")
     ap.add_argument("--comm", default="torch", choices=["torch", "native"],
                     help="N>1 plumbing: torch.distributed (nccl == RCCL) or the library's smm_comm_* (no torch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,6 +139,10 @@ class Problem2D:
 
     def run(self, y, flags):
         self.op.apply(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags)
+
+    def run_rows(self, y, flags, r0, r1):
+        """The same product restricted to batch rows [r0, r1) (one tile of the overlapped gather)."""
+        self.op.apply(self.x.rows(r0, r1), y=y.rows(r0, r1), masked=False, remap_area_min=0.5, flags=flags)
 
     def cpu_baseline(self, budget_s):
         """Oracle (C port of regrid.py:545-570, OpenMP over batch rows) on a bounded sample:
@@ -229,6 +235,10 @@ class ProblemLevels:
         self.group.apply(self.x, self.level_index, self.masked_levels, y=y, masked=True,
                          remap_area_min=0.5, transpose=True, flags=flags)
 
+    def run_rows(self, y, flags, r0, r1):
+        self.group.apply(self.x.rows(r0, r1), self.level_index, self.masked_levels, y=y.rows(r0, r1),
+                         masked=True, remap_area_min=0.5, transpose=True, flags=flags)
+
     def cpu_baseline(self, budget_s):
         from oracle import oracle
         threads, avail = cpu_threads()
@@ -268,13 +278,32 @@ class TorchDist:
         self.y_t = self.torch.empty(shape, dtype=self.torch.float64, device=self.dev)
         return DeviceArray(shape, np.float64, ptr=self.y_t.data_ptr())
 
-    def prepare_gather(self, y, root=0):
+    def prepare_gather(self, y, root=0, tiles=8):
+        """Tiled gather: the shard is cut into row tiles; tile k is gathered (async, on RCCL's own
+        stream) while the kernel of tile k+1 runs.  The root receives into a ring of two tile
+        buffers per rank -- a consumer would drain them -- so the full Y of all ranks never has to
+        fit on one GPU (config 5: 211 GB)."""
         self.root = root
+        n = self.y_t.shape[0]
+        per = -(-n // max(1, min(tiles, n)))
+        self.tiles = [(r0, min(n, r0 + per)) for r0 in range(0, n, per)]
+        self.ring = None
         if self.rank == root:
-            self.parts = [self.torch.empty_like(self.y_t) for _ in range(self.world)]
+            self.ring = [[self.torch.empty((per,) + tuple(self.y_t.shape[1:]), dtype=self.torch.float64,
+                                           device=self.dev) for _ in range(self.world)] for _ in range(2)]
+        self.pending = []
 
-    def gather(self):
-        self.dist.gather(self.y_t, self.parts, dst=self.root)
+    def gather_tile(self, k):
+        r0, r1 = self.tiles[k]
+        if len(self.pending) >= 2:                 # the ring slot about to be reused must have landed
+            self.pending.pop(0).wait()
+        recv = [buf[:r1 - r0] for buf in self.ring[k % 2]] if self.rank == self.root else None
+        self.pending.append(self.dist.gather(self.y_t[r0:r1], recv, dst=self.root, async_op=True))
+
+    def finish_gather(self):
+        for work in self.pending:
+            work.wait()
+        self.pending = []
 
     def barrier(self):
         self.dist.barrier()
@@ -306,14 +335,36 @@ class NativeDist:
         self.y = DeviceArray(shape, np.float64)
         return self.y
 
-    def prepare_gather(self, y, root=0):
-        from smmregrid_amd.device import DeviceArray
+    def prepare_gather(self, y, root=0, tiles=8):
+        """Same tiling; the collective runs on a communication stream that waits for an event
+        recorded behind each tile's kernel, so it overlaps the next tile's kernel."""
+        from smmregrid_amd.device import DeviceArray, Event, Stream
         self.root = root
+        n = y.shape[0]
+        per = -(-n // max(1, min(tiles, n)))
+        self.tiles = [(r0, min(n, r0 + per)) for r0 in range(0, n, per)]
+        self.comm_stream = Stream()
+        self.events = [Event() for _ in self.tiles]
+        self.ring = None
         if self.rank == root:
-            self.out = DeviceArray((self.world,) + tuple(y.shape), np.float64)
+            self.ring = [DeviceArray((self.world, per) + tuple(y.shape[1:]), np.float64) for _ in range(2)]
 
-    def gather(self):
-        self.comm.gather(self.y, root=self.root, out=self.out)   # on the null stream, after the kernel
+    def gather_tile(self, k):
+        r0, r1 = self.tiles[k]
+        self.events[k].record()                    # behind the kernel of tile k (null stream)
+        self.comm_stream.wait_event(self.events[k])
+        shard = self.y.rows(r0, r1)
+        out = None
+        if self.rank == self.root:                 # gathers serialise on the comm stream: ring reuse is ordered
+            out = self.ring[k % 2].reshape(self.world * self.ring[k % 2].shape[1], -1)
+        import ctypes
+        from smmregrid_amd import _lib
+        _lib.call("smm_comm_gather", self.comm.handle, ctypes.c_void_p(shard.ptr),
+                  ctypes.c_void_p(out.ptr) if out is not None else None, shard.size, _lib.SMM_F64,
+                  int(self.root), self.comm_stream.handle)
+
+    def finish_gather(self):
+        self.comm_stream.synchronize()
 
     def max(self, value):
         from smmregrid_amd.device import synchronize
@@ -381,19 +432,24 @@ def main():
 
     y = comm.alloc_y(prob.y_shape) if comm else DeviceArray(prob.y_shape, np.float64)
     if comm and args.gather == "root":
-        comm.prepare_gather(y, root=0)
+        comm.prepare_gather(y, root=0, tiles=args.gather_tiles)
 
     flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
     flags |= (args.variant << 16) | (args.jpb << 20)
 
     def step(events=None, gather=False):
+        if gather:
+            # tile k's gather (RCCL stream) overlaps tile k+1's kernel (null stream)
+            for k, (r0, r1) in enumerate(comm.tiles):
+                prob.run_rows(y, flags, r0, r1)
+                comm.gather_tile(k)
+            comm.finish_gather()
+            return
         if events:
             events[0].record()
-        prob.run(y, flags)            # launches on the null stream, which the collective is ordered after
+        prob.run(y, flags)            # launches on the null stream
         if events:
             events[1].record()
-        if gather:
-            comm.gather()
 
     def barrier():
         synchronize()
@@ -413,7 +469,7 @@ def main():
         dt = time.perf_counter() - t0
         if comm:
             dt = comm.max(dt)
-        return dt, [a.elapsed_ms(b) for a, b in ev]
+        return dt, ([] if gather else [a.elapsed_ms(b) for a, b in ev])   # tiles are not timed one by one
 
     # the measured job: every rank regrids its shard, Y shards stay resident on their GPUs
     elapsed, kernel_ms = timed(gather=False)
@@ -425,7 +481,8 @@ def main():
             g_elapsed, _ = timed(gather=True)
             with_gather = {"value": prob.cells() * world * args.steps / g_elapsed, "unit": "cells/s",
                            "ms_per_step": g_elapsed / args.steps * 1e3,
-                           "gathered_bytes_per_step": int(np.prod(prob.y_shape)) * 8 * (world - 1)}
+                           "gathered_bytes_per_step": int(np.prod(prob.y_shape)) * 8 * (world - 1),
+                           "tiles": len(comm.tiles), "overlapped_with_compute": True}
         except Exception as exc:  # report, never lose the compute measurement
             with_gather = {"error": repr(exc)}
 

@@ -97,6 +97,7 @@ int smm_event_create(void** event);
 int smm_event_destroy(void* event);
 int smm_event_record(void* event, void* stream);
 int smm_event_sync(void* event);
+int smm_stream_wait_event(void* stream, void* event); /* work queued on stream after this call waits for event */
 int smm_event_elapsed_ms(void* start, void* stop, float* ms);
 
 /* Synthetic field generator for benchmarks and full-size tests: fills n elements

@@ -69,6 +69,7 @@ SIGNATURES = {
     "smm_event_destroy": [_p],
     "smm_event_record": [_p, _p],
     "smm_event_sync": [_p],
+    "smm_stream_wait_event": [_p, _p],
     "smm_event_elapsed_ms": [_p, _p, ctypes.POINTER(ctypes.c_float)],
     "smm_fill_random": [_p, _int, _i64, ctypes.c_uint64, _dbl, _dbl, _p],
     "smm_operator_create": [_i64, _i64, _i64, _p, _p, _p, _int, _pp],

@@ -573,6 +573,10 @@ int smm_event_sync(void* event) {
   SMM_HIP(hipEventSynchronize((hipEvent_t)event));
   return SMM_OK;
 }
+int smm_stream_wait_event(void* stream, void* event) {
+  SMM_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return SMM_OK;
+}
 int smm_event_elapsed_ms(void* start, void* stop, float* ms) {
   if (!ms) return fail(SMM_ERR_INVALID, "null ms");
   SMM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));

@@ -54,6 +54,10 @@ class Stream:
     def synchronize(self):
         _lib.call("smm_stream_sync", self.handle)
 
+    def wait_event(self, event):
+        """Work queued on this stream afterwards waits for `event`."""
+        _lib.call("smm_stream_wait_event", self.handle, event.handle)
+
     def close(self):
         if self.handle:
             _lib.call("smm_stream_destroy", self.handle)
