@@ -86,6 +86,26 @@ __device__ __forceinline__ int64_t row_off(int64_t j, int64_t l, int64_t n_inner
   return o * s_o + l * s_l + i * s_i;
 }
 
+// Walks batch rows j = j0, j0+1, ... of level l without a division per row.
+struct RowWalker {
+  int64_t off, i, n_inner, step_i, step_o;
+  __device__ __forceinline__ RowWalker(int64_t j0, int64_t l, int64_t n_inner_, int64_t s_o, int64_t s_l,
+                                       int64_t s_i)
+      : n_inner(n_inner_), step_i(s_i), step_o(s_o - (n_inner_ - 1) * s_i) {
+    const int64_t o = j0 / n_inner_;
+    i = j0 - o * n_inner_;
+    off = o * s_o + l * s_l + i * s_i;
+  }
+  __device__ __forceinline__ void next() {
+    if (++i == n_inner) {
+      i = 0;
+      off += step_o;
+    } else {
+      off += step_i;
+    }
+  }
+};
+
 // ------------------------------------------------------------------ kernel A
 // SELL-64, one destination row per lane, BT batch rows register-blocked so the
 // col/val stream is read once per BT outputs and BT independent gathers are in
@@ -335,8 +355,8 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   }
 
   u32x4 v[NP];
-  auto load_row = [&](int64_t j) {
-    const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+  auto load_row = [&](int64_t xoff) {
+    const XT* __restrict__ xrow = (const XT*)a.x + xoff;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
@@ -345,16 +365,23 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       }
     }
   };
+  // the row-end piece (clamped load, see above) exists in at most one block per row: keep its
+  // element shuffle out of the common path with a wave-uniform branch
+  const bool any_shifted = __builtin_amdgcn_readfirstlane((int)__any(shifted != 0)) != 0;
   auto store_tile = [&]() {
+    if (!any_shifted) {
+#pragma unroll
+      for (int k = 0; k < NP; ++k)
+        if (k < np_w && ((pvalid >> k) & 1u)) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = v[k];
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       if (k < np_w) {
         u32x4 piece = v[k];
         if ((shifted >> k) & 1u) {  // last piece of the row: move the valid tail to the front
-          XT tmp[2 * kElemsPerPiece];
+          XT tmp[kElemsPerPiece];
           __builtin_memcpy(tmp, &piece, 16);
-#pragma unroll
-          for (int e = 0; e < kElemsPerPiece; ++e) tmp[kElemsPerPiece + e] = (XT)0;
           XT out[kElemsPerPiece];
 #pragma unroll
           for (int e = 0; e < kElemsPerPiece; ++e) {
@@ -371,17 +398,36 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     }
   };
 
+  RowWalker xw(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);   // row being prefetched
+  RowWalker yw(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);   // row being written
 #ifndef SMM_EXP_SKIP_STAGE
-  load_row(j_begin);
+  load_row(xw.off);
 #else
 #pragma unroll
   for (int k = 0; k < NP; ++k) v[k] = u32x4{0, 0, 0, 0};
 #endif
+  // Single-wave workgroups issue the Y store of row j after the LDS writes of row j+1: the wait
+  // for the prefetched pieces (in-order memory counter) then never includes the latest store's
+  // acknowledgement (cfg3 -6 %).  Four-wave workgroups store at once (deferring cost cfg4s 13 %).
+  constexpr bool kDeferStore = (WPB == 1);
+  YT pend_out = (YT)0;
+  int64_t pend_off = 0;
+  auto flush_pending = [&]() {
+    YT* __restrict__ yrow = (YT*)a.y + pend_off;
+    if (NT & 2)
+      __builtin_nontemporal_store(pend_out, yrow + d);
+    else
+      yrow[d] = pend_out;
+  };
   for (int64_t j = j_begin; j < j_end; ++j) {
     store_tile();
+    if (kDeferStore && row_live && j > j_begin) flush_pending();
     __syncthreads();
 #ifndef SMM_EXP_SKIP_STAGE
-    if (j + 1 < j_end) load_row(j + 1);
+    if (j + 1 < j_end) {
+      xw.next();
+      load_row(xw.off);
+    }
 #endif
     if (slice_live) {
       double acc = 0.0;
@@ -424,17 +470,14 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
           acc = on ? sum : acc;
         }
       }
-      if (row_live) {
-        YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
-        const YT out = (YT)epilogue(acc, dead);
-        if (NT & 2)
-          __builtin_nontemporal_store(out, yrow + d);
-        else
-          yrow[d] = out;
-      }
+      pend_out = (YT)epilogue(acc, dead);
+      pend_off = yw.off;
+      if (!kDeferStore && row_live) flush_pending();
     }
+    yw.next();
     __syncthreads();
   }
+  if (kDeferStore && row_live) flush_pending();
 }
 
 // counter-based synthetic field: splitmix64 -> two uniforms -> Box-Muller
