@@ -121,6 +121,15 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz,
                         const int32_t* src_addr_1based,
                         const int32_t* dst_addr_1based,
                         const double* w, int device, smm_operator_t* out);
+/*
+ * Build the operator from a canonical CSR kept from an earlier smm_operator_export_csr (SURVEY
+ * f1 "native CSR cache": skips the sort + duplicate pass of weights.py:37-39 on reload).  rowptr
+ * int64[n_dst+1] from 0, col int32 0-based strictly ascending inside a row, val double; anything
+ * else is SMM_ERR_INVALID.  Epilogue arrays are set separately as for smm_operator_create.
+ */
+int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
+                            const int32_t* col, const double* val, int device,
+                            smm_operator_t* out);
 int smm_operator_destroy(smm_operator_t op);
 
 /* sizes after duplicate-summing; n_used_src = distinct source cells with >= 1 link (U) */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "smm_event_elapsed_ms": [_p, _p, ctypes.POINTER(ctypes.c_float)],
     "smm_fill_random": [_p, _int, _i64, ctypes.c_uint64, _dbl, _dbl, _p],
     "smm_operator_create": [_i64, _i64, _i64, _p, _p, _p, _int, _pp],
+    "smm_operator_create_csr": [_i64, _i64, _p, _p, _p, _int, _pp],
     "smm_operator_destroy": [_p],
     "smm_operator_info": [_p] + [ctypes.POINTER(_i64)] * 5,
     "smm_operator_export_csr": [_p, _p, _p, _p],

@@ -93,6 +93,71 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
   return true;
 }
 
+bool adopt_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
+               const double* val, HostCsr& out, std::string& err) {
+  if (n_src < 0 || n_dst < 0) {
+    err = "negative size";
+    return false;
+  }
+  if (n_src > INT32_MAX || n_dst > INT32_MAX) {
+    err = "sizes beyond int32 addressing (SCRIP addresses are int32)";
+    return false;
+  }
+  if (!rowptr) {
+    err = "null rowptr";
+    return false;
+  }
+  if (rowptr[0] != 0) {
+    err = "rowptr[0] must be 0";
+    return false;
+  }
+  for (int64_t d = 0; d < n_dst; ++d) {
+    if (rowptr[d + 1] < rowptr[d]) {
+      err = "rowptr decreases at row " + std::to_string(d);
+      return false;
+    }
+  }
+  const int64_t nnz = rowptr[n_dst];
+  if (nnz > INT32_MAX) {
+    err = "more than INT32_MAX links";
+    return false;
+  }
+  if (nnz > 0 && (!col || !val)) {
+    err = "null col/val array";
+    return false;
+  }
+  std::vector<uint8_t> used((size_t)n_src, 0);
+  int64_t max_row = 0;
+  for (int64_t d = 0; d < n_dst; ++d) {
+    int64_t prev = -1;
+    for (int64_t i = rowptr[d]; i < rowptr[d + 1]; ++i) {
+      const int64_t c = col[i];
+      if (c < 0 || c >= n_src) {
+        err = "col[" + std::to_string(i) + "]=" + std::to_string(c) + " outside 0.." + std::to_string(n_src - 1);
+        return false;
+      }
+      if (c <= prev) {
+        err = "row " + std::to_string(d) + ": columns must be strictly ascending (canonical CSR)";
+        return false;
+      }
+      prev = c;
+      used[(size_t)c] = 1;
+    }
+    max_row = std::max(max_row, rowptr[d + 1] - rowptr[d]);
+  }
+  out.n_src = n_src;
+  out.n_dst = n_dst;
+  out.nnz = nnz;
+  out.max_row_nnz = max_row;
+  out.rowptr.assign(rowptr, rowptr + n_dst + 1);
+  out.col.assign(col, col + nnz);
+  out.val.assign(val, val + nnz);
+  int64_t u = 0;
+  for (uint8_t b : used) u += b;
+  out.n_used_src = u;
+  return true;
+}
+
 void build_sell(const HostCsr& csr, HostSell& out) {
   const int64_t n_slices = (csr.n_dst + 63) / 64;
   out.n_slices = n_slices;

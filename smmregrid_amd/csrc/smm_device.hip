@@ -602,9 +602,10 @@ int smm_fill_random(void* dst, int dtype, int64_t n, uint64_t seed, double mean,
 
 // ---- operators
 
-int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src_addr_1based,
-                        const int32_t* dst_addr_1based, const double* w, int device,
-                        smm_operator_t* out) {
+// Shared by the two constructors: `fill_csr` builds op->csr (false + err on invalid input).
+extern "C++" {
+template <typename F>
+static int create_operator(int device, smm_operator_t* out, F fill_csr) {
   if (!out) return fail(SMM_ERR_INVALID, "null out handle");
   *out = nullptr;
   int ndev = 0;
@@ -625,7 +626,7 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
   op->device = device;
   try {
     std::string err;
-    if (!smm::build_csr(n_src, n_dst, nnz, src_addr_1based, dst_addr_1based, w, op->csr, err)) {
+    if (!fill_csr(op->csr, err)) {
       delete op;
       return fail(SMM_ERR_INVALID, err);
     }
@@ -663,6 +664,22 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
   }
   *out = op;
   return SMM_OK;
+}
+}  // extern "C++"
+
+int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src_addr_1based,
+                        const int32_t* dst_addr_1based, const double* w, int device,
+                        smm_operator_t* out) {
+  return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
+    return smm::build_csr(n_src, n_dst, nnz, src_addr_1based, dst_addr_1based, w, csr, err);
+  });
+}
+
+int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
+                            const double* val, int device, smm_operator_t* out) {
+  return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
+    return smm::adopt_csr(n_src, n_dst, rowptr, col, val, csr, err);
+  });
 }
 
 int smm_operator_destroy(smm_operator_t op) {

@@ -38,6 +38,10 @@ struct HostSell {
 // Returns false and fills err on invalid input.
 bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
                const int32_t* dst1, const double* w, HostCsr& out, std::string& err);
+// Adopts an already canonical CSR (what smm_operator_export_csr wrote): validates it (rowptr
+// monotone from 0, columns strictly ascending inside a row and < n_src) instead of sorting.
+bool adopt_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
+               const double* val, HostCsr& out, std::string& err);
 void build_sell(const HostCsr& csr, HostSell& out);
 
 // Source-tile plan for the LDS-staged kernel.  Destination rows are grouped in

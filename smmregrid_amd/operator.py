@@ -35,12 +35,61 @@ class SparseOperator:
         h = ctypes.c_void_p()
         _lib.call("smm_operator_create", int(n_src), int(n_dst), int(src.size), _cptr(src),
                   _cptr(dst), _cptr(w), self.device, ctypes.byref(h))
-        self.handle = h
+        self._adopt(h)
+
+    def _adopt(self, handle):
+        self.handle = handle
         vals = [ctypes.c_int64(0) for _ in range(5)]
         _lib.call("smm_operator_info", self.handle, *[ctypes.byref(v) for v in vals])
         self.n_src, self.n_dst, self.nnz, self.n_used_src, self.max_row_nnz = [v.value for v in vals]
         self.has_imask = False
         self.has_frac = False
+
+    @classmethod
+    def from_csr(cls, n_src, n_dst, rowptr, col, val, device=None):
+        """Operator from a canonical CSR (what export_csr returned): no sort, no duplicate pass.
+        A non-canonical CSR (unsorted or repeated columns, bad rowptr) is a ValueError."""
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64).ravel()
+        col = np.ascontiguousarray(col, dtype=np.int32).ravel()
+        val = np.ascontiguousarray(val, dtype=np.float64).ravel()
+        if rowptr.size != int(n_dst) + 1:
+            raise ValueError(f"rowptr has {rowptr.size} entries, expected n_dst + 1 = {int(n_dst) + 1}")
+        if col.size != val.size or (rowptr.size and col.size != rowptr[-1]):
+            raise ValueError("col / val length differs from rowptr[-1]")
+        self = cls.__new__(cls)
+        self.device = int(current_device() if device is None else device)
+        h = ctypes.c_void_p()
+        try:
+            _lib.call("smm_operator_create_csr", int(n_src), int(n_dst), _cptr(rowptr), _cptr(col), _cptr(val),
+                      self.device, ctypes.byref(h))
+        except _lib.SmmError as e:
+            if e.code == _lib.SMM_ERR_INVALID:
+                raise ValueError(str(e)) from None
+            raise
+        self._adopt(h)
+        return self
+
+    def save(self, path):
+        """Persist the ready CSR (+ epilogue arrays if given to set_epilogue) as .npz -- the
+        'native CSR cache' of SURVEY f1; reload with SparseOperator.load."""
+        rowptr, col, val = self.export_csr()
+        payload = {"shape": np.array([self.n_src, self.n_dst], dtype=np.int64), "rowptr": rowptr, "col": col,
+                   "val": val}
+        for name in ("_dst_imask", "_dst_frac"):
+            a = getattr(self, name, None)
+            if a is not None:
+                payload[name[1:]] = a
+        np.savez(path, **payload)
+
+    @classmethod
+    def load(cls, path, device=None):
+        z = np.load(path, allow_pickle=False)
+        n_src, n_dst = (int(v) for v in z["shape"])
+        op = cls.from_csr(n_src, n_dst, z["rowptr"], z["col"], z["val"], device=device)
+        if "dst_imask" in z.files or "dst_frac" in z.files:
+            op.set_epilogue(z["dst_imask"] if "dst_imask" in z.files else None,
+                            z["dst_frac"] if "dst_frac" in z.files else None)
+        return op
 
     # the reference's matrix is (S, D): keep .shape for code that inspects it
     @property
@@ -55,6 +104,7 @@ class SparseOperator:
             if a is not None and a.size != self.n_dst:
                 raise ValueError(f"{name} has {a.size} entries, expected {self.n_dst}")
         _lib.call("smm_operator_set_epilogue", self.handle, _cptr(im), _cptr(fr))
+        self._dst_imask, self._dst_frac = im, fr     # kept for save()
         self.has_imask = im is not None
         self.has_frac = fr is not None
         return self

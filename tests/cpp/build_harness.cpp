@@ -75,6 +75,40 @@ int main() {
     printf("PLAN %d %d %lld %lld %lld %lld %lld\n", spb, (int)plan.valid, (long long)plan.max_block_chunks,
            (long long)plan.total_chunks, (long long)plan.distinct_chunks, (long long)plan.direct_links, pbad);
   }
+  // adopt_csr: the canonical CSR round-trips unchanged; each corruption of it is rejected
+  {
+    long long abad = 0;
+    smm::HostCsr back;
+    std::string e2;
+    if (!smm::adopt_csr(n_src, n_dst, csr.rowptr.data(), csr.col.data(), csr.val.data(), back, e2)) ++abad;
+    if (back.rowptr != csr.rowptr || back.col != csr.col || back.val != csr.val || back.nnz != csr.nnz ||
+        back.n_used_src != csr.n_used_src || back.max_row_nnz != csr.max_row_nnz)
+      ++abad;
+    smm::HostCsr tmp;
+    if (csr.nnz > 0) {
+      std::vector<int32_t> c2(csr.col);
+      c2[0] = (int32_t)n_src;                                   // column out of range
+      if (smm::adopt_csr(n_src, n_dst, csr.rowptr.data(), c2.data(), csr.val.data(), tmp, e2)) ++abad;
+      std::vector<int64_t> r2(csr.rowptr);
+      r2[0] = 1;                                                // rowptr must start at 0
+      if (smm::adopt_csr(n_src, n_dst, r2.data(), csr.col.data(), csr.val.data(), tmp, e2)) ++abad;
+    }
+    for (int64_t d = 0; d < csr.n_dst; ++d) {
+      if (csr.rowptr[(size_t)d + 1] - csr.rowptr[(size_t)d] >= 2) {
+        std::vector<int32_t> c2(csr.col);
+        std::swap(c2[(size_t)csr.rowptr[(size_t)d]], c2[(size_t)csr.rowptr[(size_t)d] + 1]);  // unsorted row
+        if (smm::adopt_csr(n_src, n_dst, csr.rowptr.data(), c2.data(), csr.val.data(), tmp, e2)) ++abad;
+        c2 = csr.col;
+        c2[(size_t)csr.rowptr[(size_t)d] + 1] = c2[(size_t)csr.rowptr[(size_t)d]];            // repeated column
+        if (smm::adopt_csr(n_src, n_dst, csr.rowptr.data(), c2.data(), csr.val.data(), tmp, e2)) ++abad;
+        std::vector<int64_t> r2(csr.rowptr);
+        r2[(size_t)d + 1] = r2[(size_t)d] - 1;                                                  // decreasing rowptr
+        if (smm::adopt_csr(n_src, n_dst, r2.data(), csr.col.data(), csr.val.data(), tmp, e2)) ++abad;
+        break;
+      }
+    }
+    printf("ADOPTBAD %lld\n", abad);
+  }
   printf("SELLBAD %lld\n", bad);
   return 0;
 }

@@ -69,6 +69,7 @@ def test_builder_under_sanitizers(harness, rng, case):
     plans = [ln.split() for ln in lines if ln.startswith("PLAN")]
     assert len(plans) == 2 and all(p[-1] == "0" for p in plans)          # every LDS index resolves
     assert lines[-1] == "SELLBAD 0"
+    assert "ADOPTBAD 0" in lines            # smm_operator_create_csr's validator (adopt_csr)
 
 
 def test_builder_rejects_bad_addresses(harness):
