@@ -290,8 +290,11 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   // An operator that does not stay in L2 (links x 12 B beyond ~32 MB) is re-read from HBM by every
   // walk: amortise it over long walks whatever the row length.
   const bool big_operator = a.n_dst * std::max<int64_t>(max_row_nnz, 1) * 12 > (32ll << 20);
+  // Rows of 5..16 links walk 16 rows: neighbouring blocks share halo lines through the memory-side
+  // cache only while they work on nearby batch rows, and longer walks let them drift apart
+  // (config 5, B = 12 741: 27.8 ms at 16, 31-34 ms and bimodal at 32-64).
   int64_t walk = jpb ? (int64_t)jpb
-                     : (big_operator ? 64 : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 32 : 64)));
+                     : (big_operator ? 64 : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 16 : 64)));
   if (!jpb)
     while (walk > 1 && a.n_dblocks * ((a.n_j + walk - 1) / walk) * n_lev < 4096) walk /= 2;
   args.j_per_block = (int)std::min<int64_t>(a.n_j, walk);

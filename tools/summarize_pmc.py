@@ -19,11 +19,13 @@ import os
 
 def mean_counter(d, kernel_substr):
     f = max(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
-    agg = collections.defaultdict(list)
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         if kernel_substr in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+            per_kernel[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # the dominant kernel of the run: set-up launches (mask products of a level group) also match
+    name = max(per_kernel, key=lambda k: sum(sum(v) for v in per_kernel[k].values()))
+    return {k: (sum(v) / len(v), len(v)) for k, v in per_kernel[name].items()}
 
 
 def main():
