@@ -252,4 +252,46 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_pe
   plan.valid = plan.direct_links * 4 <= csr.nnz;
 }
 
+int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_budget) {
+  if (!plan.valid || plan.n_blocks == 0) return full_budget;
+  const int64_t rows_per_block = (int64_t)plan.slices_per_block * 64;
+  auto block_links = [&](int64_t b) {
+    const int64_t d0 = b * rows_per_block, d1 = std::min(csr.n_dst, d0 + rows_per_block);
+    return csr.rowptr[(size_t)d1] - csr.rowptr[(size_t)d0];
+  };
+  int64_t chosen = full_budget;
+  for (int64_t cand : {full_budget / 8, full_budget / 4, full_budget / 2}) {
+    if (cand < 1 || cand >= plan.max_block_chunks) continue;   // would not shrink the tile
+    int64_t demoted = 0;
+    for (int64_t b = 0; b < plan.n_blocks; ++b)
+      if (plan.blk_chunk_off[(size_t)b + 1] - plan.blk_chunk_off[(size_t)b] > cand) demoted += block_links(b);
+    if ((plan.direct_links + demoted) * 100 <= csr.nnz) {
+      chosen = cand;
+      break;
+    }
+  }
+  if (chosen == full_budget) return full_budget;
+  std::vector<int32_t> kept;
+  kept.reserve(plan.chunk_src.size());
+  int64_t new_max = 0;
+  int64_t prev_end = 0;  // old end offset of the previous block
+  for (int64_t b = 0; b < plan.n_blocks; ++b) {
+    const int64_t o0 = prev_end, o1 = plan.blk_chunk_off[(size_t)b + 1];
+    prev_end = o1;
+    plan.blk_chunk_off[(size_t)b] = (int64_t)kept.size();
+    if (o1 - o0 > chosen) {
+      plan.blk_direct[(size_t)b] = 1;
+      plan.direct_links += block_links(b);
+    } else {
+      kept.insert(kept.end(), plan.chunk_src.begin() + o0, plan.chunk_src.begin() + o1);
+      new_max = std::max(new_max, o1 - o0);
+    }
+  }
+  plan.blk_chunk_off[(size_t)plan.n_blocks] = (int64_t)kept.size();
+  plan.chunk_src.swap(kept);
+  plan.max_block_chunks = new_max;
+  plan.total_chunks = (int64_t)plan.chunk_src.size();
+  return chosen;
+}
+
 }  // namespace smm

@@ -242,7 +242,9 @@ int ensure_plan(smm_operator* op, int which) {
   const int spb = which ? 1 : kWavesPerBlock;
   smm::HostTilePlan hp;
   // LDS / staging-register budget per destination row is the same for both block shapes
-  smm::build_tile_plan(op->csr, op->sell_shape, spb, kChunkElems, kTileMaxChunks * spb / kWavesPerBlock, hp);
+  const int64_t budget = kTileMaxChunks * spb / kWavesPerBlock;
+  smm::build_tile_plan(op->csr, op->sell_shape, spb, kChunkElems, budget, hp);
+  smm::tighten_tile_plan(op->csr, hp, budget);
   pl.built = true;
   if (!hp.valid) return SMM_OK;
   int rc = SMM_OK;
@@ -294,7 +296,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   // cache only while they work on nearby batch rows, and longer walks let them drift apart
   // (config 5, B = 12 741: 27.8 ms at 16, 31-34 ms and bimodal at 32-64).
   int64_t walk = jpb ? (int64_t)jpb
-                     : (big_operator ? 64 : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 16 : 64)));
+                     : (big_operator ? 128 : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 16 : 64)));
   if (!jpb)
     while (walk > 1 && a.n_dblocks * ((a.n_j + walk - 1) / walk) * n_lev < 4096) walk /= 2;
   args.j_per_block = (int)std::min<int64_t>(a.n_j, walk);
@@ -302,19 +304,37 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   const int64_t total = args.n_dblocks * args.n_jtiles * n_lev;
   if (total <= 0) return SMM_OK;
   if (total > 0x7fffffffLL) return fail(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
-  const size_t lds = (size_t)max_chunks * kChunkElems * sizeof(XT);
+  args.n_blocks = total;
+  args.xcd_remap = (variant == 6 || variant == 7) ? 1 : 0;
+  const size_t tile = (size_t)max_chunks * kChunkElems * sizeof(XT);
   const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
   const int threads = (tile_which ? 1 : kWavesPerBlock) * 64;  // == tile_waves(MAXK) * 64
   const int np_needed = (int)((max_pieces + threads - 1) / threads);
+  // Small tiles (one or two 16-B pieces per thread, 4-wave shape): a step of 4 / 2 batch rows per
+  // barrier pair keeps as many bytes in flight as a full tile would (variant 12: off, for A/B runs).
+  int rows = 1;
+  if (!tile_which && variant != 12) rows = np_needed <= 1 ? 4 : (np_needed <= 2 ? 2 : 1);
+  while (rows > 1 && rows > args.j_per_block) rows /= 2;
+  args.tile_bytes = (int)tile;
+  const size_t lds = tile * (size_t)rows;
 
-  auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
+  auto go3 = [&](auto k_tag, auto np_tag, auto nt_tag, auto r_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
     constexpr int NP = decltype(np_tag)::value;
     constexpr int NT = decltype(nt_tag)::value;
-    hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NP, NT>), dim3((unsigned)total),
+    constexpr int R = decltype(r_tag)::value;
+    hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NP, NT, R>), dim3((unsigned)total),
                        dim3(tile_waves(MAXK) * 64), lds, s, args, fill);
     SMM_HIP(hipGetLastError());
     return SMM_OK;
+  };
+  auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
+    constexpr int MAXK = decltype(k_tag)::value;
+    if constexpr (MAXK > 0 && MAXK <= 16) {
+      if (rows == 4) return go3(k_tag, std::integral_constant<int, 1>(), nt_tag, std::integral_constant<int, 4>());
+      if (rows == 2) return go3(k_tag, std::integral_constant<int, 2>(), nt_tag, std::integral_constant<int, 2>());
+    }
+    return go3(k_tag, np_tag, nt_tag, std::integral_constant<int, 1>());
   };
   auto with_k = [&](auto fn) -> int {  // plan shape 0 <-> MAXK <= 16 (4 waves), shape 1 <-> MAXK >= 32 / 0 (1 wave)
     if (!tile_which) {
@@ -335,6 +355,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   if (variant == 3) nt = 3;
   if (variant == 4) nt = 2;
   if (variant == 5) nt = 1;
+  if (variant == 7) nt = 2;
   return with_k([&](auto k_tag) -> int {
     auto with_nt = [&](auto np_tag) -> int {
       switch (nt) {

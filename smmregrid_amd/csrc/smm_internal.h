@@ -68,6 +68,11 @@ struct HostTilePlan {
 };
 // Blocks needing more than max_chunks_per_block chunks are marked direct; plan.valid == false when
 // they carry more than a quarter of the links (then the SELL kernel serves the operator better).
+// A few very wide blocks (polar caps of HEALPix targets) would size the LDS tile -- and with it the
+// workgroups per CU -- for every block.  Picks the smallest of full_budget/8, /4, /2 chunks that
+// leaves at most 1 % of the links in over-budget blocks, marks those blocks direct and drops their
+// chunk lists.  Returns the budget in force (full_budget when nothing changed).
+int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_budget);
 void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_per_block,
                      int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan);
 

@@ -54,6 +54,9 @@ struct ApplyArgs {
   double area_min;
   int masked;
   int j_per_block;   // tile kernel: batch rows walked by one workgroup
+  int xcd_remap;     // tile kernel: logical block = contiguous range per XCD (hardware ids are dealt round-robin)
+  int64_t n_blocks;  // grid size (for the remap)
+  int tile_bytes;    // tile kernel with R > 1: LDS bytes of one batch row's tile
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
@@ -202,15 +205,24 @@ typedef u32x4 u32x4_u __attribute__((aligned(4)));  // 16-B piece that may start
 // drift apart and overlap each other's HBM waits.
 constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPerBlock : 1; }
 
-template <typename XT, typename YT, int MAXK, int NP, int NT>
+//
+// R > 1 (small tiles only): R batch rows are staged, consumed and stored per barrier pair, each in
+// its own LDS region.  A workgroup whose tile needs one or two pieces per thread is bound by the
+// memory round trip per batch row, not by bandwidth; R rows in flight per workgroup hide it.
+template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1>
 __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   constexpr int WPB = tile_waves(MAXK);
   constexpr int T = WPB * 64;
+  static_assert(R == 1 || (MAXK > 0 && MAXK <= 16), "multi-row steps exist for the 4-wave shape only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   int64_t bid = blockIdx.x;
+  if (a.xcd_remap) {  // hardware block b runs on XCD b % 8: give each XCD one contiguous range
+    const int64_t q = a.n_blocks >> 3, r = a.n_blocks & 7, xcd = bid & 7;
+    bid = xcd * q + (xcd < r ? xcd : r) + (bid >> 3);
+  }
   const int64_t db = bid % a.n_dblocks;
   bid /= a.n_dblocks;
   const int64_t jt = bid % a.n_jtiles;
@@ -274,7 +286,6 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   constexpr int kElemsPerPiece = 16 / (int)sizeof(XT);
   constexpr int pieces_per_chunk = kChunkElems / kElemsPerPiece;
   const int npieces = nch * pieces_per_chunk;
-  const XT* lds_x = (const XT*)smem;
 
   // Pieces [wave*64 + k*256, +64) belong to this wave in round k.  poff = element offset of
   // the piece inside a batch row (clamped so that the 16-B load stays inside the row),
@@ -354,130 +365,273 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     return;
   }
 
-  u32x4 v[NP];
-  auto load_row = [&](int64_t xoff) {
-    const XT* __restrict__ xrow = (const XT*)a.x + xoff;
+  if constexpr (R == 1) {
+    const XT* lds_x = (const XT*)smem;
+    u32x4 v[NP];
+    auto load_row = [&](int64_t xoff) {
+      const XT* __restrict__ xrow = (const XT*)a.x + xoff;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
-        const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
-        v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
-      }
-    }
-  };
-  // the row-end piece (clamped load, see above) exists in at most one block per row: keep its
-  // element shuffle out of the common path with a wave-uniform branch
-  const bool any_shifted = __builtin_amdgcn_readfirstlane((int)__any(shifted != 0)) != 0;
-  auto store_tile = [&]() {
-    if (!any_shifted) {
-#pragma unroll
-      for (int k = 0; k < NP; ++k)
-        if (k < np_w && ((pvalid >> k) & 1u)) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = v[k];
-      return;
-    }
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      if (k < np_w) {
-        u32x4 piece = v[k];
-        if ((shifted >> k) & 1u) {  // last piece of the row: move the valid tail to the front
-          XT tmp[kElemsPerPiece];
-          __builtin_memcpy(tmp, &piece, 16);
-          XT out[kElemsPerPiece];
-#pragma unroll
-          for (int e = 0; e < kElemsPerPiece; ++e) {
-            XT val = (XT)0;
-#pragma unroll
-            for (int q = 0; q < kElemsPerPiece; ++q)
-              if (q == e + shift_amt) val = tmp[q];
-            out[e] = val;
-          }
-          __builtin_memcpy(&piece, out, 16);
+      for (int k = 0; k < NP; ++k) {
+        if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
+          const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
+          v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
         }
-        if ((pvalid >> k) & 1u) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = piece;
       }
-    }
-  };
-
-  RowWalker xw(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);   // row being prefetched
-  RowWalker yw(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);   // row being written
-#ifndef SMM_EXP_SKIP_STAGE
-  load_row(xw.off);
-#else
+    };
+    // the row-end piece (clamped load, see above) exists in at most one block per row: keep its
+    // element shuffle out of the common path with a wave-uniform branch
+    const bool any_shifted = __builtin_amdgcn_readfirstlane((int)__any(shifted != 0)) != 0;
+    auto store_tile = [&]() {
+      if (!any_shifted) {
 #pragma unroll
-  for (int k = 0; k < NP; ++k) v[k] = u32x4{0, 0, 0, 0};
-#endif
-  // Single-wave workgroups issue the Y store of row j after the LDS writes of row j+1: the wait
-  // for the prefetched pieces (in-order memory counter) then never includes the latest store's
-  // acknowledgement (cfg3 -6 %).  Four-wave workgroups store at once (deferring cost cfg4s 13 %).
-  constexpr bool kDeferStore = (WPB == 1);
-  YT pend_out = (YT)0;
-  int64_t pend_off = 0;
-  auto flush_pending = [&]() {
-    YT* __restrict__ yrow = (YT*)a.y + pend_off;
-    if (NT & 2)
-      __builtin_nontemporal_store(pend_out, yrow + d);
-    else
-      yrow[d] = pend_out;
-  };
-  for (int64_t j = j_begin; j < j_end; ++j) {
-    store_tile();
-    if (kDeferStore && row_live && j > j_begin) flush_pending();
-    __syncthreads();
-#ifndef SMM_EXP_SKIP_STAGE
-    if (j + 1 < j_end) {
-      xw.next();
-      load_row(xw.off);
-    }
-#endif
-    if (slice_live) {
-      double acc = 0.0;
-#ifdef SMM_EXP_SKIP_COMPUTE
-      if (false) {
-#else
-      if (MAXK > 0) {
-#endif
+        for (int k = 0; k < NP; ++k)
+          if (k < np_w && ((pvalid >> k) & 1u)) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = v[k];
+        return;
+      }
 #pragma unroll
-        for (int k0 = 0; k0 < KREG; k0 += 4) {
-          if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static
-            double xv[4];
+      for (int k = 0; k < NP; ++k) {
+        if (k < np_w) {
+          u32x4 piece = v[k];
+          if ((shifted >> k) & 1u) {  // last piece of the row: move the valid tail to the front
+            XT tmp[kElemsPerPiece];
+            __builtin_memcpy(tmp, &piece, 16);
+            XT out[kElemsPerPiece];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const int k = k0 + kk;
-              const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
-                                          : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-              xv[kk] = load_fixed(lds_x + li, fill);  // unconditional: index 0 for unused slots
+            for (int e = 0; e < kElemsPerPiece; ++e) {
+              XT val = (XT)0;
+#pragma unroll
+              for (int q = 0; q < kElemsPerPiece; ++q)
+                if (q == e + shift_amt) val = tmp[q];
+              out[e] = val;
             }
+            __builtin_memcpy(&piece, out, 16);
+          }
+          if ((pvalid >> k) & 1u) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = piece;
+        }
+      }
+    };
+
+    RowWalker xw(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);   // row being prefetched
+    RowWalker yw(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);   // row being written
+#ifndef SMM_EXP_SKIP_STAGE
+    load_row(xw.off);
+#else
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const int k = k0 + kk;
-              if (k < KREG) {
-                const double p = w[k] * xv[kk];
-                const double sum = acc + p;
-                acc = (k < len) ? sum : acc;
+    for (int k = 0; k < NP; ++k) v[k] = u32x4{0, 0, 0, 0};
+#endif
+    // Single-wave workgroups issue the Y store of row j after the LDS writes of row j+1: the wait
+    // for the prefetched pieces (in-order memory counter) then never includes the latest store's
+    // acknowledgement (cfg3 -6 %).  Four-wave workgroups store at once (deferring cost cfg4s 13 %).
+    constexpr bool kDeferStore = (WPB == 1);
+    YT pend_out = (YT)0;
+    int64_t pend_off = 0;
+    auto flush_pending = [&]() {
+      YT* __restrict__ yrow = (YT*)a.y + pend_off;
+      if (NT & 2)
+        __builtin_nontemporal_store(pend_out, yrow + d);
+      else
+        yrow[d] = pend_out;
+    };
+    for (int64_t j = j_begin; j < j_end; ++j) {
+      store_tile();
+      if (kDeferStore && row_live && j > j_begin) flush_pending();
+      __syncthreads();
+#ifndef SMM_EXP_SKIP_STAGE
+      if (j + 1 < j_end) {
+        xw.next();
+        load_row(xw.off);
+      }
+#endif
+      if (slice_live) {
+        double acc = 0.0;
+#ifdef SMM_EXP_SKIP_COMPUTE
+        if (false) {
+#else
+        if (MAXK > 0) {
+#endif
+#pragma unroll
+          for (int k0 = 0; k0 < KREG; k0 += 4) {
+            if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static
+              double xv[4];
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                const int k = k0 + kk;
+                const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
+                                            : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
+                xv[kk] = load_fixed(lds_x + li, fill);  // unconditional: index 0 for unused slots
+              }
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk) {
+                const int k = k0 + kk;
+                if (k < KREG) {
+                  const double p = w[k] * xv[kk];
+                  const double sum = acc + p;
+                  acc = (k < len) ? sum : acc;
+                }
               }
             }
           }
-        }
-      } else {
+        } else {
 #pragma unroll 4
-        for (int k = 0; k < wmax; ++k) {
-          const int kc = min(k, nslots - 1);
-          const bool on = k < len;
-          const int32_t li = cp[(int64_t)kc * 64];
-          const double xv = load_fixed(lds_x + (on ? li : 0), fill);
-          const double p = vp[(int64_t)kc * 64] * xv;
-          const double sum = acc + p;
-          acc = on ? sum : acc;
+          for (int k = 0; k < wmax; ++k) {
+            const int kc = min(k, nslots - 1);
+            const bool on = k < len;
+            const int32_t li = cp[(int64_t)kc * 64];
+            const double xv = load_fixed(lds_x + (on ? li : 0), fill);
+            const double p = vp[(int64_t)kc * 64] * xv;
+            const double sum = acc + p;
+            acc = on ? sum : acc;
+          }
+        }
+        pend_out = (YT)epilogue(acc, dead);
+        pend_off = yw.off;
+        if (!kDeferStore && row_live) flush_pending();
+      }
+      yw.next();
+      __syncthreads();
+    }
+    if (kDeferStore && row_live) flush_pending();
+  } else {
+    u32x4 v[R][NP];
+    auto load_row = [&](int r, int64_t xoff) {
+      const XT* __restrict__ xrow = (const XT*)a.x + xoff;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
+          const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
+          v[r][k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
         }
       }
-      pend_out = (YT)epilogue(acc, dead);
-      pend_off = yw.off;
-      if (!kDeferStore && row_live) flush_pending();
+    };
+    // the row-end piece (clamped load, see above) exists in at most one block per row: keep its
+    // element shuffle out of the common path with a wave-uniform branch
+    const bool any_shifted = __builtin_amdgcn_readfirstlane((int)__any(shifted != 0)) != 0;
+    const int tile_bytes = R > 1 ? a.tile_bytes : 0;  // LDS region of batch row r of a step: r * tile_bytes
+    auto store_tile = [&](int r) {
+      char* region = smem + r * tile_bytes;
+      if (!any_shifted) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          if (k < np_w && ((pvalid >> k) & 1u)) *(u32x4*)(region + (size_t)(tid + k * T) * 16) = v[r][k];
+        return;
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (k < np_w) {
+          u32x4 piece = v[r][k];
+          if ((shifted >> k) & 1u) {  // last piece of the row: move the valid tail to the front
+            XT tmp[kElemsPerPiece];
+            __builtin_memcpy(tmp, &piece, 16);
+            XT out[kElemsPerPiece];
+#pragma unroll
+            for (int e = 0; e < kElemsPerPiece; ++e) {
+              XT val = (XT)0;
+#pragma unroll
+              for (int q = 0; q < kElemsPerPiece; ++q)
+                if (q == e + shift_amt) val = tmp[q];
+              out[e] = val;
+            }
+            __builtin_memcpy(&piece, out, 16);
+          }
+          if ((pvalid >> k) & 1u) *(u32x4*)(region + (size_t)(tid + k * T) * 16) = piece;
+        }
+      }
+    };
+
+    // xw.off / yw.off: the next batch row to load / to write.  A step covers rows jb .. jb+R-1; rows
+    // past the walk's end repeat its last row (loaded again, never stored).
+    RowWalker xw(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+    RowWalker yw(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+    auto load_step = [&](int64_t jb) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        load_row(r, xw.off);
+        if (jb + r + 1 < j_end) xw.next();
+      }
+    };
+#ifndef SMM_EXP_SKIP_STAGE
+    load_step(j_begin);
+#else
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < NP; ++k) v[r][k] = u32x4{0, 0, 0, 0};
+#endif
+    // Single-wave workgroups issue the Y store of row j after the LDS writes of row j+1: the wait
+    // for the prefetched pieces (in-order memory counter) then never includes the latest store's
+    // acknowledgement (cfg3 -6 %).  Four-wave workgroups store at once (deferring cost cfg4s 13 %).
+    constexpr bool kDeferStore = (WPB == 1 && R == 1);
+    YT pend_out = (YT)0;
+    int64_t pend_off = 0;
+    auto flush_pending = [&]() {
+      YT* __restrict__ yrow = (YT*)a.y + pend_off;
+      if (NT & 2)
+        __builtin_nontemporal_store(pend_out, yrow + d);
+      else
+        yrow[d] = pend_out;
+    };
+    for (int64_t jb = j_begin; jb < j_end; jb += R) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) store_tile(r);
+      if (kDeferStore && row_live && jb > j_begin) flush_pending();
+      __syncthreads();
+#ifndef SMM_EXP_SKIP_STAGE
+      if (jb + R < j_end) load_step(jb + R);
+#endif
+      if (slice_live) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const XT* lds_r = (const XT*)(smem + r * tile_bytes);
+          double acc = 0.0;
+#ifdef SMM_EXP_SKIP_COMPUTE
+          if (false) {
+#else
+          if (MAXK > 0) {
+#endif
+#pragma unroll
+            for (int k0 = 0; k0 < KREG; k0 += 4) {
+              if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static
+                double xv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int k = k0 + kk;
+                  const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
+                                              : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
+                  xv[kk] = load_fixed(lds_r + li, fill);  // unconditional: index 0 for unused slots
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int k = k0 + kk;
+                  if (k < KREG) {
+                    const double p = w[k] * xv[kk];
+                    const double sum = acc + p;
+                    acc = (k < len) ? sum : acc;
+                  }
+                }
+              }
+            }
+          } else {
+#pragma unroll 4
+            for (int k = 0; k < wmax; ++k) {
+              const int kc = min(k, nslots - 1);
+              const bool on = k < len;
+              const int32_t li = cp[(int64_t)kc * 64];
+              const double xv = load_fixed(lds_r + (on ? li : 0), fill);
+              const double p = vp[(int64_t)kc * 64] * xv;
+              const double sum = acc + p;
+              acc = on ? sum : acc;
+            }
+          }
+          pend_out = (YT)epilogue(acc, dead);
+          pend_off = yw.off;
+          if (!kDeferStore && row_live && jb + r < j_end) flush_pending();
+          if (jb + r + 1 < j_end) yw.next();
+        }
+      }
+      __syncthreads();
     }
-    yw.next();
-    __syncthreads();
+    if (kDeferStore && row_live) flush_pending();
   }
-  if (kDeferStore && row_live) flush_pending();
 }
 
 // counter-based synthetic field: splitmix64 -> two uniforms -> Box-Muller

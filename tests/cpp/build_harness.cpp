@@ -53,10 +53,23 @@ int main() {
   // both tile-plan shapes: every link's LDS index must resolve to its source column
   for (int spb : {4, 1}) {
     smm::HostTilePlan plan;
-    smm::build_tile_plan(csr, sell, spb, 16, 512 * spb / 4, plan);
-    long long pbad = 0;
-    if (plan.valid) {
+    const int64_t budget = 512 * spb / 4;
+    smm::build_tile_plan(csr, sell, spb, 16, budget, plan);
+    auto check_plan = [&](int64_t limit) {
+      long long pbad = 0;
+      if (!plan.valid) return pbad;
       const int64_t rows_per_block = (int64_t)spb * 64;
+      int64_t direct_links = 0;
+      for (int64_t b = 0; b < plan.n_blocks; ++b) {
+        const int64_t nch = plan.blk_chunk_off[(size_t)b + 1] - plan.blk_chunk_off[(size_t)b];
+        if (nch < 0 || nch > limit || nch > plan.max_block_chunks) ++pbad;
+        if (plan.blk_direct[(size_t)b]) {
+          if (nch != 0) ++pbad;
+          const int64_t d0 = b * rows_per_block, d1 = std::min(csr.n_dst, d0 + rows_per_block);
+          direct_links += csr.rowptr[(size_t)d1] - csr.rowptr[(size_t)d0];
+        }
+      }
+      if (direct_links != plan.direct_links || plan.total_chunks != (int64_t)plan.chunk_src.size()) ++pbad;
       for (int64_t d = 0; d < csr.n_dst; ++d) {
         const int64_t b = d / rows_per_block, s = d >> 6, r = d & 63;
         if (plan.blk_direct[(size_t)b]) continue;  // gathered from X directly, no LDS indices
@@ -70,10 +83,17 @@ int main() {
           if (col != csr.col[(size_t)(csr.rowptr[(size_t)d] + k)]) ++pbad;
         }
       }
-    }
-    if (plan.max_block_chunks > 512 * spb / 4) ++pbad;  // staged blocks respect the LDS budget
+      return pbad;
+    };
+    long long pbad = check_plan(budget);
     printf("PLAN %d %d %lld %lld %lld %lld %lld\n", spb, (int)plan.valid, (long long)plan.max_block_chunks,
            (long long)plan.total_chunks, (long long)plan.distinct_chunks, (long long)plan.direct_links, pbad);
+    // tightened budget: demoted blocks are direct, every remaining LDS index still resolves
+    const int64_t chosen = smm::tighten_tile_plan(csr, plan, budget);
+    long long tbad = check_plan(chosen);
+    if (plan.valid && plan.direct_links * 100 > csr.nnz && chosen != budget) ++tbad;
+    printf("TIGHT %d %lld %lld %lld %lld\n", spb, (long long)chosen, (long long)plan.max_block_chunks,
+           (long long)plan.direct_links, tbad);
   }
   // adopt_csr: the canonical CSR round-trips unchanged; each corruption of it is rejected
   {

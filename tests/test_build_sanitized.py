@@ -31,7 +31,7 @@ def run(exe, n_src, n_dst, src, dst, w):
     return out.stdout.splitlines()
 
 
-@pytest.mark.parametrize("case", ["random", "ragged", "dups", "empty", "one_long_row", "tail_cols"])
+@pytest.mark.parametrize("case", ["random", "ragged", "dups", "empty", "one_long_row", "tail_cols", "few_wide_blocks"])
 def test_builder_under_sanitizers(harness, rng, case):
     if case == "random":
         n_src, n_dst = 5000, 1300
@@ -50,6 +50,14 @@ def test_builder_under_sanitizers(harness, rng, case):
         src = np.concatenate([rng.permutation(n_src)[:9000] + 1, [1, 2]]).astype(np.int32)
         dst = np.concatenate([np.full(9000, 65), [1, 70]]).astype(np.int32)
         w = rng.random(src.size)
+    elif case == "few_wide_blocks":
+        # narrow banded blocks plus one block spread over ~300 chunks: tighten_tile_plan demotes it
+        n_dst, n_src = 256 * 120, 256 * 120 * 2 + 8
+        d = np.repeat(np.arange(n_dst), 4)
+        s_ = d * 2 + np.tile(np.arange(4), n_dst)
+        wide = (d >= 256 * 50) & (d < 256 * 51)
+        s_[wide] = 256 * 50 * 2 + rng.integers(0, 4800, size=int(wide.sum()))
+        src, dst, w = (s_ + 1).astype(np.int32), (d + 1).astype(np.int32), rng.random(d.size)
     else:
         n_src, n_dst = 1006, 64
         src = np.concatenate([np.full(64, 1006), np.full(64, 1005), np.arange(1, 65)]).astype(np.int32)
@@ -68,7 +76,12 @@ def test_builder_under_sanitizers(harness, rng, case):
     assert np.array_equal(got.view(np.uint64), ref_c.view(np.uint64))
     plans = [ln.split() for ln in lines if ln.startswith("PLAN")]
     assert len(plans) == 2 and all(p[-1] == "0" for p in plans)          # every LDS index resolves
+    tight = [ln.split() for ln in lines if ln.startswith("TIGHT")]
+    assert len(tight) == 2 and all(t[-1] == "0" for t in tight)          # ... also after tighten_tile_plan
     assert lines[-1] == "SELLBAD 0"
+    if case == "few_wide_blocks":
+        t4 = [t for t in tight if t[1] == "4"][0]
+        assert int(t4[2]) == 64 and int(t4[3]) <= 34 and 1000 <= int(t4[4]) <= 1024   # budget 512 -> 64, one block direct
     assert "ADOPTBAD 0" in lines            # smm_operator_create_csr's validator (adopt_csr)
 
 
