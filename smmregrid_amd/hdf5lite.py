@@ -1,0 +1,857 @@
+"""Minimal read-only HDF5 reader (pure Python + numpy) for NetCDF-4 files.
+
+Why it exists: the reference opens weights and fields with ``xarray.open_dataset(..., engine=
+"netcdf4")`` (cdogenerate.py:296, regrid.py:136) and CDO writes HDF5-based NetCDF-4 with ``-f nc4``
+(cdogenerate.py:381); seven of the eight files of the reference's tests/data are HDF5.  This
+module lets :mod:`smmregrid_amd.io` read such files when neither xarray, netCDF4 nor h5py is
+importable ("HDF5-based NetCDF-4 needs a fallback").
+
+Scope: what the netCDF-C library writes for the classic data model --
+superblock v0-v3; object headers v1 and v2 (with continuation blocks); old-style groups (symbol
+table: v1 B-tree + local heap) and new-style groups (compact link messages, dense links in a
+fractal heap indexed by a v2 B-tree); attributes compact or dense; datatypes fixed-point, float,
+fixed and variable-length strings, object references, variable-length sequences of those;
+layouts compact, contiguous and chunked (v1 B-tree index; v4 single-chunk / implicit / fixed-array
+indexes); filters deflate, shuffle, fletcher32.  Anything else raises :class:`H5Unsupported` with the
+feature named -- never a silent wrong answer.  Only the root group is listed (netCDF classic
+model); nested groups can be opened by path.
+"""
+import mmap
+import struct
+import zlib
+
+import numpy as np
+
+UNDEF = 0xFFFFFFFFFFFFFFFF
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+
+
+class H5Error(OSError):
+    """Malformed or truncated file."""
+
+
+class H5Unsupported(H5Error):
+    """A valid HDF5 feature this reader does not implement."""
+
+
+def _pad8(n):
+    return (n + 7) & ~7
+
+
+class VlenType:
+    def __init__(self, base, is_string):
+        self.base, self.is_string = base, is_string
+
+
+class RefType:
+    pass
+
+
+class OpaqueType:
+    def __init__(self, size):
+        self.size = size
+
+
+class File:
+    def __init__(self, path):
+        self._fh = open(path, "rb")
+        try:
+            self.buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError:
+            self._fh.close()
+            raise H5Error(f"{path}: empty file")
+        self.path = path
+        try:
+            self._superblock()
+            self.root = Group(self, self.root_addr, "/")
+        except (struct.error, IndexError) as e:
+            self.close()
+            raise H5Error(f"{path}: truncated or corrupt HDF5 file ({e})")
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if self.buf is not None:
+            try:
+                self.buf.close()
+            except BufferError:
+                pass             # numpy views into the map are still alive; the map goes with them
+            self.buf = None
+        self._fh.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- primitives
+    def u(self, off, n):
+        if off < 0 or off + n > len(self.buf):
+            raise H5Error(f"{self.path}: read beyond end of file at {off}")
+        return int.from_bytes(self.buf[off:off + n], "little")
+
+    def addr(self, off):
+        v = self.u(off, self.so)
+        return UNDEF if v == (1 << (8 * self.so)) - 1 else v + self.base
+
+    def length(self, off):
+        return self.u(off, self.sl)
+
+    def _superblock(self):
+        b = self.buf
+        base = 0
+        while b[base:base + 8] != SIGNATURE:          # the superblock may sit at 0, 512, 1024, ...
+            base = 512 if base == 0 else base * 2
+            if base + 8 > len(b):
+                raise H5Error(f"{self.path}: not an HDF5 file")
+        ver = b[base + 8]
+        self.base = 0
+        if ver in (0, 1):
+            self.so, self.sl = b[base + 13], b[base + 14]
+            off = base + 24 + (4 if ver == 1 else 0)
+            self.base = self.u(off, self.so)
+            ste = off + 4 * self.so                    # root group symbol table entry
+            self.root_addr = self.addr(ste + self.so)
+        elif ver in (2, 3):
+            self.so, self.sl = b[base + 9], b[base + 10]
+            self.base = self.u(base + 12, self.so)
+            self.root_addr = self.addr(base + 12 + 3 * self.so)
+        else:
+            raise H5Unsupported(f"{self.path}: superblock version {ver}")
+        if self.so not in (2, 4, 8) or self.sl not in (2, 4, 8):
+            raise H5Error(f"{self.path}: bad offset/length sizes {self.so}/{self.sl}")
+
+    def __getitem__(self, name):
+        return self.root[name]
+
+    def keys(self):
+        return self.root.keys()
+
+    @property
+    def attrs(self):
+        return self.root.attrs
+
+    # ---- object headers
+    def messages(self, addr):
+        """[(type, flags, data_offset, size)] of the object header at addr (all chunks)."""
+        b = self.buf
+        out = []
+        if b[addr:addr + 4] == b"OHDR":
+            if b[addr + 4] != 2:
+                raise H5Unsupported(f"object header version {b[addr + 4]}")
+            flags = b[addr + 5]
+            p = addr + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            n = 1 << (flags & 3)
+            size0 = self.u(p, n)
+            p += n
+            blocks = [(p, size0)]
+            order = 2 if flags & 0x04 else 0
+            while blocks:
+                p, size = blocks.pop(0)
+                end = p + size
+                while p + 4 + order <= end:
+                    mtype, msize, mflags = b[p], self.u(p + 1, 2), b[p + 3]
+                    p += 4 + order
+                    if mtype == 0x10:
+                        caddr, clen = self.addr(p), self.length(p + self.so)
+                        if b[caddr:caddr + 4] != b"OCHK":
+                            raise H5Error("object header continuation without OCHK signature")
+                        blocks.append((caddr + 4, clen - 8))   # minus signature and checksum
+                    elif mtype != 0:
+                        out.append((mtype, mflags, p, msize))
+                    p += msize
+            return out
+        if b[addr] != 1:
+            raise H5Error(f"no object header at {addr}")
+        nmsg = self.u(addr + 2, 2)
+        size0 = self.u(addr + 8, 4)
+        blocks = [(addr + 16, size0)]
+        while blocks and nmsg > 0:
+            p, size = blocks.pop(0)
+            end = p + size
+            while p + 8 <= end and nmsg > 0:
+                mtype, msize, mflags = self.u(p, 2), self.u(p + 2, 2), b[p + 4]
+                p += 8
+                nmsg -= 1
+                if mtype == 0x10:
+                    blocks.append((self.addr(p), self.length(p + self.so)))
+                elif mtype != 0:
+                    out.append((mtype, mflags, p, msize))
+                p += msize
+        return out
+
+    # ---- datatypes
+    def datatype(self, p):
+        b = self.buf
+        cls, ver = b[p] & 0x0F, b[p] >> 4
+        bits = self.u(p + 1, 3)
+        size = self.u(p + 4, 4)
+        if cls == 0:
+            order = ">" if bits & 1 else "<"
+            kind = "i" if bits & 0x08 else "u"
+            if size not in (1, 2, 4, 8):
+                raise H5Unsupported(f"{size}-byte integer")
+            return np.dtype(f"{order}{kind}{size}")
+        if cls == 1:
+            if bits & 0x40:
+                raise H5Unsupported("VAX floating point")
+            if size not in (2, 4, 8):
+                raise H5Unsupported(f"{size}-byte float")
+            return np.dtype(f"{'>' if bits & 1 else '<'}f{size}")
+        if cls == 3:
+            return np.dtype(f"S{size}")
+        if cls == 7:
+            if size != self.so:
+                raise H5Unsupported("region / new-style references")
+            return RefType()
+        if cls == 9:
+            return VlenType(self.datatype(p + 8), (bits & 0x0F) == 1)
+        if cls == 8:                                  # enum (netCDF bool/enum): use the base integer
+            return self.datatype(p + 8)
+        return OpaqueType(size)                       # compound (REFERENCE_LIST), opaque, array, ...
+
+    def dataspace(self, p):
+        b = self.buf
+        ver, rank, flags = b[p], b[p + 1], b[p + 2]
+        if ver == 1:
+            q = p + 8
+        elif ver == 2:
+            if b[p + 3] == 2:
+                return None                            # null dataspace
+            q = p + 4
+        else:
+            raise H5Unsupported(f"dataspace version {ver}")
+        return tuple(self.length(q + i * self.sl) for i in range(rank))
+
+    # ---- heaps
+    def global_heap_object(self, caddr, index):
+        b = self.buf
+        if b[caddr:caddr + 4] != b"GCOL":
+            raise H5Error("global heap collection without GCOL signature")
+        size = self.length(caddr + 8)
+        p, end = caddr + 8 + self.sl, caddr + size
+        while p + 8 + self.sl <= end:
+            idx = self.u(p, 2)
+            osize = self.length(p + 8)
+            if idx == 0:
+                break
+            if idx == index:
+                return bytes(b[p + 8 + self.sl:p + 8 + self.sl + osize])
+            p += 8 + self.sl + _pad8(osize)
+        raise H5Error(f"global heap object {index} not found")
+
+    def decode(self, dtype, raw, shape):
+        """Raw element bytes -> numpy array / python objects."""
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        if isinstance(dtype, np.dtype):
+            arr = np.frombuffer(raw, dtype=dtype, count=n)
+            return arr.reshape(shape) if shape else arr.reshape(())
+        if isinstance(dtype, RefType):
+            arr = np.frombuffer(raw, dtype=f"<u{self.so}", count=n).astype(np.uint64)
+            return arr.reshape(shape) if shape else arr.reshape(())
+        if isinstance(dtype, VlenType):
+            out = np.empty(n, dtype=object)
+            step = 4 + self.so + 4
+            for i in range(n):
+                q = i * step
+                cnt = int.from_bytes(raw[q:q + 4], "little")
+                caddr = int.from_bytes(raw[q + 4:q + 4 + self.so], "little")
+                index = int.from_bytes(raw[q + 4 + self.so:q + step], "little")
+                if cnt == 0 or caddr == 0:
+                    out[i] = "" if dtype.is_string else np.zeros(0)
+                    continue
+                data = self.global_heap_object(caddr + self.base, index)
+                if dtype.is_string:
+                    out[i] = data[:cnt].decode("utf-8", "replace")
+                else:
+                    out[i] = self.decode(dtype.base, data, (cnt,))
+            return out.reshape(shape) if shape else out.reshape(())
+        return np.frombuffer(raw, dtype=f"V{dtype.size}", count=n).reshape(shape if shape else ())
+
+    def elem_size(self, dtype):
+        if isinstance(dtype, np.dtype):
+            return dtype.itemsize
+        if isinstance(dtype, RefType):
+            return self.so
+        if isinstance(dtype, VlenType):
+            return 4 + self.so + 4
+        return dtype.size
+
+    # ---- fractal heap + v2 B-tree (dense links / attributes)
+    def fractal_heap(self, addr):
+        return _FractalHeap(self, addr)
+
+    def btree2_records(self, addr):
+        b = self.buf
+        if b[addr:addr + 4] != b"BTHD":
+            raise H5Error("v2 B-tree without BTHD signature")
+        node_size = self.u(addr + 6, 4)
+        rec_size = self.u(addr + 10, 2)
+        depth = self.u(addr + 12, 2)
+        root = self.addr(addr + 16)
+        nroot = self.u(addr + 16 + self.so, 2)
+        if root == UNDEF or nroot == 0:
+            return []
+        # bytes needed to count the records of a child at each level (format spec III.A.2)
+        def nbytes(v):
+            return max(1, (int(v).bit_length() + 7) // 8)
+        max_leaf = (node_size - 10) // rec_size
+        max_per_level = [max_leaf]
+        cum_per_level = [max_leaf]
+        for lev in range(1, depth + 1):
+            ptr = self.so + nbytes(max_per_level[lev - 1]) + (nbytes(cum_per_level[lev - 1]) if lev > 1 else 0)
+            m = (node_size - 10 - ptr) // (rec_size + ptr)
+            max_per_level.append(m)
+            cum_per_level.append(m + (m + 1) * cum_per_level[lev - 1])
+        out = []
+
+        def walk(naddr, nrec, level):
+            sig = b[naddr:naddr + 4]
+            if level == 0:
+                if sig != b"BTLF":
+                    raise H5Error("v2 B-tree leaf without BTLF signature")
+                for i in range(nrec):
+                    q = naddr + 6 + i * rec_size
+                    out.append(bytes(b[q:q + rec_size]))
+                return
+            if sig != b"BTIN":
+                raise H5Error("v2 B-tree internal node without BTIN signature")
+            recs = [bytes(b[naddr + 6 + i * rec_size:naddr + 6 + (i + 1) * rec_size]) for i in range(nrec)]
+            q = naddr + 6 + nrec * rec_size
+            n1 = nbytes(max_per_level[level - 1])
+            n2 = nbytes(cum_per_level[level - 1]) if level > 1 else 0
+            for i in range(nrec + 1):
+                child = self.addr(q)
+                cn = self.u(q + self.so, n1)
+                q += self.so + n1 + n2
+                walk(child, cn, level - 1)
+                if i < nrec:
+                    out.append(recs[i])
+
+        walk(root, nroot, depth)
+        return out
+
+
+class _FractalHeap:
+    def __init__(self, f, addr):
+        b = f.buf
+        if b[addr:addr + 4] != b"FRHP":
+            raise H5Error("fractal heap without FRHP signature")
+        self.f = f
+        p = addr + 5
+        self.id_len = f.u(p, 2)
+        filt_len = f.u(p + 2, 2)
+        self.flags = b[p + 4]
+        p += 5
+        self.max_managed = f.u(p, 4)
+        p += 4 + f.sl + f.so + f.sl + f.so      # next huge id, huge btree, free space, fs manager
+        p += 4 * f.sl                            # managed space, allocated, iterator offset, nobjects
+        p += 4 * f.sl                            # huge size/count, tiny size/count
+        self.width = f.u(p, 2)
+        self.start_size = f.length(p + 2)
+        self.max_direct = f.length(p + 2 + f.sl)
+        self.max_heap_bits = f.u(p + 2 + 2 * f.sl, 2)
+        p += 2 + 2 * f.sl + 2 + 2
+        self.root = f.addr(p)
+        self.cur_rows = f.u(p + f.so, 2)
+        if filt_len:
+            raise H5Unsupported("filtered fractal heap")
+        self.off_bytes = (self.max_heap_bits + 7) // 8
+        lim = min(self.max_direct, self.max_managed)
+        self.len_bytes = max(1, (int(lim).bit_length() + 7) // 8)
+        self.blocks = []                         # (heap offset, file address, size) of direct blocks
+        if self.root != UNDEF:
+            if self.cur_rows == 0:
+                self.blocks.append((0, self.root, self.start_size))
+            else:
+                self._indirect(self.root, self.cur_rows)
+
+    def _row_size(self, row):
+        return self.start_size if row < 2 else self.start_size << (row - 1)
+
+    def _indirect(self, addr, nrows):
+        f = self.f
+        if f.buf[addr:addr + 4] != b"FHIB":
+            raise H5Error("fractal heap indirect block without FHIB signature")
+        p = addr + 5 + f.so
+        block_off = f.u(p, self.off_bytes)
+        p += self.off_bytes
+        max_direct_rows = 2
+        while self._row_size(max_direct_rows) <= self.max_direct and max_direct_rows < 64:
+            max_direct_rows += 1
+        # rows whose block size is <= max_direct hold direct blocks
+        off = block_off
+        for row in range(nrows):
+            size = self._row_size(row)
+            for _ in range(self.width):
+                child = f.addr(p)
+                p += f.so
+                if size <= self.max_direct:
+                    if child != UNDEF:
+                        self.blocks.append((off, child, size))
+                else:
+                    if child != UNDEF:
+                        sub_rows = (size // self.start_size // self.width).bit_length()  # log2 + 1
+                        self._indirect(child, sub_rows)
+                off += size
+
+    def get(self, heap_id):
+        kind = (heap_id[0] >> 4) & 3
+        if kind == 2:                            # tiny: data inside the id
+            n = (heap_id[0] & 0x0F) + 1
+            return bytes(heap_id[1:1 + n])
+        if kind != 0:
+            raise H5Unsupported("huge fractal-heap object")
+        off = int.from_bytes(heap_id[1:1 + self.off_bytes], "little")
+        ln = int.from_bytes(heap_id[1 + self.off_bytes:1 + self.off_bytes + self.len_bytes], "little")
+        for boff, baddr, bsize in self.blocks:
+            if boff <= off < boff + bsize:
+                q = baddr + (off - boff)
+                return bytes(self.f.buf[q:q + ln])
+        raise H5Error("fractal heap offset outside every direct block")
+
+
+class _Object:
+    def __init__(self, f, addr, name):
+        self.file, self.addr, self.name = f, addr, name
+        self._msgs = f.messages(addr)
+        self._attrs = None
+
+    def _parse_attribute(self, p):
+        f = self.file
+        b = f.buf
+        ver = b[p]
+        nsize, tsize, ssize = f.u(p + 2, 2), f.u(p + 4, 2), f.u(p + 6, 2)
+        if ver == 1:
+            q = p + 8
+            name = bytes(b[q:q + nsize]).split(b"\0")[0].decode("utf-8", "replace")
+            q += _pad8(nsize)
+            dt, qd = f.datatype(q), q
+            q += _pad8(tsize)
+            shape = f.dataspace(q)
+            q += _pad8(ssize)
+        elif ver in (2, 3):
+            if b[p + 1] & 0x03:
+                raise H5Unsupported("shared attribute datatype/dataspace")
+            q = p + 8 + (1 if ver == 3 else 0)
+            name = bytes(b[q:q + nsize]).split(b"\0")[0].decode("utf-8", "replace")
+            q += nsize
+            dt = f.datatype(q)
+            q += tsize
+            shape = f.dataspace(q)
+            q += ssize
+        else:
+            raise H5Unsupported(f"attribute message version {ver}")
+        if shape is None:
+            return name, None
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        raw = bytes(b[q:q + n * f.elem_size(dt)])
+        return name, f.decode(dt, raw, shape)
+
+    @property
+    def attrs(self):
+        if self._attrs is None:
+            f = self.file
+            out = {}
+            for mtype, _, p, _ in self._msgs:
+                if mtype == 0x0C:
+                    k, v = self._parse_attribute(p)
+                    out[k] = v
+                elif mtype == 0x15:                      # attribute info: dense storage
+                    flags = f.buf[p + 1]
+                    q = p + 2 + (2 if flags & 1 else 0)
+                    heap_addr, bt_addr = f.addr(q), f.addr(q + f.so)
+                    if heap_addr != UNDEF and bt_addr != UNDEF:
+                        heap = f.fractal_heap(heap_addr)
+                        for rec in f.btree2_records(bt_addr):
+                            msg = heap.get(rec[:heap.id_len] if heap.id_len <= 8 else rec[:8])
+                            # the heap object is an attribute message body: parse it from a scratch map
+                            k, v = _parse_attr_bytes(f, msg)
+                            out[k] = v
+            self._attrs = out
+        return self._attrs
+
+
+def _parse_attr_bytes(f, msg):
+    """Attribute message held in a heap object (not in the file map)."""
+    tmp = _Scratch(f, msg)
+    return _Object._parse_attribute(tmp.obj, 0)
+
+
+class _Scratch:
+    """Lets the message parsers run on a detached bytes object."""
+
+    def __init__(self, f, data):
+        class _F:
+            pass
+        g = _F()
+        g.buf, g.so, g.sl, g.base, g.path = data, f.so, f.sl, f.base, f.path
+        g.u = lambda off, n: int.from_bytes(data[off:off + n], "little")
+        g.length = lambda off: g.u(off, f.sl)
+        g.addr = lambda off: (UNDEF if g.u(off, f.so) == (1 << (8 * f.so)) - 1 else g.u(off, f.so) + f.base)
+        g.datatype = lambda p: File.datatype(g, p)
+        g.dataspace = lambda p: File.dataspace(g, p)
+        g.elem_size = lambda dt: File.elem_size(g, dt)
+        g.decode = lambda dt, raw, shape: f.decode(dt, raw, shape)       # heaps live in the real file
+        o = object.__new__(_Object)
+        o.file = g
+        self.obj = o
+
+
+class Group(_Object):
+    def __init__(self, f, addr, name):
+        super().__init__(f, addr, name)
+        self._links = None
+
+    def _load_links(self):
+        f = self.file
+        b = f.buf
+        links = {}
+        for mtype, _, p, size in self._msgs:
+            if mtype == 0x06:
+                k, a = _parse_link(f, p)
+                if a is not None:
+                    links[k] = a
+            elif mtype == 0x02:                          # link info: dense storage
+                flags = b[p + 1]
+                q = p + 2 + (8 if flags & 1 else 0)
+                heap_addr, bt_addr = f.addr(q), f.addr(q + f.so)
+                if heap_addr != UNDEF and bt_addr != UNDEF:
+                    heap = f.fractal_heap(heap_addr)
+                    for rec in f.btree2_records(bt_addr):
+                        msg = heap.get(rec[4:4 + heap.id_len])   # record = name hash (4 B) + heap id
+                        k, a = _parse_link(_Scratch(f, msg).obj.file, 0)
+                        if a is not None:
+                            links[k] = a
+            elif mtype == 0x11:                          # symbol table (old-style group)
+                self._symbol_table(f.addr(p), f.addr(p + f.so), links)
+        self._links = links
+
+    def _symbol_table(self, btree, heap, links):
+        f = self.file
+        b = f.buf
+        if b[heap:heap + 4] != b"HEAP":
+            raise H5Error("local heap without HEAP signature")
+        data = f.addr(heap + 8 + 2 * f.sl)
+
+        def name_at(off):
+            q = data + off
+            end = b.find(b"\0", q)
+            return bytes(b[q:end]).decode("utf-8", "replace")
+
+        def walk(addr):
+            if b[addr:addr + 4] == b"SNOD":
+                n = f.u(addr + 6, 2)
+                q = addr + 8
+                for _ in range(n):
+                    links[name_at(f.u(q, f.so))] = f.addr(q + f.so)
+                    q += 2 * f.so + 24
+                return
+            if b[addr:addr + 4] != b"TREE" or b[addr + 4] != 0:
+                raise H5Error("group B-tree node expected")
+            used = f.u(addr + 6, 2)
+            q = addr + 8 + 2 * f.so
+            for _ in range(used):
+                q += f.sl                                # key
+                walk(f.addr(q))
+                q += f.so
+        if btree != UNDEF:
+            walk(btree)
+
+    def keys(self):
+        if self._links is None:
+            self._load_links()
+        return list(self._links)
+
+    def __contains__(self, name):
+        return name in self.keys()
+
+    def __getitem__(self, name):
+        node = self
+        for part in [s for s in name.split("/") if s]:
+            if node._links is None:
+                node._load_links()
+            if part not in node._links:
+                raise KeyError(name)
+            node = _open_object(node.file, node._links[part], part)
+        return node
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+
+def _parse_link(f, p):
+    b = f.buf
+    flags = b[p + 1]
+    q = p + 2
+    ltype = 0
+    if flags & 0x08:
+        ltype = b[q]
+        q += 1
+    if flags & 0x04:
+        q += 8
+    if flags & 0x10:
+        q += 1
+    n = 1 << (flags & 3)
+    nlen = f.u(q, n)
+    q += n
+    name = bytes(b[q:q + nlen]).decode("utf-8", "replace")
+    q += nlen
+    if ltype != 0:
+        return name, None                               # soft / external links are not followed
+    return name, f.addr(q)
+
+
+def _open_object(f, addr, name):
+    kinds = {m[0] for m in f.messages(addr)}
+    if 0x08 in kinds or 0x01 in kinds and 0x03 in kinds:
+        return DatasetNode(f, addr, name)
+    return Group(f, addr, name)
+
+
+class DatasetNode(_Object):
+    def __init__(self, f, addr, name):
+        super().__init__(f, addr, name)
+        self.shape = ()
+        self.dtype = None
+        self._layout = None
+        self._filters = []
+        self._fill = None
+        b = f.buf
+        for mtype, mflags, p, size in self._msgs:
+            if mtype == 0x01:
+                self.shape = f.dataspace(p)
+            elif mtype == 0x03:
+                if mflags & 0x02:
+                    raise H5Unsupported("shared (committed) datatype")
+                self.dtype = f.datatype(p)
+            elif mtype == 0x08:
+                self._layout = p
+            elif mtype == 0x0B:
+                self._filters = self._parse_filters(p)
+            elif mtype == 0x05:
+                self._fill = self._parse_fill(p)
+        if self.shape is None:
+            self.shape = ()
+            self._null = True
+        else:
+            self._null = False
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def _parse_filters(self, p):
+        f = self.file
+        b = f.buf
+        ver, n = b[p], b[p + 1]
+        out = []
+        q = p + (8 if ver == 1 else 2)
+        for _ in range(n):
+            fid = f.u(q, 2)
+            q += 2
+            nlen = 0
+            if ver == 1 or fid >= 256:
+                nlen = f.u(q, 2)
+                q += 2
+            q += 2                                       # flags
+            ncd = f.u(q, 2)
+            q += 2
+            q += _pad8(nlen) if ver == 1 else nlen
+            cd = [f.u(q + 4 * i, 4) for i in range(ncd)]
+            q += 4 * ncd
+            if ver == 1 and ncd % 2:
+                q += 4
+            out.append((fid, cd))
+        return out
+
+    def _parse_fill(self, p):
+        f = self.file
+        b = f.buf
+        ver = b[p]
+        if ver in (1, 2):
+            defined = b[p + 3]
+            if ver == 1 or defined:
+                size = f.u(p + 4, 4)
+                return bytes(b[p + 8:p + 8 + size]) if size else None
+            return None
+        if ver == 3:
+            flags = b[p + 1]
+            if flags & 0x20:
+                size = f.u(p + 2, 4)
+                return bytes(b[p + 6:p + 6 + size]) if size else None
+            return None
+        return None
+
+    def _unfilter(self, raw, mask, itemsize):
+        for i in range(len(self._filters) - 1, -1, -1):
+            fid, cd = self._filters[i]
+            if mask & (1 << i):
+                continue
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                n = len(raw) // itemsize
+                arr = np.frombuffer(raw, dtype=np.uint8, count=n * itemsize).reshape(itemsize, n)
+                raw = arr.T.tobytes() + raw[n * itemsize:]
+            elif fid == 3:
+                raw = raw[:-4]
+            else:
+                raise H5Unsupported(f"filter id {fid} (only deflate, shuffle, fletcher32)")
+        return raw
+
+    def read(self):
+        f = self.file
+        b = f.buf
+        if self._null or self._layout is None or self.dtype is None:
+            return None
+        dt = self.dtype
+        isz = f.elem_size(dt)
+        shape = self.shape
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        p = self._layout
+        ver = b[p]
+        if ver not in (3, 4):
+            raise H5Unsupported(f"data layout message version {ver}")
+        cls = b[p + 1]
+        if cls == 0:
+            size = f.u(p + 2, 2)
+            return self._finish(bytes(b[p + 4:p + 4 + size]), shape)
+        if cls == 1:
+            a = f.addr(p + 2)
+            if a == UNDEF:
+                return self._filled(shape)
+            if a + n * isz > len(b):
+                raise H5Error(f"{f.path}: dataset {self.name} extends beyond the end of the file")
+            return self._finish(b[a:a + n * isz], shape)
+        if cls != 2:
+            raise H5Unsupported(f"layout class {cls} (virtual datasets)")
+        if not isinstance(dt, np.dtype):
+            raise H5Unsupported("chunked dataset of a non-numeric type")
+        if ver == 3:
+            nd = b[p + 2]
+            bt = f.addr(p + 3)
+            cdims = tuple(f.u(p + 3 + f.so + 4 * i, 4) for i in range(nd - 1))
+            chunks = self._btree1_chunks(bt, nd) if bt != UNDEF else []
+        else:
+            flags, nd, enc = b[p + 2], b[p + 3], b[p + 4]
+            cdims = tuple(f.u(p + 5 + enc * i, enc) for i in range(nd - 1))
+            q = p + 5 + enc * nd
+            itype = b[q]
+            q += 1
+            chunks = self._v4_chunks(itype, q, flags, cdims, isz)
+        out = self._filled(shape)
+        chunk_bytes = int(np.prod(cdims, dtype=np.int64)) * isz
+        for offs, caddr, csize, mask in chunks:
+            raw = bytes(b[caddr:caddr + csize])
+            if self._filters:
+                raw = self._unfilter(raw, mask, isz)
+            if len(raw) < chunk_bytes:
+                raise H5Error(f"{f.path}: chunk of {self.name} is short ({len(raw)} < {chunk_bytes})")
+            block = np.frombuffer(raw, dtype=dt, count=chunk_bytes // isz).reshape(cdims)
+            sel_out, sel_in = [], []
+            for o, c, s in zip(offs, cdims, shape):
+                m = min(c, s - o)
+                if m <= 0:
+                    break
+                sel_out.append(slice(o, o + m))
+                sel_in.append(slice(0, m))
+            else:
+                out[tuple(sel_out)] = block[tuple(sel_in)]
+        return out
+
+    def _filled(self, shape):
+        dt = self.dtype
+        out = np.zeros(shape, dtype=dt.newbyteorder("=") if isinstance(dt, np.dtype) else dt)
+        if self._fill and isinstance(dt, np.dtype) and len(self._fill) == dt.itemsize:
+            out[...] = np.frombuffer(self._fill, dtype=dt, count=1)[0]
+        return out
+
+    def _finish(self, raw, shape):
+        arr = self.file.decode(self.dtype, raw, shape)
+        if isinstance(arr, np.ndarray) and arr.dtype.kind in "iuf" and not arr.dtype.isnative:
+            arr = arr.astype(arr.dtype.newbyteorder("="))
+        return np.array(arr) if isinstance(arr, np.ndarray) else arr
+
+    def _btree1_chunks(self, addr, nd):
+        f = self.file
+        b = f.buf
+        out = []
+        key = 8 + 8 * nd
+
+        def walk(a):
+            if b[a:a + 4] != b"TREE" or b[a + 4] != 1:
+                raise H5Error("chunk B-tree node expected")
+            level, used = b[a + 5], f.u(a + 6, 2)
+            q = a + 8 + 2 * f.so
+            for _ in range(used):
+                csize, mask = f.u(q, 4), f.u(q + 4, 4)
+                offs = tuple(f.u(q + 8 + 8 * i, 8) for i in range(nd - 1))
+                child = f.addr(q + key)
+                if level == 0:
+                    out.append((offs, child, csize, mask))
+                else:
+                    walk(child)
+                q += key + f.so
+        walk(addr)
+        return out
+
+    def _v4_chunks(self, itype, q, flags, cdims, isz):
+        f = self.file
+        b = f.buf
+        shape = self.shape
+        nchunks = [-(-s // c) for s, c in zip(shape, cdims)]
+        total = int(np.prod(nchunks, dtype=np.int64)) if nchunks else 1
+        chunk_bytes = int(np.prod(cdims, dtype=np.int64)) * isz
+
+        def offsets(i):
+            offs = []
+            for nc, c in zip(reversed(nchunks), reversed(cdims)):
+                offs.append((i % nc) * c)
+                i //= nc
+            return tuple(reversed(offs))
+
+        if itype == 1:                                  # single chunk
+            if flags & 0x02:
+                size, mask = f.length(q), f.u(q + f.sl, 4)
+                a = f.addr(q + f.sl + 4)
+            else:
+                size, mask, a = chunk_bytes, 0, f.addr(q)
+            return [] if a == UNDEF else [(offsets(0), a, size, mask)]
+        if itype == 2:                                  # implicit: contiguous run of unfiltered chunks
+            a = f.addr(q)
+            return [] if a == UNDEF else [(offsets(i), a + i * chunk_bytes, chunk_bytes, 0) for i in range(total)]
+        if itype == 3:                                  # fixed array
+            page_bits = b[q]
+            hdr = f.addr(q + 1)
+            if hdr == UNDEF:
+                return []
+            if b[hdr:hdr + 4] != b"FAHD":
+                raise H5Error("fixed array header expected")
+            client, esize = b[hdr + 5], b[hdr + 6]
+            nelem = f.length(hdr + 8)
+            dblk = f.addr(hdr + 8 + f.sl)
+            if dblk == UNDEF:
+                return []
+            if nelem > (1 << page_bits):
+                raise H5Unsupported("paged fixed-array chunk index")
+            p = dblk + 6 + f.so
+            out = []
+            for i in range(nelem):
+                a = f.addr(p)
+                if client == 1:                         # filtered chunks: address, size, mask
+                    sz = f.u(p + f.so, esize - f.so - 4)
+                    mask = f.u(p + esize - 4, 4)
+                else:
+                    sz, mask = chunk_bytes, 0
+                if a != UNDEF:
+                    out.append((offsets(i), a, sz, mask))
+                p += esize
+            return out
+        raise H5Unsupported(f"chunk index type {itype} (extensible array / v2 B-tree)")

@@ -1,6 +1,6 @@
-"""Weights files without xarray/netCDF4: ``.npz`` (this package's cache format)
-and NetCDF-3 classic / 64-bit-offset (``scipy.io.netcdf_file``).  HDF5-based
-NetCDF-4 files need xarray (then pass the opened Dataset to Regridder)."""
+"""Weights and field files without xarray/netCDF4: ``.npz`` (this package's cache format),
+NetCDF-3 classic / 64-bit-offset (``scipy.io.netcdf_file``) and HDF5-based NetCDF-4 -- through
+xarray or h5py when importable, else the built-in pure-Python reader (``hdf5lite.py``)."""
 import json
 
 import numpy as np
@@ -55,8 +55,93 @@ def open_weights(path):
     try:
         import h5py
     except ImportError:
-        raise OSError(f"{path}: HDF5-based NetCDF-4 needs xarray, netCDF4 or h5py")
+        return _open_netcdf4_lite(path)      # built-in pure-Python HDF5 reader (hdf5lite.py)
     return _open_netcdf4_h5py(h5py, path)
+
+
+open_dataset = open_weights                 # fields and grids come through the same readers
+
+
+_NC4_INTERNAL = {"DIMENSION_LIST", "REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates",
+                 "_NCProperties", "_nc3_strict"}
+
+
+def _attr_value(v):
+    """HDF5 attribute -> what xarray shows: str for text, python scalar for 1-element arrays."""
+    if isinstance(v, bytes):
+        return v.decode("utf-8", "replace")
+    if isinstance(v, np.ndarray):
+        if v.dtype.kind == "S":
+            return _attr_value(bytes(v.ravel()[0])) if v.size == 1 else [_attr_value(bytes(x)) for x in v.ravel()]
+        if v.dtype.kind == "O":
+            return v.ravel()[0] if v.size == 1 else list(v.ravel())
+        if v.size == 1:
+            return v.ravel()[0].item()
+    return v
+
+
+def _cf_decode(values, attrs):
+    """xarray's default mask_and_scale for what the regridding path consumes: _FillValue /
+    missing_value -> NaN, then scale_factor / add_offset.  Times stay numeric."""
+    fills = [attrs[k] for k in ("_FillValue", "missing_value") if k in attrs]
+    scale, offset = attrs.get("scale_factor"), attrs.get("add_offset")
+    if not fills and scale is None and offset is None:
+        return values
+    if values.dtype.kind not in "iuf":
+        return values
+    out_dtype = values.dtype if values.dtype.kind == "f" else np.float64
+    if values.dtype.kind in "iu" and values.dtype.itemsize <= 2 and (scale is not None or offset is not None):
+        out_dtype = np.float32
+    mask = np.zeros(values.shape, dtype=bool)
+    for fv in fills:
+        for x in np.atleast_1d(fv):
+            mask |= values == x
+    out = values.astype(out_dtype)
+    if scale is not None:
+        out = out * np.asarray(scale, dtype=out_dtype)
+    if offset is not None:
+        out = out + np.asarray(offset, dtype=out_dtype)
+    if mask.any():
+        out[mask] = np.nan
+    return out
+
+
+def _open_netcdf4_lite(path, decode=True):
+    """NetCDF-4 (HDF5) through the built-in reader: variables with the dimension names netCDF stores
+    as attached dimension scales (DIMENSION_LIST object references), coordinates, attributes."""
+    from . import hdf5lite
+    with hdf5lite.File(path) as f:
+        nodes = {k: v for k, v in f.root.items() if isinstance(v, hdf5lite.DatasetNode)}
+        by_addr = {v.addr: k for k, v in nodes.items()}
+        ds = Dataset(attrs={k: _attr_value(v) for k, v in f.attrs.items() if k not in _NC4_INTERNAL})
+        for name, var in nodes.items():
+            at = var.attrs
+            cls = at.get("CLASS")
+            is_scale = cls is not None and _attr_value(cls) == "DIMENSION_SCALE"
+            if is_scale and str(_attr_value(at.get("NAME", b""))).startswith("This is a netCDF dimension"):
+                continue                       # a dimension without coordinate variable
+            dims = []
+            dimlist = at.get("DIMENSION_LIST")
+            for i in range(var.ndim):
+                refs = dimlist[i] if dimlist is not None and i < len(dimlist) else ()
+                if len(refs) and int(refs[0]) in by_addr:
+                    dims.append(by_addr[int(refs[0])])
+                else:
+                    dims.append(name if is_scale else f"{name}_dim{i}")
+            values = var.read()
+            if values is None:
+                continue
+            attrs = {k: _attr_value(v) for k, v in at.items() if k not in _NC4_INTERNAL}
+            if decode and isinstance(values, np.ndarray):
+                values = _cf_decode(values, attrs)
+                for k in ("_FillValue", "missing_value", "scale_factor", "add_offset"):
+                    attrs.pop(k, None)
+            arr = DataArray(values, dims=dims, name=name, attrs=attrs)
+            if is_scale and dims == [name]:
+                ds.coords[name] = arr
+            else:
+                ds[name] = arr
+    return ds
 
 
 def _open_netcdf4_h5py(h5py, path):

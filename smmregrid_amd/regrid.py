@@ -86,6 +86,9 @@ class Regridder(object):
             if isinstance(source_grid, str) and os.path.sep in source_grid \
                     and not os.path.isfile(source_grid):
                 raise FileNotFoundError(f'Cannot find grid file {source_grid}')
+            if isinstance(source_grid, str) and os.path.isfile(source_grid):
+                from .io import open_dataset       # regrid.py:133-136: a data file as source grid
+                source_grid = open_dataset(source_grid)
             source_grid_array = from_xarray(source_grid)
             self.grids = self._gridtype_from_data(source_grid_array)
             if len(self.grids) == 0:

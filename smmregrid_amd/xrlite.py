@@ -88,7 +88,7 @@ class Dataset:
     """Ordered name -> DataArray mapping with shared attrs (weights files, multi-variable input)."""
 
     def __init__(self, data_vars=None, coords=None, attrs=None):
-        self.data_vars = OrderedDict()
+        self._vars = OrderedDict()
         self.coords = OrderedDict()
         for k, v in (coords or {}).items():
             self.coords[k] = v if isinstance(v, DataArray) else DataArray(np.asarray(v), dims=(k,), name=k)
@@ -103,17 +103,29 @@ class Dataset:
             value = DataArray(data, dims=dims, attrs=attrs)
         if value.name is None:
             value.name = name
-        self.data_vars[name] = value
+        self._vars[name] = value
 
     def __getitem__(self, name):
-        if name in self.data_vars:
-            return self.data_vars[name]
+        if name in self._vars:
+            # as in xarray, a variable taken from a Dataset carries the coordinates on its dimensions
+            var = self._vars[name]
+            extra = {k: c for k, c in self.coords.items()
+                     if k not in var.coords and c.dims and set(c.dims) <= set(var.dims)}
+            if not extra:
+                return var
+            coords = OrderedDict(var.coords)
+            coords.update(extra)
+            return DataArray(var.data, dims=var.dims, coords=coords, attrs=var.attrs, name=var.name)
         if name in self.coords:
             return self.coords[name]
         raise KeyError(name)
 
     def __contains__(self, name):
-        return name in self.data_vars or name in self.coords
+        return name in self._vars or name in self.coords
+
+    @property
+    def data_vars(self):
+        return OrderedDict((k, self[k]) for k in self._vars)
 
     def __getattr__(self, name):
         try:
@@ -140,9 +152,15 @@ class Dataset:
         return self.sizes
 
     def map(self, func, keep_attrs=True):
-        out = Dataset(attrs=self.attrs if keep_attrs else None, coords=self.coords)
+        # as xarray.Dataset.map: the new Dataset is built from the results, so its coordinates are
+        # theirs (target lat/lon after a regrid), not this Dataset's
+        out = Dataset(attrs=self.attrs if keep_attrs else None)
         for k, v in self.data_vars.items():
-            out[k] = func(v)
+            res = func(v)
+            out[k] = res
+            for ck, cv in res.coords.items():
+                if ck not in out.coords and cv.dims:
+                    out.coords[ck] = cv
         return out
 
     def drop_vars(self, names):

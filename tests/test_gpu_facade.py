@@ -325,6 +325,33 @@ def test_reference_test_data_2t_era5(hip, method, target, shape):
     assert 180.0 < np.nanmin(out.values) and np.nanmax(out.values) < 330.0      # Kelvin stays Kelvin
 
 
+def test_netcdf4_files_of_the_reference_through_the_builtin_reader(hip):
+    """basic_test.py:42-79 pattern, from the file: `Regridder(source_grid=<path>, ...)` and
+    `open_dataset(path)` go through smmregrid_amd/hdf5lite.py (no xarray / netCDF4 / h5py here)
+    and give the same result as the arrays of the h5py-made fixture."""
+    from smmregrid_amd.io import open_dataset
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    path = os.path.join(golden, "refdata", "2t-era5.nc")
+    ds = open_dataset(path)
+    rg = Regridder(source_grid=path, target_grid="r72x36", method="bil")
+    out = rg.regrid(ds)
+    assert out["2t"].shape == (12, 36, 72)
+    # a bounds variable defines no grid (gridinspector.py:70-78), so regrid_array returns the empty
+    # DataArray and regrid() drops it (regrid.py:264-266); the Dataset's coordinates are the target's
+    assert "time_bnds" not in out.variables and out.coords["lat"].values.shape == (36,)
+    z = np.load(os.path.join(golden, "2t_era5.npz"))
+    field = DataArray(z["t2m"], dims=("time", "lat", "lon"), coords={"time": z["time"], "lat": z["lat"], "lon": z["lon"]},
+                      name="2t")
+    want = Regridder(source_grid=field, target_grid="r72x36", method="bil").regrid(field)
+    assert_same(out["2t"].values, want.values, exact=True)
+    # a HEALPix + levels file and a regional lon/lat file of the same test-data set
+    hp = open_dataset(os.path.join(golden, "refdata", "healpix_0.nc"))
+    assert hp["ta"].dims == ("time", "level_full", "x")
+    reg = open_dataset(os.path.join(golden, "refdata", "r360x180.nc"))
+    outr = Regridder(source_grid=reg, target_grid="r90x45", method="con").regrid(reg["pr"])
+    assert outr.shape == (1, 45, 90) and np.isfinite(outr.values).all()
+
+
 def test_out_dtype_float32_is_the_rounded_float64_result(hip, rng):
     field = tas_field(rng, nt=3)
     w = CdoGenerate("r96x48", "r36x18").weights(method="con")
