@@ -71,3 +71,25 @@ def test_healpix_polar_blocks_in_group(hip, rng):
     y = grp.apply(to_device(x), np.array([1, 0], np.int32), transpose=True).to_host()
     ref = oracle.apply_levels([o.export_csr() for o in ops], x, 1, [1, 0], [False, False], None, None, 0.0, True)
     assert_same(y, ref, exact=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tightened_budget_demotes_moderately_wide_blocks(hip, rng, dtype):
+    """A block that would fit the full LDS budget but is far wider than all the others is demoted to
+    direct gathering (tighten_tile_plan), so the LDS request -- and the workgroups per CU -- follow
+    the typical block; the small tiles then run the multi-row steps.  Every kernel form stays exact."""
+    n_dst, n_src = 256 * 150, 256 * 150 * 2 + 8
+    d = np.repeat(np.arange(n_dst), 4)
+    s_ = d * 2 + np.tile(np.arange(4), n_dst)
+    wide = (d >= 256 * 50) & (d < 256 * 51)
+    s_[wide] = 256 * 50 * 2 + rng.integers(0, 4800, size=int(wide.sum()))     # ~300 chunks, budget 512
+    src, dst, w = (s_ + 1).astype(np.int32), (d + 1).astype(np.int32), rng.random(d.size)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    info = op.plan_info()
+    assert info["tile_plan"] and info["lds_bytes"] <= 64 * 16 * 8, info        # 64 chunks, not ~300
+    csr = op.export_csr()
+    x = field(rng, 11, n_src, dtype=dtype, nan_frac=0.01)
+    ref = oracle.apply_c(csr, x)
+    t = _lib.APPLY_KERNEL_TILE
+    for fl in (0, t, t | (12 << 16), t | (6 << 16), t | (3 << 20), _lib.APPLY_KERNEL_SELL):
+        assert_same(op.apply(to_device(x), flags=fl).to_host(), ref, exact=True)

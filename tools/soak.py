@@ -22,7 +22,11 @@ for seed in range(n):
     x = field(rng, int(rng.integers(1, 70)), n_src, dtype=dtype, nan_frac=0.03, inf_frac=0.003)
     amin = float(rng.choice([0.0, 0.5])); masked = bool(seed % 2)
     ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
-    ks = [0, _lib.APPLY_KERNEL_SELL] + ([_lib.APPLY_KERNEL_TILE] if op.plan_info()["tile_plan"] else [])
+    ks = [0, _lib.APPLY_KERNEL_SELL]
+    if op.plan_info()["tile_plan"]:
+        # default tile kernel, XCD remap, single-row steps, and odd walk lengths (tails of multi-row steps)
+        t = _lib.APPLY_KERNEL_TILE
+        ks += [t, t | (6 << 16), t | (12 << 16)] + [t | (j << 20) for j in (1, 3, 5, 7)]
     dx = to_device(x)
     for fl in ks:
         for rep in range(3):
