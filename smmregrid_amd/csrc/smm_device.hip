@@ -292,11 +292,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   // An operator that does not stay in L2 (links x 12 B beyond ~32 MB) is re-read from HBM by every
   // walk: amortise it over long walks whatever the row length.
   const bool big_operator = a.n_dst * std::max<int64_t>(max_row_nnz, 1) * 12 > (32ll << 20);
-  // Rows of 5..16 links walk 16 rows: neighbouring blocks share halo lines through the memory-side
-  // cache only while they work on nearby batch rows, and longer walks let them drift apart
-  // (config 5, B = 12 741: 27.8 ms at 16, 31-34 ms and bimodal at 32-64).
-  int64_t walk = jpb ? (int64_t)jpb
-                     : (big_operator ? 128 : (max_row_nnz <= 4 ? 4 : (max_row_nnz <= 16 ? 16 : 64)));
+  int64_t walk = jpb ? (int64_t)jpb : (big_operator ? 128 : (max_row_nnz <= 4 ? 4 : 64));
   if (!jpb)
     while (walk > 1 && a.n_dblocks * ((a.n_j + walk - 1) / walk) * n_lev < 4096) walk /= 2;
   args.j_per_block = (int)std::min<int64_t>(a.n_j, walk);
@@ -305,7 +301,8 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   if (total <= 0) return SMM_OK;
   if (total > 0x7fffffffLL) return fail(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
   args.n_blocks = total;
-  args.xcd_remap = (variant == 6 || variant == 7) ? 1 : 0;
+  // runs of 32 consecutive blocks per XCD (variant 6: dispatcher order, 7 / 13: runs of 8 / 128)
+  args.xcd_remap = variant == 6 ? 0 : (variant == 7 ? 8 : (variant == 13 ? 128 : 32));
   const size_t tile = (size_t)max_chunks * kChunkElems * sizeof(XT);
   const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
   const int threads = (tile_which ? 1 : kWavesPerBlock) * 64;  // == tile_waves(MAXK) * 64
@@ -355,7 +352,6 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   if (variant == 3) nt = 3;
   if (variant == 4) nt = 2;
   if (variant == 5) nt = 1;
-  if (variant == 7) nt = 2;
   return with_k([&](auto k_tag) -> int {
     auto with_nt = [&](auto np_tag) -> int {
       switch (nt) {

@@ -54,7 +54,7 @@ struct ApplyArgs {
   double area_min;
   int masked;
   int j_per_block;   // tile kernel: batch rows walked by one workgroup
-  int xcd_remap;     // tile kernel: logical block = contiguous range per XCD (hardware ids are dealt round-robin)
+  int xcd_remap;     // tile kernel: > 0 = length of the runs of consecutive blocks given to one XCD
   int64_t n_blocks;  // grid size (for the remap)
   int tile_bytes;    // tile kernel with R > 1: LDS bytes of one batch row's tile
 };
@@ -219,9 +219,16 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   const int lane = tid & 63;
   const int wave = tid >> 6;
   int64_t bid = blockIdx.x;
-  if (a.xcd_remap) {  // hardware block b runs on XCD b % 8: give each XCD one contiguous range
-    const int64_t q = a.n_blocks >> 3, r = a.n_blocks & 7, xcd = bid & 7;
-    bid = xcd * q + (xcd < r ? xcd : r) + (bid >> 3);
+  if (a.xcd_remap > 0) {
+    // Hardware block b runs on XCD b % 8.  Runs of C consecutive logical blocks (neighbours in
+    // space, sharing halo lines) go to one XCD, and the runs are dealt round-robin so that every
+    // XCD sees the same mix of light and heavy levels.  Blocks past the last full round keep
+    // their id (bijective for any grid size).
+    const int64_t C = a.xcd_remap, round = 8 * C;
+    if (bid < (a.n_blocks / round) * round) {
+      const int64_t xcd = bid & 7, slot = bid >> 3;
+      bid = (slot / C) * round + xcd * C + (slot % C);
+    }
   }
   const int64_t db = bid % a.n_dblocks;
   bid /= a.n_dblocks;
@@ -330,8 +337,10 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     // hold the global columns), one batch row at a time; no LDS, no barrier
     if (slice_live) {
       const int32_t* __restrict__ gcp = L.col + soff + lane;
-      for (int64_t j = j_begin; j < j_end; ++j) {
-        const XT* __restrict__ xrow = (const XT*)a.x + row_off(j, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+      RowWalker xwd(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+      RowWalker ywd(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+      for (int64_t j = j_begin; j < j_end; ++j, xwd.next(), ywd.next()) {
+        const XT* __restrict__ xrow = (const XT*)a.x + xwd.off;
         double acc = 0.0;
 #pragma unroll 4
         for (int k = 0; k < wmax; ++k) {
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
           acc = (k < len) ? sum : acc;
         }
         if (row_live) {
-          YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+          YT* __restrict__ yrow = (YT*)a.y + ywd.off;
           yrow[d] = (YT)epilogue(acc, dead);
         }
       }
@@ -354,12 +363,14 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     // no barrier needed -- every batch row gets epilogue(0)
     if (row_live) {
       const YT out = (YT)epilogue(0.0, dead);
+      RowWalker yw0(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
       for (int64_t j = j_begin; j < j_end; ++j) {
-        YT* __restrict__ yrow = (YT*)a.y + row_off(j, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+        YT* __restrict__ yrow = (YT*)a.y + yw0.off;
         if (NT & 2)
           __builtin_nontemporal_store(out, yrow + d);
         else
           yrow[d] = out;
+        yw0.next();
       }
     }
     return;

@@ -24,9 +24,9 @@ for seed in range(n):
     ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
     ks = [0, _lib.APPLY_KERNEL_SELL]
     if op.plan_info()["tile_plan"]:
-        # default tile kernel, XCD remap, single-row steps, and odd walk lengths (tails of multi-row steps)
+        # default tile kernel, other block orders, single-row steps, odd walk lengths (tails of multi-row steps)
         t = _lib.APPLY_KERNEL_TILE
-        ks += [t, t | (6 << 16), t | (12 << 16)] + [t | (j << 20) for j in (1, 3, 5, 7)]
+        ks += [t, t | (6 << 16), t | (7 << 16), t | (13 << 16), t | (12 << 16)] + [t | (j << 20) for j in (1, 3, 5, 7)]
     dx = to_device(x)
     for fl in ks:
         for rep in range(3):
