@@ -339,6 +339,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
       if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
       return fn(std::integral_constant<int, 16>());
     }
+    if (variant == 14) return fn(std::integral_constant<int, 0>());  // tuning: stream the links
     if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
     if (max_row_nnz <= 48) return fn(std::integral_constant<int, 48>());
     return fn(std::integral_constant<int, 0>());  // longer rows: links streamed from L2

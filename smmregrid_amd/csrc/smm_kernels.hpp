@@ -342,13 +342,25 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       for (int64_t j = j_begin; j < j_end; ++j, xwd.next(), ywd.next()) {
         const XT* __restrict__ xrow = (const XT*)a.x + xwd.off;
         double acc = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < wmax; ++k) {
-          const int kc = min(k, nslots - 1);
-          const double xv = load_fixed(xrow + gcp[(int64_t)kc * 64], fill);   // padding repeats a valid column
-          const double p = vp[(int64_t)kc * 64] * xv;
-          const double sum = acc + p;
-          acc = (k < len) ? sum : acc;
+        // eight slots at a time: their column / weight loads, then the eight gathers, are in flight
+        // together (a load per link in front of its gather would serialise the round trips)
+        for (int k0 = 0; k0 < wmax; k0 += 8) {
+          int32_t gc[8];
+          double wv[8], xv[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int kc = min(k0 + q, nslots - 1);   // padding repeats a valid column
+            gc[q] = gcp[(int64_t)kc * 64];
+            wv[q] = vp[(int64_t)kc * 64];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) xv[q] = load_fixed(xrow + gc[q], fill);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const double p = wv[q] * xv[q];
+            const double sum = acc + p;
+            acc = (k0 + q < len) ? sum : acc;
+          }
         }
         if (row_live) {
           YT* __restrict__ yrow = (YT*)a.y + ywd.off;
@@ -483,15 +495,24 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             }
           }
         } else {
-#pragma unroll 4
-          for (int k = 0; k < wmax; ++k) {
-            const int kc = min(k, nslots - 1);
-            const bool on = k < len;
-            const int32_t li = cp[(int64_t)kc * 64];
-            const double xv = load_fixed(lds_x + (on ? li : 0), fill);
-            const double p = vp[(int64_t)kc * 64] * xv;
-            const double sum = acc + p;
-            acc = on ? sum : acc;
+          // rows longer than 48 links: links streamed from L2, eight slots per round trip
+          for (int k0 = 0; k0 < wmax; k0 += 8) {
+            int32_t li[8];
+            double wv[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int kc = min(k0 + q, nslots - 1);
+              li[q] = cp[(int64_t)kc * 64];
+              wv[q] = vp[(int64_t)kc * 64];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xv[q] = load_fixed(lds_x + (k0 + q < len ? li[q] : 0), fill);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const double p = wv[q] * xv[q];
+              const double sum = acc + p;
+              acc = (k0 + q < len) ? sum : acc;
+            }
           }
         }
         pend_out = (YT)epilogue(acc, dead);
