@@ -36,5 +36,13 @@ for seed in range(n):
                 bad += 1; print("MISMATCH seed", seed, "flags", fl, "rep", rep, flush=True)
     op.close()
     if seed % 50 == 49: print(f"{seed+1} cases, {bad} mismatches, {time.time()-t0:.0f}s", flush=True)
-print("soak done:", n, "cases,", bad, "mismatches")
+# level groups (grouped launch, both Y layouts, host pipeline): the fuzz test body on many more seeds
+from tests.test_gpu_fuzz import test_fuzz_levels
+n_groups = max(1, n // 4)
+for seed in range(100, 100 + n_groups):
+    try:
+        test_fuzz_levels(_lib, seed)
+    except AssertionError as e:
+        bad += 1; print("GROUP MISMATCH seed", seed, str(e)[:200], flush=True)
+print("soak done:", n, "cases +", n_groups, "level groups,", bad, "mismatches")
 sys.exit(1 if bad else 0)
