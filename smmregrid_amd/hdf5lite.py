@@ -138,6 +138,7 @@ class File:
         """[(type, flags, data_offset, size)] of the object header at addr (all chunks)."""
         b = self.buf
         out = []
+        seen = set()
         if b[addr:addr + 4] == b"OHDR":
             if b[addr + 4] != 2:
                 raise H5Unsupported(f"object header version {b[addr + 4]}")
@@ -162,6 +163,9 @@ class File:
                         caddr, clen = self.addr(p), self.length(p + self.so)
                         if b[caddr:caddr + 4] != b"OCHK":
                             raise H5Error("object header continuation without OCHK signature")
+                        if caddr in seen:
+                            raise H5Error("object header continuation loop")
+                        seen.add(caddr)
                         blocks.append((caddr + 4, clen - 8))   # minus signature and checksum
                     elif mtype != 0:
                         out.append((mtype, mflags, p, msize))
@@ -180,6 +184,9 @@ class File:
                 p += 8
                 nmsg -= 1
                 if mtype == 0x10:
+                    if self.addr(p) in seen:
+                        raise H5Error("object header continuation loop")
+                    seen.add(self.addr(p))
                     blocks.append((self.addr(p), self.length(p + self.so)))
                 elif mtype != 0:
                     out.append((mtype, mflags, p, msize))
@@ -312,6 +319,8 @@ class File:
         out = []
 
         def walk(naddr, nrec, level):
+            if len(out) > 10_000_000:
+                raise H5Error("v2 B-tree larger than any sane index (loop?)")
             sig = b[naddr:naddr + 4]
             if level == 0:
                 if sig != b"BTLF":
@@ -545,7 +554,9 @@ class Group(_Object):
             end = b.find(b"\0", q)
             return bytes(b[q:end]).decode("utf-8", "replace")
 
-        def walk(addr):
+        def walk(addr, depth=0):
+            if depth > 64:
+                raise H5Error("group B-tree deeper than 64 levels (loop?)")
             if b[addr:addr + 4] == b"SNOD":
                 n = f.u(addr + 6, 2)
                 q = addr + 8
@@ -559,7 +570,7 @@ class Group(_Object):
             q = addr + 8 + 2 * f.so
             for _ in range(used):
                 q += f.sl                                # key
-                walk(f.addr(q))
+                walk(f.addr(q), depth + 1)
                 q += f.so
         if btree != UNDEF:
             walk(btree)
@@ -785,9 +796,11 @@ class DatasetNode(_Object):
         out = []
         key = 8 + 8 * nd
 
-        def walk(a):
+        def walk(a, depth=0):
             if b[a:a + 4] != b"TREE" or b[a + 4] != 1:
                 raise H5Error("chunk B-tree node expected")
+            if depth > 64:
+                raise H5Error("chunk B-tree deeper than 64 levels (loop?)")
             level, used = b[a + 5], f.u(a + 6, 2)
             q = a + 8 + 2 * f.so
             for _ in range(used):
@@ -797,7 +810,7 @@ class DatasetNode(_Object):
                 if level == 0:
                     out.append((offs, child, csize, mask))
                 else:
-                    walk(child)
+                    walk(child, depth + 1)
                 q += key + f.so
         walk(addr)
         return out
