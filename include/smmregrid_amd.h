@@ -59,7 +59,7 @@ enum {
 /* smm_apply flags */
 enum {
   SMM_APPLY_MASKED = 1u << 0,   /* apply dst_imask (regrid.py:553-559); per level in a group */
-  SMM_APPLY_NO_FILL = 1u << 1,  /* skip the 1e20 fill (caller guarantees finite X)           */
+  SMM_APPLY_NO_FILL = 1u << 1,  /* skip the 1e20 fill: the caller guarantees finite X (results are undefined otherwise) */
   SMM_APPLY_KERNEL_SELL = 1u << 8, /* force the row-per-lane SELL-64 kernel                  */
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };

@@ -257,14 +257,20 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   const int32_t* __restrict__ cp = L.lcol + soff + lane;   // global pointers on every path
   const double* __restrict__ vp = L.val + soff + lane;
   if (MAXK > 0 && nslots > 0) {  // wave-uniform; loads unconditional, slots past the slice clamp
+    const uint32_t cpad = len > 0 ? (uint32_t)cp[0] : 0u;
 #pragma unroll
     for (int k = 0; k < KREG; k += 2) {
       const int k0 = min(k, nslots - 1), k1 = min(k + 1, nslots - 1);
       const uint32_t c0 = (uint32_t)cp[(int64_t)k0 * 64];
       const uint32_t c1 = (uint32_t)cp[(int64_t)k1 * 64];
-      lc2[k / 2] = (k < len ? c0 : 0u) | ((k + 1 < len ? c1 : 0u) << 16);
-      w[k] = vp[(int64_t)k0 * 64];
-      w[k + 1] = vp[(int64_t)k1 * 64];
+      lc2[k / 2] = (k < len ? c0 : cpad) | ((k + 1 < len ? c1 : cpad) << 16);
+      // Slots past the row's length get weight +0.0 and the LDS index of the row's first link: the
+      // running sum is never -0.0 (it starts at +0.0) and the staged value is finite after the fill,
+      // so acc + 0*x == acc bit for bit and the walk loop needs no per-link select.  (Without the
+      // fill, SMM_APPLY_NO_FILL, a NaN there belongs to the row anyway.)
+      const double w0 = vp[(int64_t)k0 * 64], w1 = vp[(int64_t)k1 * 64];
+      w[k] = k < len ? w0 : 0.0;
+      w[k + 1] = k + 1 < len ? w1 : 0.0;
     }
   } else {
 #pragma unroll
@@ -488,8 +494,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                 const int k = k0 + kk;
                 if (k < KREG) {
                   const double p = w[k] * xv[kk];
-                  const double sum = acc + p;
-                  acc = (k < len) ? sum : acc;
+                  acc = acc + p;
                 }
               }
             }
@@ -515,6 +520,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             }
           }
         }
+        if (MAXK > 0) acc = len > 0 ? acc : 0.0;   // a row without links never looks at the tile
         pend_out = (YT)epilogue(acc, dead);
         pend_off = yw.off;
         if (!kDeferStore && row_live) flush_pending();
@@ -636,8 +642,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                   const int k = k0 + kk;
                   if (k < KREG) {
                     const double p = w[k] * xv[kk];
-                    const double sum = acc + p;
-                    acc = (k < len) ? sum : acc;
+                    acc = acc + p;
                   }
                 }
               }
@@ -654,6 +659,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
               acc = on ? sum : acc;
             }
           }
+          if (MAXK > 0) acc = len > 0 ? acc : 0.0;   // a row without links never looks at the tile
           pend_out = (YT)epilogue(acc, dead);
           pend_off = yw.off;
           if (!kDeferStore && row_live && jb + r < j_end) flush_pending();
