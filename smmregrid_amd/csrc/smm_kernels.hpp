@@ -151,22 +151,25 @@ __global__ __launch_bounds__(kThreads) void smm_apply_sell_kernel(ApplyArgs a, b
 #pragma unroll
   for (int t = 0; t < BT; ++t) acc[t] = 0.0;
 
-  // Padded slots carry a valid column (the row's last one) and are masked out of the
-  // sum by a select, so the loop body is branch-free and two slots are in flight.
+  // Padded slots carry a valid column (the row's last one) and weight +0.0: the running sum is
+  // never -0.0 and the gathered value is finite after the fill, so acc + 0*x == acc bit for bit --
+  // the loop body is branch- and select-free and two slots are in flight.
 #pragma unroll 2
   for (int k = 0; k < nslots; ++k) {
     const int32_t c = cp[(int64_t)k * 64];
     const double w = vp[(int64_t)k * 64];
-    const bool on = k < len;
     double xv[BT];
 #pragma unroll
     for (int t = 0; t < BT; ++t) xv[t] = load_fixed(xr[t] + c, fill);
 #pragma unroll
     for (int t = 0; t < BT; ++t) {
       const double p = w * xv[t];
-      const double s = acc[t] + p;
-      acc[t] = on ? s : acc[t];
+      acc[t] = acc[t] + p;
     }
+  }
+  if (len == 0) {  // a row without links never looks at X (its padded slots read column 0)
+#pragma unroll
+    for (int t = 0; t < BT; ++t) acc[t] = 0.0;
   }
 
   if (d < a.n_dst) {
