@@ -160,7 +160,9 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask,
  */
 int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask);
 
-/* kernel selection the library made for this operator: 0 = SELL row-per-lane, 1 = LDS tile */
+/* kernel selection the library made for this operator -- kernel_kind bit 0: an LDS tile plan
+ * exists, bit 1: it is the default kernel (else SELL row-per-lane), bits 8..: destination rows
+ * per block of the plan (256, 64, or 32 / 16 / 8 for rows with very wide footprints) */
 int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
                            int64_t* staged_src_elems);
 

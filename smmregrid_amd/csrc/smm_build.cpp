@@ -189,13 +189,13 @@ void build_sell(const HostCsr& csr, HostSell& out) {
   }
 }
 
-void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_per_block,
+void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_block_,
                      int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan) {
   plan = HostTilePlan();
-  plan.slices_per_block = slices_per_block;
+  plan.rows_per_block = rows_per_block_;
   plan.chunk_elems = chunk_elems;
-  if (csr.n_dst == 0 || slices_per_block <= 0 || chunk_elems <= 0) return;
-  const int64_t rows_per_block = (int64_t)slices_per_block * 64;
+  if (csr.n_dst == 0 || rows_per_block_ <= 0 || chunk_elems <= 0) return;
+  const int64_t rows_per_block = rows_per_block_;
   const int64_t n_blocks = (csr.n_dst + rows_per_block - 1) / rows_per_block;
   plan.n_blocks = n_blocks;
   plan.blk_chunk_off.assign((size_t)n_blocks + 1, 0);
@@ -254,7 +254,7 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_pe
 
 int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_budget) {
   if (!plan.valid || plan.n_blocks == 0) return full_budget;
-  const int64_t rows_per_block = (int64_t)plan.slices_per_block * 64;
+  const int64_t rows_per_block = plan.rows_per_block;
   auto block_links = [&](int64_t b) {
     const int64_t d0 = b * rows_per_block, d1 = std::min(csr.n_dst, d0 + rows_per_block);
     return csr.rowptr[(size_t)d1] - csr.rowptr[(size_t)d0];

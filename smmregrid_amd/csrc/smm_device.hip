@@ -117,6 +117,9 @@ struct HostPipe {
 
 // ------------------------------------------------------------------ handles
 
+constexpr int kNumShapes = 5;
+constexpr int shape_rows(int which) { return which == 0 ? 256 : (64 >> (which - 1)); }
+
 struct smm_operator {
   int device = -1;
   smm::HostCsr csr;
@@ -127,9 +130,10 @@ struct smm_operator {
   int32_t* d_rowlen = nullptr;
   uint8_t* d_imask = nullptr;
   double* d_frac = nullptr;
-  // LDS tile plans: [0] = 4 slices (256 rows) per block, [1] = 1 slice per block (heavy rows).
-  // The operator's own shape is built at create time, the other one on demand when the
-  // operator joins a group of the other shape.
+  // LDS tile plans by block shape: [0] = 4 slices (256 rows) per block, [1] = 1 slice (heavy rows),
+  // [2..4] = 32 / 16 / 8 rows of a slice (rows so long -- high-resolution source, coarse target --
+  // that a whole slice's footprint exceeds the LDS budget).  The operator's own shape is built at
+  // create time, the others on demand when it joins a group of another shape.
   struct TilePlan {
     bool built = false, valid = false;
     int64_t max_chunks = 0, total_chunks = 0;
@@ -139,12 +143,13 @@ struct smm_operator {
     int32_t* d_chunk_src = nullptr;
     int32_t* d_lcol = nullptr;
     uint8_t* d_blk_direct = nullptr;
-  } plan[2];
+  } plan[kNumShapes];
   smm::HostSell sell_shape;  // slice_off / rowlen only (col/val dropped after upload)
   std::mutex plan_mu;
   std::mutex pipe_mu;        // smm_apply_host calls on one operator take turns
   HostPipe pipe;
-  int native_plan() const { return csr.max_row_nnz > 16 ? 1 : 0; }
+  int native = 0;            // shape of the operator's own plan (choose_native_plan)
+  int native_plan() const { return native; }
   LevelDesc* d_desc = nullptr;  // one-element device copy (native plan)
   LevelDesc desc(int which) const {
     LevelDesc L;
@@ -239,11 +244,11 @@ int ensure_plan(smm_operator* op, int which) {
   std::lock_guard<std::mutex> lock(op->plan_mu);
   smm_operator::TilePlan& pl = op->plan[which];
   if (pl.built) return SMM_OK;
-  const int spb = which ? 1 : kWavesPerBlock;
   smm::HostTilePlan hp;
-  // LDS / staging-register budget per destination row is the same for both block shapes
-  const int64_t budget = kTileMaxChunks * spb / kWavesPerBlock;
-  smm::build_tile_plan(op->csr, op->sell_shape, spb, kChunkElems, budget, hp);
+  // LDS / staging-register budget: 64 KiB per 4-wave block, 16 KiB per single-wave block (whatever
+  // part of the slice's rows it owns)
+  const int64_t budget = which == 0 ? kTileMaxChunks : kTileMaxChunks / kWavesPerBlock;
+  smm::build_tile_plan(op->csr, op->sell_shape, shape_rows(which), kChunkElems, budget, hp);
   smm::tighten_tile_plan(op->csr, hp, budget);
   pl.built = true;
   if (!hp.valid) return SMM_OK;
@@ -426,8 +431,9 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
        ? (y_dtype == SMM_F64 ? FN<double, double>(__VA_ARGS__) : FN<double, float>(__VA_ARGS__)) \
        : (y_dtype == SMM_F64 ? FN<float, double>(__VA_ARGS__) : FN<float, float>(__VA_ARGS__)))
   if (use_tile) {
-    const int64_t spb = tile_which ? 1 : kWavesPerBlock;  // slices per block of the tile plan
-    a.n_dblocks = ((n_dst + 63) / 64 + spb - 1) / spb;
+    const int64_t rows = shape_rows(tile_which);          // destination rows per block of the tile plan
+    a.n_dblocks = (n_dst + rows - 1) / rows;
+    a.sub_shift = tile_which >= 2 ? tile_which - 1 : 0;   // block = 1 / 2^sub_shift of a slice
   }
   if (use_tile)
     return SMM_DISPATCH(launch_tile, a, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_reuse, fill, flags, s);
@@ -671,9 +677,33 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr) {
     op->sell_shape.n_slots = sell.n_slots;
     op->sell_shape.slice_off = std::move(sell.slice_off);
     op->sell_shape.rowlen = std::move(sell.rowlen);
-    if ((rc = ensure_plan(op, op->native_plan()))) {
+    // own block shape: 256 rows for rows of <= 16 links; else one slice, or the largest part of a
+    // slice whose footprint fits the LDS budget and is used well enough (plan valid and preferred)
+    op->native = op->csr.max_row_nnz > 16 ? 1 : 0;
+    if ((rc = ensure_plan(op, op->native))) {
       release(op);
       return rc;
+    }
+    if (op->native == 1) {
+      for (int w = 1; w < kNumShapes; ++w) {
+        if ((rc = ensure_plan(op, w))) {
+          release(op);
+          return rc;
+        }
+        if (op->plan[w].valid && op->plan[w].preferred) {
+          op->native = w;
+          break;
+        }
+      }
+      for (int w = 1; w < kNumShapes; ++w) {   // plans tried on the way are rebuilt on demand
+        if (w == op->native) continue;
+        smm_operator::TilePlan& pl = op->plan[w];
+        (void)hipFree(pl.d_blk_chunk_off);
+        (void)hipFree(pl.d_chunk_src);
+        (void)hipFree(pl.d_lcol);
+        (void)hipFree(pl.d_blk_direct);
+        pl = smm_operator::TilePlan();
+      }
     }
     if ((rc = refresh_desc(op))) {
       release(op);
@@ -756,7 +786,8 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
                            int64_t* staged_src_elems) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   const smm_operator::TilePlan& pl = op->plan[op->native_plan()];
-  if (kernel_kind) *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0);
+  if (kernel_kind)
+    *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0) | (shape_rows(op->native_plan()) << 8);
   if (lds_bytes) *lds_bytes = pl.valid ? pl.max_chunks * kChunkElems * 8 : 0;
   if (staged_src_elems) *staged_src_elems = pl.valid ? pl.total_chunks * kChunkElems : 0;
   return SMM_OK;
@@ -944,7 +975,7 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
   g->tile_valid = true;
   // one launch covers all levels: one plan shape for all members (single-wave blocks as soon as
   // any level has rows longer than 16 links), and the links' majority decides tile vs SELL
-  for (int i = 0; i < n_ops; ++i) g->tile_which = g->tile_which || ops[i]->native_plan();
+  for (int i = 0; i < n_ops; ++i) g->tile_which = std::max(g->tile_which, ops[i]->native_plan());
   DeviceGuard guard(g->device);
   if (!guard.ok) {
     delete g;
@@ -980,7 +1011,7 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
 int smm_group_plan_info(smm_group_t g, int* kernel_kind, int* slices_per_block) {
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   if (kernel_kind) *kernel_kind = (g->tile_valid ? 1 : 0) | (g->tile_preferred ? 2 : 0);
-  if (slices_per_block) *slices_per_block = g->tile_which ? 1 : kWavesPerBlock;
+  if (slices_per_block) *slices_per_block = g->tile_which ? 1 : kWavesPerBlock;   // 1 also for parts of a slice
   return SMM_OK;
 }
 

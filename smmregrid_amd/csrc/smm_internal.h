@@ -45,7 +45,8 @@ bool adopt_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_
 void build_sell(const HostCsr& csr, HostSell& out);
 
 // Source-tile plan for the LDS-staged kernel.  Destination rows are grouped in
-// blocks of `slices_per_block` SELL slices; the distinct source cells a block
+// blocks of `rows_per_block` consecutive rows (4 SELL slices, 1 slice, or 1/2, 1/4, 1/8 of a slice
+// for rows whose footprint is wide); the distinct source cells a block
 // references are covered by aligned chunks of `chunk_elems` source elements
 // (one chunk = one 128-B line of f64).  The kernel copies a block's chunks to
 // LDS in list order with 16-B-per-lane coalesced loads, so LDS element
@@ -53,7 +54,7 @@ void build_sell(const HostCsr& csr, HostSell& out);
 // the block's links address LDS through lcol.
 struct HostTilePlan {
   bool valid = false;
-  int32_t slices_per_block = 0;
+  int32_t rows_per_block = 0;
   int32_t chunk_elems = 0;
   int64_t n_blocks = 0;
   int64_t max_block_chunks = 0;       // largest chunk count of any block
@@ -73,7 +74,7 @@ struct HostTilePlan {
 // leaves at most 1 % of the links in over-budget blocks, marks those blocks direct and drops their
 // chunk lists.  Returns the budget in force (full_budget when nothing changed).
 int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_budget);
-void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t slices_per_block,
+void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_block,
                      int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan);
 
 }  // namespace smm

@@ -57,6 +57,7 @@ struct ApplyArgs {
   int xcd_remap;     // tile kernel: > 0 = length of the runs of consecutive blocks given to one XCD
   int64_t n_blocks;  // grid size (for the remap)
   int tile_bytes;    // tile kernel with R > 1: LDS bytes of one batch row's tile
+  int sub_shift;     // single-wave tile kernel: a block owns 64 >> sub_shift rows of its slice
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
@@ -240,9 +241,12 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   const int di = a.lev_map ? a.lev_map[l] : 0;
   const LevelDesc L = a.descs[di];
 
-  const int64_t slice = db * WPB + wave;
+  // 4-wave blocks own 4 slices; single-wave blocks own a slice or the 64 >> sub_shift rows of it
+  // whose lanes are `sub` (the other lanes idle: len 0, no store)
+  const int64_t slice = WPB == 1 ? (db >> a.sub_shift) : db * WPB + wave;
+  const bool in_blk = WPB != 1 || (lane >> (6 - a.sub_shift)) == (int)(db & ((1 << a.sub_shift) - 1));
   const int64_t d = slice * 64 + lane;
-  const bool row_live = d < a.n_dst;
+  const bool row_live = in_blk && d < a.n_dst;
   const bool slice_live = slice * 64 < a.n_dst;
 
   // MAXK > 0: the row's links live in registers across batch rows (LDS indices are
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   if (slice_live) {
     soff = L.slice_off[slice];
     nslots = (int)((L.slice_off[slice + 1] - soff) >> 6);
-    len = L.rowlen[d];
+    len = in_blk ? L.rowlen[d] : 0;
   }
   const int32_t* __restrict__ cp = L.lcol + soff + lane;   // global pointers on every path
   const double* __restrict__ vp = L.val + soff + lane;

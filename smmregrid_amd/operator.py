@@ -124,7 +124,7 @@ class SparseOperator:
         _lib.call("smm_operator_plan_info", self.handle, ctypes.byref(kind), ctypes.byref(lds),
                   ctypes.byref(staged))
         return {"tile_plan": bool(kind.value & 1), "tile_preferred": bool(kind.value & 2),
-                "lds_bytes": lds.value, "staged_src_elems": staged.value}
+                "lds_bytes": lds.value, "staged_src_elems": staged.value, "rows_per_block": kind.value >> 8}
 
     def mask_apply(self, src_imask):
         """weights.py:47-52 on the device: (src_imask . W) < 0.5 ? 0 : 1."""

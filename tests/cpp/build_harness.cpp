@@ -51,14 +51,15 @@ int main() {
     }
   }
   // both tile-plan shapes: every link's LDS index must resolve to its source column
-  for (int spb : {4, 1}) {
+  for (int rows : {256, 64, 16}) {
+    const int spb = rows / 64;   // 0 for the sub-slice shape
     smm::HostTilePlan plan;
-    const int64_t budget = 512 * spb / 4;
-    smm::build_tile_plan(csr, sell, spb, 16, budget, plan);
+    const int64_t budget = rows == 256 ? 512 : 128;
+    smm::build_tile_plan(csr, sell, rows, 16, budget, plan);
     auto check_plan = [&](int64_t limit) {
       long long pbad = 0;
       if (!plan.valid) return pbad;
-      const int64_t rows_per_block = (int64_t)spb * 64;
+      const int64_t rows_per_block = rows;
       int64_t direct_links = 0;
       for (int64_t b = 0; b < plan.n_blocks; ++b) {
         const int64_t nch = plan.blk_chunk_off[(size_t)b + 1] - plan.blk_chunk_off[(size_t)b];

@@ -75,9 +75,9 @@ def test_builder_under_sanitizers(harness, rng, case):
     got = np.array([float(v) for v in lines[3].split()])
     assert np.array_equal(got.view(np.uint64), ref_c.view(np.uint64))
     plans = [ln.split() for ln in lines if ln.startswith("PLAN")]
-    assert len(plans) == 2 and all(p[-1] == "0" for p in plans)          # every LDS index resolves
+    assert len(plans) == 3 and all(p[-1] == "0" for p in plans)          # every LDS index resolves
     tight = [ln.split() for ln in lines if ln.startswith("TIGHT")]
-    assert len(tight) == 2 and all(t[-1] == "0" for t in tight)          # ... also after tighten_tile_plan
+    assert len(tight) == 3 and all(t[-1] == "0" for t in tight)          # ... also after tighten_tile_plan
     assert lines[-1] == "SELLBAD 0"
     if case == "few_wide_blocks":
         t4 = [t for t in tight if t[1] == "4"][0]

@@ -1,0 +1,56 @@
+"""Rows with very wide source footprints (high-resolution source, coarse target: ~100 links per
+row, 10 source rows under every destination cell): a whole 64-row slice no longer fits the LDS
+budget, so the tile plan gives a block 32 / 16 / 8 rows of the slice."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from smmregrid_amd import OperatorGroup, SparseOperator, _lib, gridgen, to_device
+from tests.helpers import assert_same, field
+
+pytestmark = pytest.mark.gpu
+
+
+def build(sgrid, tgrid, mask=None):
+    w = gridgen.generate_weights(sgrid, tgrid, method="con", src_mask=mask)
+    op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                        w["dst_address"].values, w["remap_matrix"].values, device=0)
+    op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
+    return w, op
+
+
+@pytest.mark.parametrize("sgrid,tgrid", [("r720x360", "r72x36"), ("r1800x900", "r180x90")])
+def test_part_slice_blocks_match_the_oracle(hip, rng, sgrid, tgrid):
+    w, op = build(sgrid, tgrid)
+    info = op.plan_info()
+    assert op.max_row_nnz >= 100
+    assert info["tile_plan"] and info["tile_preferred"] and info["rows_per_block"] in (32, 16, 8), info
+    csr = op.export_csr()
+    imask, frac = w["dst_grid_imask"].values, w["dst_grid_frac"].values
+    for dtype in (np.float64, np.float32):
+        x = field(rng, 13, op.n_src, dtype=dtype, nan_frac=0.01)
+        ref = oracle.apply_c(csr, x, True, imask, frac, 0.5)
+        t = _lib.APPLY_KERNEL_TILE
+        for fl in (0, t, t | (6 << 16), t | (5 << 20), _lib.APPLY_KERNEL_SELL):
+            assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.5, flags=fl).to_host(), ref, exact=True)
+    assert_same(op.apply_host(x, masked=True, remap_area_min=0.5), ref, exact=True)
+
+
+def test_group_of_part_slice_and_full_slice_operators(hip, rng):
+    """Levels with different native block shapes share the most finely split one."""
+    nx, ny = 720, 360
+    mask = (rng.random(nx * ny) > 0.4).astype(np.int32)
+    w0, op0 = build("r720x360", "r72x36")
+    w1, op1 = build("r720x360", "r72x36", mask=mask)
+    grp = OperatorGroup([op0, op1])
+    assert grp.plan_info()["tile_plan"]
+    x = field(rng, 3 * 2 * 2, op0.n_src, nan_frac=0.02).reshape(3, 2, 2, op0.n_src)
+    level_index = np.array([1, 0], dtype=np.int32)
+    masked_levels = np.array([1, 1], dtype=np.uint8)
+    imask = np.stack([w0["dst_grid_imask"].values, w1["dst_grid_imask"].values])
+    frac = np.stack([w0["dst_grid_frac"].values, w1["dst_grid_frac"].values])
+    ref = oracle.apply_levels([op0.export_csr(), op1.export_csr()], x, 1, level_index, masked_levels.astype(bool),
+                              imask, frac, 0.5, True)
+    for fl in (0, _lib.APPLY_KERNEL_TILE, _lib.APPLY_KERNEL_SELL):
+        y = grp.apply(to_device(x), level_index, masked_levels, masked=True, remap_area_min=0.5, flags=fl).to_host()
+        assert_same(y, ref, exact=True)
