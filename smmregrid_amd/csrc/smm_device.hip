@@ -139,6 +139,7 @@ struct smm_operator {
     int64_t max_chunks = 0, total_chunks = 0;
     bool preferred = false;  // staged lines are used well enough to beat direct gathers
     bool reuse = false;      // some staged lines are shared by several blocks (keep them cacheable)
+    bool no_direct = false;  // every block is staged (the split-row kernel has no direct path)
     int64_t* d_blk_chunk_off = nullptr;
     int32_t* d_chunk_src = nullptr;
     int32_t* d_lcol = nullptr;
@@ -175,6 +176,7 @@ struct smm_group {
   bool tile_valid = false;
   bool tile_preferred = false;
   bool tile_reuse = false;
+  bool tile_no_direct = true;
   int64_t tile_max_chunks = 0;
   int64_t max_row_nnz = 0;
   // uploaded (level_index, masked_levels) configurations, keyed by content
@@ -260,6 +262,7 @@ int ensure_plan(smm_operator* op, int which) {
   pl.max_chunks = hp.max_block_chunks;
   pl.total_chunks = hp.total_chunks;
   pl.reuse = hp.total_chunks * 50 > hp.distinct_chunks * 51;  // > 2 % of lines staged twice
+  pl.no_direct = hp.direct_links == 0;
   // at least a quarter of every staged 128-B line is consumed
   pl.preferred = hp.total_distinct * 4 >= hp.total_chunks * (int64_t)hp.chunk_elems;
   return SMM_OK;
@@ -288,7 +291,7 @@ int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, unsigned flags, hi
 
 template <typename XT, typename YT>
 int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_chunks,
-                int64_t max_row_nnz, bool tile_reuse, bool fill, unsigned flags, hipStream_t s) {
+                int64_t max_row_nnz, int tile_flags, bool fill, unsigned flags, hipStream_t s) {
   ApplyArgs args = a;
   const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
   const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
@@ -330,8 +333,22 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
     SMM_HIP(hipGetLastError());
     return SMM_OK;
   };
+  // Part-of-a-slice blocks: the idle lanes take over parts of the rows (SPLIT kernels) when every
+  // block is staged and a lane group's share fits the link registers (variant 15: off, for A/B runs).
+  const int n_grp = 1 << args.sub_shift;
+  const bool split = args.sub_shift > 0 && (tile_flags & 2) && variant != 15 &&
+                     max_row_nnz <= (int64_t)n_grp * 48 && a.n_src * sizeof(XT) >= 16;
+  const int64_t per_grp = (max_row_nnz + n_grp - 1) / n_grp;
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
+    if constexpr (MAXK == 32 || MAXK == 48) {
+      if (split) {
+        hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, true>),
+                           dim3((unsigned)total), dim3(64), lds, s, args, fill);
+        SMM_HIP(hipGetLastError());
+        return SMM_OK;
+      }
+    }
     if constexpr (MAXK > 0 && MAXK <= 16) {
       if (rows == 4) return go3(k_tag, std::integral_constant<int, 1>(), nt_tag, std::integral_constant<int, 4>());
       if (rows == 2) return go3(k_tag, std::integral_constant<int, 2>(), nt_tag, std::integral_constant<int, 2>());
@@ -345,6 +362,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
       return fn(std::integral_constant<int, 16>());
     }
     if (variant == 14) return fn(std::integral_constant<int, 0>());  // tuning: stream the links
+    if (split) return per_grp <= 32 ? fn(std::integral_constant<int, 32>()) : fn(std::integral_constant<int, 48>());
     if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
     if (max_row_nnz <= 48) return fn(std::integral_constant<int, 48>());
     return fn(std::integral_constant<int, 0>());  // longer rows: links streamed from L2
@@ -353,6 +371,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
     return fail(SMM_ERR_UNSUPPORTED, "tile plan exceeds the staging register budget");
   // variant 0: X loads non-temporal only if no staged line is shared between blocks
   // (tile_reuse false), Y stores always non-temporal; 2: none; 3: both; 4: stores; 5: loads
+  const bool tile_reuse = tile_flags & 1;
   int nt = tile_reuse ? 2 : 3;
   if (variant == 2) nt = 0;
   if (variant == 3) nt = 3;
@@ -377,7 +396,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
 // Common launch path for a single operator (descs = op->d_desc) or a group.
 int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t* d_lev_masked,
               int64_t n_src, int64_t n_dst, int tile_which, bool tile_ok, bool tile_preferred,
-              bool tile_reuse, int64_t tile_max_chunks,
+              int tile_flags, int64_t tile_max_chunks,
               int64_t max_row_nnz, const void* x, int x_dtype, int64_t xs_o, int64_t xs_l,
               int64_t xs_i, void* y, int y_dtype, int64_t ys_o, int64_t ys_l, int64_t ys_i,
               int64_t n_outer, int64_t n_lev, int64_t n_inner, double area_min, unsigned flags,
@@ -436,7 +455,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
     a.sub_shift = tile_which >= 2 ? tile_which - 1 : 0;   // block = 1 / 2^sub_shift of a slice
   }
   if (use_tile)
-    return SMM_DISPATCH(launch_tile, a, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_reuse, fill, flags, s);
+    return SMM_DISPATCH(launch_tile, a, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_flags, fill, flags, s);
   return SMM_DISPATCH(launch_sell, a, n_lev, fill, flags, s);
 #undef SMM_DISPATCH
 }
@@ -685,14 +704,21 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr) {
       return rc;
     }
     if (op->native == 1) {
-      for (int w = 1; w < kNumShapes; ++w) {
-        if ((rc = ensure_plan(op, w))) {
-          release(op);
-          return rc;
-        }
-        if (op->plan[w].valid && op->plan[w].preferred) {
-          op->native = w;
-          break;
+      // rows beyond 48 links: start at the shape whose lane groups can keep the whole row in
+      // registers (split rows) -- streaming the links from L2 is ~2x slower; else from one slice
+      int w_first = 1;
+      while (w_first < kNumShapes - 1 && op->csr.max_row_nnz > 48ll << (w_first - 1)) ++w_first;
+      bool found = false;
+      for (int pass = 0; pass < 2 && !found; ++pass) {
+        for (int w = pass == 0 ? w_first : 1; w < (pass == 0 ? kNumShapes : w_first) && !found; ++w) {
+          if ((rc = ensure_plan(op, w))) {
+            release(op);
+            return rc;
+          }
+          if (op->plan[w].valid && op->plan[w].preferred) {
+            op->native = w;
+            found = true;
+          }
         }
       }
       for (int w = 1; w < kNumShapes; ++w) {   // plans tried on the way are rebuilt on demand
@@ -807,7 +833,7 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   const int pw = op->native_plan();
   const smm_operator::TilePlan& pl = op->plan[pw];
   return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid,
-                   pl.preferred, pl.reuse, pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
+                   pl.preferred, (pl.reuse ? 1 : 0) | (pl.no_direct ? 2 : 0), pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
 
@@ -892,7 +918,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     }
     const int pw = op->native_plan();
     const smm_operator::TilePlan& pl = op->plan[pw];
-    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, pw, pl.valid, pl.preferred, pl.reuse,
+    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0) | (pl.no_direct ? 2 : 0),
                        pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
                        ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
                        pipe.stream[b]);
@@ -995,6 +1021,7 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
     nnz_all += ops[i]->csr.nnz;
     if (pl.preferred) nnz_pref += ops[i]->csr.nnz;
     g->tile_reuse = g->tile_reuse || pl.reuse;
+    g->tile_no_direct = g->tile_no_direct && pl.no_direct;
     g->tile_max_chunks = std::max(g->tile_max_chunks, pl.max_chunks);
     g->max_row_nnz = std::max(g->max_row_nnz, ops[i]->csr.max_row_nnz);
   }
@@ -1082,7 +1109,7 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
   const uint8_t* d_masked = masked_levels ? (const uint8_t*)d_cfg + map_bytes : nullptr;
   const smm_operator* op0 = g->ops[0];
   return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_which,
-                   g->tile_valid, g->tile_preferred, g->tile_reuse, g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
+                   g->tile_valid, g->tile_preferred, (g->tile_reuse ? 1 : 0) | (g->tile_no_direct ? 2 : 0), g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
 }

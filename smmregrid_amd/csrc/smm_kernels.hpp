@@ -213,10 +213,17 @@ constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPer
 // R > 1 (small tiles only): R batch rows are staged, consumed and stored per barrier pair, each in
 // its own LDS region.  A workgroup whose tile needs one or two pieces per thread is bound by the
 // memory round trip per batch row, not by bandwidth; R rows in flight per workgroup hide it.
-template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1>
+//
+// SPLIT (single-wave blocks of 64 >> sub_shift rows, rows of up to (1 << sub_shift) * MAXK links):
+// the idle lanes take over parts of the rows.  Lane (g, r) keeps links [g*Kg, (g+1)*Kg) of row r in
+// registers; per batch row the G = 1 << sub_shift lane groups run one after the other, each starting
+// from the sum its predecessor handed over (a shuffle), so every row is still accumulated link by
+// link in ascending source order -- bit-identical -- while no link is re-read from L2.
+template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SPLIT = false>
 __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   constexpr int WPB = tile_waves(MAXK);
   constexpr int T = WPB * 64;
+  static_assert(!SPLIT || (WPB == 1 && R == 1 && MAXK > 0), "split rows: single-wave, single-row steps");
   static_assert(R == 1 || (MAXK > 0 && MAXK <= 16), "multi-row steps exist for the 4-wave shape only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -244,9 +251,15 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   // 4-wave blocks own 4 slices; single-wave blocks own a slice or the 64 >> sub_shift rows of it
   // whose lanes are `sub` (the other lanes idle: len 0, no store)
   const int64_t slice = WPB == 1 ? (db >> a.sub_shift) : db * WPB + wave;
-  const bool in_blk = WPB != 1 || (lane >> (6 - a.sub_shift)) == (int)(db & ((1 << a.sub_shift) - 1));
-  const int64_t d = slice * 64 + lane;
-  const bool row_live = in_blk && d < a.n_dst;
+  const int sub = (int)(db & ((1 << a.sub_shift) - 1));
+  const int grp = lane >> (6 - a.sub_shift);            // lane group (SPLIT: part of the row's links)
+  const int n_grp = 1 << a.sub_shift;
+  // lane of the slice whose row this lane works on
+  const int rowlane = SPLIT ? (sub << (6 - a.sub_shift)) + (lane & ((64 >> a.sub_shift) - 1)) : lane;
+  const bool in_blk = SPLIT || WPB != 1 || grp == sub;
+  const int64_t d = slice * 64 + rowlane;
+  // SPLIT: the last lane group ends up with the rows' sums and stores them
+  const bool row_live = in_blk && d < a.n_dst && (!SPLIT || grp == n_grp - 1);
   const bool slice_live = slice * 64 < a.n_dst;
 
   // MAXK > 0: the row's links live in registers across batch rows (LDS indices are
@@ -256,18 +269,27 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   uint32_t lc2[KREG / 2];
   double w[KREG];
   int64_t soff = 0;
+  int first = 0;   // SPLIT: first slot of this lane's part of the row
   if (slice_live) {
     soff = L.slice_off[slice];
     nslots = (int)((L.slice_off[slice + 1] - soff) >> 6);
-    len = in_blk ? L.rowlen[d] : 0;
+    len = (in_blk && d < a.n_dst) ? L.rowlen[d] : 0;
+    if (SPLIT) {
+      int longest = len;   // longest row of the block -> links per lane group (wave-uniform)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off));
+      const int per_grp = (__builtin_amdgcn_readfirstlane(longest) + n_grp - 1) >> a.sub_shift;
+      first = grp * per_grp;
+      len = min(max(len - first, 0), per_grp);
+    }
   }
-  const int32_t* __restrict__ cp = L.lcol + soff + lane;   // global pointers on every path
-  const double* __restrict__ vp = L.val + soff + lane;
+  const int32_t* __restrict__ cp = L.lcol + soff + rowlane;   // global pointers on every path
+  const double* __restrict__ vp = L.val + soff + rowlane;
   if (MAXK > 0 && nslots > 0) {  // wave-uniform; loads unconditional, slots past the slice clamp
-    const uint32_t cpad = len > 0 ? (uint32_t)cp[0] : 0u;
+    const uint32_t cpad = len > 0 ? (uint32_t)cp[(int64_t)min(first, nslots - 1) * 64] : 0u;
 #pragma unroll
     for (int k = 0; k < KREG; k += 2) {
-      const int k0 = min(k, nslots - 1), k1 = min(k + 1, nslots - 1);
+      const int k0 = min(first + k, nslots - 1), k1 = min(first + k + 1, nslots - 1);
       const uint32_t c0 = (uint32_t)cp[(int64_t)k0 * 64];
       const uint32_t c1 = (uint32_t)cp[(int64_t)k1 * 64];
       lc2[k / 2] = (k < len ? c0 : cpad) | ((k + 1 < len ? c1 : cpad) << 16);
@@ -480,10 +502,40 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
 #endif
       if (slice_live) {
         double acc = 0.0;
+        if constexpr (SPLIT) {
+          // lane groups take their turn: group g continues the sums group g-1 handed over
+          const int rows_blk = 64 >> a.sub_shift;
+          for (int g = 0; g < n_grp; ++g) {
+            double t = acc;
+#pragma unroll
+            for (int k0 = 0; k0 < KREG; k0 += 4) {
+              if (k0 < wmax) {
+                double xv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int k = k0 + kk;
+                  const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
+                                              : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
+                  xv[kk] = load_fixed(lds_x + li, fill);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int k = k0 + kk;
+                  if (k < KREG) {
+                    const double p = w[k] * xv[kk];
+                    t = t + p;
+                  }
+                }
+              }
+            }
+            acc = (grp == g && len > 0) ? t : acc;
+            const double handed = __shfl(acc, (lane - rows_blk) & 63);
+            acc = (grp == g + 1) ? handed : acc;
+          }
 #ifdef SMM_EXP_SKIP_COMPUTE
-        if (false) {
+        } else if (false) {
 #else
-        if (MAXK > 0) {
+        } else if (MAXK > 0) {
 #endif
 #pragma unroll
           for (int k0 = 0; k0 < KREG; k0 += 4) {
@@ -527,7 +579,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             }
           }
         }
-        if (MAXK > 0) acc = len > 0 ? acc : 0.0;   // a row without links never looks at the tile
+        if (MAXK > 0 && !SPLIT) acc = len > 0 ? acc : 0.0;   // a row without links never looks at the tile
         pend_out = (YT)epilogue(acc, dead);
         pend_off = yw.off;
         if (!kDeferStore && row_live) flush_pending();

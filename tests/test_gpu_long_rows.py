@@ -31,7 +31,7 @@ def test_part_slice_blocks_match_the_oracle(hip, rng, sgrid, tgrid):
         x = field(rng, 13, op.n_src, dtype=dtype, nan_frac=0.01)
         ref = oracle.apply_c(csr, x, True, imask, frac, 0.5)
         t = _lib.APPLY_KERNEL_TILE
-        for fl in (0, t, t | (6 << 16), t | (5 << 20), _lib.APPLY_KERNEL_SELL):
+        for fl in (0, t, t | (6 << 16), t | (5 << 20), t | (15 << 16), _lib.APPLY_KERNEL_SELL):   # 15: rows not split over lanes
             assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.5, flags=fl).to_host(), ref, exact=True)
     assert_same(op.apply_host(x, masked=True, remap_area_min=0.5), ref, exact=True)
 
@@ -54,3 +54,32 @@ def test_group_of_part_slice_and_full_slice_operators(hip, rng):
     for fl in (0, _lib.APPLY_KERNEL_TILE, _lib.APPLY_KERNEL_SELL):
         y = grp.apply(to_device(x), level_index, masked_levels, masked=True, remap_area_min=0.5, flags=fl).to_host()
         assert_same(y, ref, exact=True)
+
+
+@pytest.mark.parametrize("stride,max_len,want_rows", [(200, 150, 8), (120, 150, 16), (50, 90, 32)])
+def test_split_rows_of_ragged_length(hip, rng, stride, max_len, want_rows):
+    """Rows of very different length (0 .. max_len links, some empty) inside part-of-a-slice blocks:
+    the lane groups' shares follow the block's longest row, shorter rows leave groups empty."""
+    n_dst = 333
+    n_src = n_dst * stride + max_len + 7
+    src, dst, w = [], [], []
+    for d in range(n_dst):
+        n = 0 if d % 11 == 3 else int(rng.integers(1, max_len + 1))
+        cols = d * stride + np.sort(rng.choice(max_len, size=n, replace=False))
+        src.append(cols + 1)
+        dst.append(np.full(n, d + 1))
+        w.append(rng.uniform(-0.3, 1.0, size=n))
+    src, dst, w = (np.concatenate(src).astype(np.int32), np.concatenate(dst).astype(np.int32), np.concatenate(w))
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    info = op.plan_info()
+    assert info["tile_plan"] and info["rows_per_block"] == want_rows, info
+    imask = (rng.random(n_dst) > 0.2).astype(np.int32)
+    frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    csr = op.export_csr()
+    for dtype in (np.float64, np.float32):
+        x = field(rng, 9, n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.002)
+        ref = oracle.apply_c(csr, x, True, imask, frac, 0.4)
+        t = _lib.APPLY_KERNEL_TILE
+        for fl in (0, t, t | (15 << 16), t | (3 << 20), _lib.APPLY_KERNEL_SELL):
+            assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.4, flags=fl).to_host(), ref, exact=True)
