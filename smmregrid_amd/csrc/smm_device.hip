@@ -333,11 +333,10 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
     SMM_HIP(hipGetLastError());
     return SMM_OK;
   };
-  // Part-of-a-slice blocks: the idle lanes take over parts of the rows (SPLIT kernels) when every
-  // block is staged and a lane group's share fits the link registers (variant 15: off, for A/B runs).
+  // Part-of-a-slice blocks: the idle lanes take over parts of the rows (SPLIT kernels) when a lane
+  // group's share fits the link registers (variant 15: off, for A/B runs).
   const int n_grp = 1 << args.sub_shift;
-  const bool split = args.sub_shift > 0 && (tile_flags & 2) && variant != 15 &&
-                     max_row_nnz <= (int64_t)n_grp * 48 && a.n_src * sizeof(XT) >= 16;
+  const bool split = args.sub_shift > 0 && variant != 15 && max_row_nnz <= (int64_t)n_grp * 48;
   const int64_t per_grp = (max_row_nnz + n_grp - 1) / n_grp;
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;

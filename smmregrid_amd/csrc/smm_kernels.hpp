@@ -371,7 +371,26 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     // block's links straight from X (SELL arrays
     // hold the global columns), one batch row at a time; no LDS, no barrier
     if (slice_live) {
+      // this path is row-per-lane; in a SPLIT kernel the lanes of group `sub` take their own rows
+      const int64_t dd = SPLIT ? slice * 64 + lane : d;
+      const bool dlive = SPLIT ? (grp == sub && dd < a.n_dst) : row_live;
+      int dlen = len, dmax = wmax;
+      bool ddead = dead;
+      if (SPLIT) {
+        dlen = dlive ? L.rowlen[dd] : 0;
+        dmax = dlen;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dmax = max(dmax, __shfl_xor(dmax, off));
+        dmax = __builtin_amdgcn_readfirstlane(dmax);
+        ddead = false;
+        if (dlive) {
+          const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
+          if (use_mask && L.imask) ddead = (L.imask[dd] == 0);
+          if (a.area_min > 0.0 && L.frac) ddead = ddead || (L.frac[dd] < a.area_min);
+        }
+      }
       const int32_t* __restrict__ gcp = L.col + soff + lane;
+      const double* __restrict__ gvp = L.val + soff + lane;
       RowWalker xwd(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
       RowWalker ywd(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
       for (int64_t j = j_begin; j < j_end; ++j, xwd.next(), ywd.next()) {
@@ -379,14 +398,14 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
         double acc = 0.0;
         // eight slots at a time: their column / weight loads, then the eight gathers, are in flight
         // together (a load per link in front of its gather would serialise the round trips)
-        for (int k0 = 0; k0 < wmax; k0 += 8) {
+        for (int k0 = 0; k0 < dmax; k0 += 8) {
           int32_t gc[8];
           double wv[8], xv[8];
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             const int kc = min(k0 + q, nslots - 1);   // padding repeats a valid column
             gc[q] = gcp[(int64_t)kc * 64];
-            wv[q] = vp[(int64_t)kc * 64];
+            wv[q] = gvp[(int64_t)kc * 64];
           }
 #pragma unroll
           for (int q = 0; q < 8; ++q) xv[q] = load_fixed(xrow + gc[q], fill);
@@ -394,12 +413,12 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
           for (int q = 0; q < 8; ++q) {
             const double p = wv[q] * xv[q];
             const double sum = acc + p;
-            acc = (k0 + q < len) ? sum : acc;
+            acc = (k0 + q < dlen) ? sum : acc;
           }
         }
-        if (row_live) {
+        if (dlive) {
           YT* __restrict__ yrow = (YT*)a.y + ywd.off;
-          yrow[d] = (YT)epilogue(acc, dead);
+          yrow[dd] = (YT)epilogue(acc, ddead);
         }
       }
     }

@@ -83,3 +83,34 @@ def test_split_rows_of_ragged_length(hip, rng, stride, max_len, want_rows):
         t = _lib.APPLY_KERNEL_TILE
         for fl in (0, t, t | (15 << 16), t | (3 << 20), _lib.APPLY_KERNEL_SELL):
             assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.4, flags=fl).to_host(), ref, exact=True)
+
+
+def test_split_kernel_with_direct_blocks(hip, rng):
+    """One 16-row block whose links scatter over the whole source (beyond the LDS budget even for
+    part-of-a-slice blocks) is gathered directly inside the split-row kernel."""
+    stride, max_len, n_dst = 120, 150, 400
+    n_src = n_dst * stride + max_len + 7
+    src, dst, w = [], [], []
+    for d in range(n_dst):
+        n = int(rng.integers(1, max_len + 1))
+        if 160 <= d < 176:                                     # the scattered block
+            cols = np.sort(rng.choice(n_src, size=n, replace=False))
+        else:
+            cols = d * stride + np.sort(rng.choice(max_len, size=n, replace=False))
+        src.append(cols + 1)
+        dst.append(np.full(n, d + 1))
+        w.append(rng.uniform(-0.3, 1.0, size=n))
+    src, dst, w = (np.concatenate(src).astype(np.int32), np.concatenate(dst).astype(np.int32), np.concatenate(w))
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    info = op.plan_info()
+    assert info["tile_plan"] and info["rows_per_block"] == 16, info
+    imask = (rng.random(n_dst) > 0.2).astype(np.int32)
+    frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    csr = op.export_csr()
+    for dtype in (np.float64, np.float32):
+        x = field(rng, 7, n_src, dtype=dtype, nan_frac=0.02)
+        ref = oracle.apply_c(csr, x, True, imask, frac, 0.4)
+        t = _lib.APPLY_KERNEL_TILE
+        for fl in (0, t, t | (15 << 16), _lib.APPLY_KERNEL_SELL):
+            assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.4, flags=fl).to_host(), ref, exact=True)
