@@ -139,7 +139,6 @@ struct smm_operator {
     int64_t max_chunks = 0, total_chunks = 0;
     bool preferred = false;  // staged lines are used well enough to beat direct gathers
     bool reuse = false;      // some staged lines are shared by several blocks (keep them cacheable)
-    bool no_direct = false;  // every block is staged (the split-row kernel has no direct path)
     int64_t* d_blk_chunk_off = nullptr;
     int32_t* d_chunk_src = nullptr;
     int32_t* d_lcol = nullptr;
@@ -176,7 +175,6 @@ struct smm_group {
   bool tile_valid = false;
   bool tile_preferred = false;
   bool tile_reuse = false;
-  bool tile_no_direct = true;
   int64_t tile_max_chunks = 0;
   int64_t max_row_nnz = 0;
   // uploaded (level_index, masked_levels) configurations, keyed by content
@@ -262,7 +260,6 @@ int ensure_plan(smm_operator* op, int which) {
   pl.max_chunks = hp.max_block_chunks;
   pl.total_chunks = hp.total_chunks;
   pl.reuse = hp.total_chunks * 50 > hp.distinct_chunks * 51;  // > 2 % of lines staged twice
-  pl.no_direct = hp.direct_links == 0;
   // at least a quarter of every staged 128-B line is consumed
   pl.preferred = hp.total_distinct * 4 >= hp.total_chunks * (int64_t)hp.chunk_elems;
   return SMM_OK;
@@ -832,7 +829,7 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   const int pw = op->native_plan();
   const smm_operator::TilePlan& pl = op->plan[pw];
   return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid,
-                   pl.preferred, (pl.reuse ? 1 : 0) | (pl.no_direct ? 2 : 0), pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
+                   pl.preferred, (pl.reuse ? 1 : 0), pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
 
@@ -917,7 +914,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     }
     const int pw = op->native_plan();
     const smm_operator::TilePlan& pl = op->plan[pw];
-    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0) | (pl.no_direct ? 2 : 0),
+    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
                        pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
                        ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
                        pipe.stream[b]);
@@ -1020,7 +1017,6 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
     nnz_all += ops[i]->csr.nnz;
     if (pl.preferred) nnz_pref += ops[i]->csr.nnz;
     g->tile_reuse = g->tile_reuse || pl.reuse;
-    g->tile_no_direct = g->tile_no_direct && pl.no_direct;
     g->tile_max_chunks = std::max(g->tile_max_chunks, pl.max_chunks);
     g->max_row_nnz = std::max(g->max_row_nnz, ops[i]->csr.max_row_nnz);
   }
@@ -1108,7 +1104,7 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
   const uint8_t* d_masked = masked_levels ? (const uint8_t*)d_cfg + map_bytes : nullptr;
   const smm_operator* op0 = g->ops[0];
   return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_which,
-                   g->tile_valid, g->tile_preferred, (g->tile_reuse ? 1 : 0) | (g->tile_no_direct ? 2 : 0), g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
+                   g->tile_valid, g->tile_preferred, (g->tile_reuse ? 1 : 0), g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
 }
