@@ -66,7 +66,7 @@ enum {
 /* tuning knobs for benchmarks (0 = library default; results are identical for every value):
  * kernel variant in bits 16..19 -- tile kernel: 2..5 cache policy of X loads / Y stores,
  * 6 dispatcher block order instead of runs of 32 consecutive blocks per XCD (7 / 13: runs of
- * 8 / 128), 12 single-row steps on small tiles; SELL kernel: 1 / 2 = 4 / 2 batch rows per thread -- and the batch rows walked per
+ * 8 / 128), 12 single-row steps on small tiles; SELL kernel: 1 / 2 = 8 / 2 batch rows per thread -- and the batch rows walked per
  * workgroup of the tile kernel in bits 20..27 */
 #define SMM_APPLY_VARIANT_SHIFT 16
 #define SMM_APPLY_JPB_SHIFT 20
