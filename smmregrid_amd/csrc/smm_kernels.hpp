@@ -20,7 +20,8 @@
 
 #pragma clang fp contract(off)
 
-namespace {
+// argument structs: external linkage (they appear in the launch templates' signatures, which are
+// instantiated in separate translation units)
 
 // ------------------------------------------------------------------ device structs
 
@@ -59,6 +60,8 @@ struct ApplyArgs {
   int tile_bytes;    // tile kernel with R > 1: LDS bytes of one batch row's tile
   int sub_shift;     // single-wave tile kernel: a block owns 64 >> sub_shift rows of its slice
 };
+
+namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
 constexpr int kWavesPerBlock = 4;

@@ -1,0 +1,158 @@
+// Kernel launch templates, one explicit instantiation per (X dtype, Y dtype) pair
+// (smm_launch_inst.hip is compiled four times, in parallel): the tile kernel alone has several
+// hundred instantiations, which one translation unit would compile for minutes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <type_traits>
+
+#include "../../include/smmregrid_amd.h"
+#include "smm_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace smm {
+int fail_msg(int code, const std::string& msg);   // sets the thread-local error text (smm_device.hip)
+}
+
+namespace smm_launch {
+
+#define SMM_LAUNCH_HIP(call)                                                              \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (void)hipGetLastError();                                                            \
+      return smm::fail_msg(SMM_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    }                                                                                     \
+  } while (0)
+
+template <typename XT, typename YT>
+int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, unsigned flags, hipStream_t s) {
+  ApplyArgs args = a;
+  auto go = [&](auto bt_tag) -> int {
+    constexpr int BT = decltype(bt_tag)::value;
+    args.n_jtiles = (a.n_j + BT - 1) / BT;
+    const int64_t total = args.n_dblocks * args.n_jtiles * n_lev;
+    if (total <= 0) return SMM_OK;
+    if (total > 0x7fffffffLL) return smm::fail_msg(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
+    hipLaunchKernelGGL((smm_apply_sell_kernel<XT, YT, BT>), dim3((unsigned)total), dim3(kThreads), 0,
+                       s, args, fill);
+    SMM_LAUNCH_HIP(hipGetLastError());
+    return SMM_OK;
+  };
+  // batch rows per thread: 4 (gather-bound operators want many waves in flight: scatter -3 %,
+  // config 2 -1 % against 8); tuning variant 1 -> 8 rows, 2 -> 2 rows
+  const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
+  if (a.n_j >= 8 && variant == 1) return go(std::integral_constant<int, 8>());
+  if (a.n_j >= 4 && variant <= 1) return go(std::integral_constant<int, 4>());
+  if (a.n_j >= 2) return go(std::integral_constant<int, 2>());
+  return go(std::integral_constant<int, 1>());
+}
+
+template <typename XT, typename YT>
+int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_chunks,
+                int64_t max_row_nnz, int tile_flags, bool fill, unsigned flags, hipStream_t s) {
+  ApplyArgs args = a;
+  const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
+  const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
+  // Batch rows walked per workgroup: the prologue (links -> registers) is amortised over
+  // them, so heavier rows want longer walks; keep >= ~4096 workgroups to fill 256 CUs.
+  // An operator that does not stay in L2 (links x 12 B beyond ~32 MB) is re-read from HBM by every
+  // walk: amortise it over long walks whatever the row length.
+  const bool big_operator = a.n_dst * std::max<int64_t>(max_row_nnz, 1) * 12 > (32ll << 20);
+  int64_t walk = jpb ? (int64_t)jpb : (big_operator ? 128 : (max_row_nnz <= 4 ? 4 : 64));
+  if (!jpb)
+    while (walk > 1 && a.n_dblocks * ((a.n_j + walk - 1) / walk) * n_lev < 4096) walk /= 2;
+  args.j_per_block = (int)std::min<int64_t>(a.n_j, walk);
+  args.n_jtiles = (a.n_j + args.j_per_block - 1) / args.j_per_block;
+  const int64_t total = args.n_dblocks * args.n_jtiles * n_lev;
+  if (total <= 0) return SMM_OK;
+  if (total > 0x7fffffffLL) return smm::fail_msg(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
+  args.n_blocks = total;
+  // runs of 32 consecutive blocks per XCD (variant 6: dispatcher order, 7 / 13: runs of 8 / 128)
+  args.xcd_remap = variant == 6 ? 0 : (variant == 7 ? 8 : (variant == 13 ? 128 : 32));
+  const size_t tile = (size_t)max_chunks * kChunkElems * sizeof(XT);
+  const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
+  const int threads = (tile_which ? 1 : kWavesPerBlock) * 64;  // == tile_waves(MAXK) * 64
+  const int np_needed = (int)((max_pieces + threads - 1) / threads);
+  // Small tiles (one or two 16-B pieces per thread, 4-wave shape): a step of 4 / 2 batch rows per
+  // barrier pair keeps as many bytes in flight as a full tile would (variant 12: off, for A/B runs).
+  int rows = 1;
+  if (!tile_which && variant != 12) rows = np_needed <= 1 ? 4 : (np_needed <= 2 ? 2 : 1);
+  while (rows > 1 && rows > args.j_per_block) rows /= 2;
+  args.tile_bytes = (int)tile;
+  const size_t lds = tile * (size_t)rows;
+
+  auto go3 = [&](auto k_tag, auto np_tag, auto nt_tag, auto r_tag) -> int {
+    constexpr int MAXK = decltype(k_tag)::value;
+    constexpr int NP = decltype(np_tag)::value;
+    constexpr int NT = decltype(nt_tag)::value;
+    constexpr int R = decltype(r_tag)::value;
+    hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NP, NT, R>), dim3((unsigned)total),
+                       dim3(tile_waves(MAXK) * 64), lds, s, args, fill);
+    SMM_LAUNCH_HIP(hipGetLastError());
+    return SMM_OK;
+  };
+  // Part-of-a-slice blocks: the idle lanes take over parts of the rows (SPLIT kernels) when a lane
+  // group's share fits the link registers (variant 15: off, for A/B runs).
+  const int n_grp = 1 << args.sub_shift;
+  const bool split = args.sub_shift > 0 && variant != 15 && max_row_nnz <= (int64_t)n_grp * 48;
+  const int64_t per_grp = (max_row_nnz + n_grp - 1) / n_grp;
+  auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
+    constexpr int MAXK = decltype(k_tag)::value;
+    if constexpr (MAXK == 32 || MAXK == 48) {
+      if (split) {
+        hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, true>),
+                           dim3((unsigned)total), dim3(64), lds, s, args, fill);
+        SMM_LAUNCH_HIP(hipGetLastError());
+        return SMM_OK;
+      }
+    }
+    if constexpr (MAXK > 0 && MAXK <= 16) {
+      if (rows == 4) return go3(k_tag, std::integral_constant<int, 1>(), nt_tag, std::integral_constant<int, 4>());
+      if (rows == 2) return go3(k_tag, std::integral_constant<int, 2>(), nt_tag, std::integral_constant<int, 2>());
+    }
+    return go3(k_tag, np_tag, nt_tag, std::integral_constant<int, 1>());
+  };
+  auto with_k = [&](auto fn) -> int {  // plan shape 0 <-> MAXK <= 16 (4 waves), shape 1 <-> MAXK >= 32 / 0 (1 wave)
+    if (!tile_which) {
+      if (max_row_nnz <= 4) return fn(std::integral_constant<int, 4>());
+      if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
+      return fn(std::integral_constant<int, 16>());
+    }
+    if (variant == 14) return fn(std::integral_constant<int, 0>());  // tuning: stream the links
+    if (split) return per_grp <= 32 ? fn(std::integral_constant<int, 32>()) : fn(std::integral_constant<int, 48>());
+    if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
+    if (max_row_nnz <= 48) return fn(std::integral_constant<int, 48>());
+    return fn(std::integral_constant<int, 0>());  // longer rows: links streamed from L2
+  };
+  if (np_needed > 16)
+    return smm::fail_msg(SMM_ERR_UNSUPPORTED, "tile plan exceeds the staging register budget");
+  // variant 0: X loads non-temporal only if no staged line is shared between blocks
+  // (tile_reuse false), Y stores always non-temporal; 2: none; 3: both; 4: stores; 5: loads
+  const bool tile_reuse = tile_flags & 1;
+  int nt = tile_reuse ? 2 : 3;
+  if (variant == 2) nt = 0;
+  if (variant == 3) nt = 3;
+  if (variant == 4) nt = 2;
+  if (variant == 5) nt = 1;
+  return with_k([&](auto k_tag) -> int {
+    auto with_nt = [&](auto np_tag) -> int {
+      switch (nt) {
+        case 0: return go2(k_tag, np_tag, std::integral_constant<int, 0>());
+        case 1: return go2(k_tag, np_tag, std::integral_constant<int, 1>());
+        case 2: return go2(k_tag, np_tag, std::integral_constant<int, 2>());
+        default: return go2(k_tag, np_tag, std::integral_constant<int, 3>());
+      }
+    };
+    if (np_needed <= 4) return with_nt(std::integral_constant<int, 4>());
+    if (np_needed <= 8) return with_nt(std::integral_constant<int, 8>());
+    return with_nt(std::integral_constant<int, 16>());
+  });
+}
+
+}  // namespace smm_launch
