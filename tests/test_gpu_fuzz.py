@@ -15,6 +15,22 @@ def make_links(rng, kind, n_src, n_dst):
         return random_links(rng, n_src, n_dst, int(rng.integers(0, 6 * n_dst + 1)), dup_frac=0.1)
     if kind == "ragged":
         return ragged_links(rng, n_src, n_dst, max_len=int(rng.integers(1, 70)))
+    if kind == "longband":
+        # long rows in windows that lie far apart (high-resolution source, coarse target): part-of-a-slice
+        # blocks with rows split over lane groups, ragged lengths, some rows empty
+        stride, max_len = int(rng.integers(10, 220)), int(rng.integers(20, 260))
+        n_src_need = n_dst * stride + max_len + 1
+        src, dst, w = [], [], []
+        for d in range(n_dst):
+            n = 0 if rng.random() < 0.1 else int(rng.integers(1, max_len + 1))
+            cols = (d * stride + np.sort(rng.choice(max_len, size=n, replace=False))) % max(n_src, 1)
+            cols = np.unique(cols)
+            src.append(cols + 1)
+            dst.append(np.full(cols.size, d + 1))
+            w.append(rng.uniform(-0.2, 1.0, size=cols.size))
+        perm = rng.permutation(sum(c.size for c in src))
+        return (np.concatenate(src)[perm].astype(np.int32), np.concatenate(dst)[perm].astype(np.int32),
+                np.concatenate(w)[perm])
     # banded stencil: k consecutive columns per row (structured grids), some rows empty
     k = int(rng.integers(1, 20))
     step = max(1, (n_src - k) // max(n_dst, 1))

@@ -13,20 +13,23 @@ t0 = time.time(); bad = 0
 for seed in range(n):
     rng = np.random.default_rng(900000 + seed)
     n_src = int(rng.integers(1, 20000)); n_dst = int(rng.integers(1, 5000))
-    src, dst, w = make_links(rng, ["random", "ragged", "banded"][seed % 3], n_src, n_dst)
+    kind = ["random", "ragged", "banded", "longband"][seed % 4]
+    if kind == "longband":
+        n_src, n_dst = int(rng.integers(5000, 200000)), int(rng.integers(1, 900))
+    src, dst, w = make_links(rng, kind, n_src, n_dst)
     op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
     csr = op.export_csr()
     imask = (rng.random(n_dst) > 0.3).astype(np.int32); frac = rng.random(n_dst)
     op.set_epilogue(imask, frac)
-    dtype = np.float32 if seed % 2 else np.float64
+    dtype = np.float32 if (seed // 4) % 2 else np.float64
     x = field(rng, int(rng.integers(1, 70)), n_src, dtype=dtype, nan_frac=0.03, inf_frac=0.003)
-    amin = float(rng.choice([0.0, 0.5])); masked = bool(seed % 2)
+    amin = float(rng.choice([0.0, 0.5])); masked = bool((seed // 8) % 2)
     ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
     ks = [0, _lib.APPLY_KERNEL_SELL]
     if op.plan_info()["tile_plan"]:
         # default tile kernel, other block orders, single-row steps, odd walk lengths (tails of multi-row steps)
         t = _lib.APPLY_KERNEL_TILE
-        ks += [t, t | (6 << 16), t | (7 << 16), t | (13 << 16), t | (12 << 16)] + [t | (j << 20) for j in (1, 3, 5, 7)]
+        ks += [t, t | (6 << 16), t | (7 << 16), t | (13 << 16), t | (12 << 16), t | (15 << 16)] + [t | (j << 20) for j in (1, 3, 5, 7)]
     dx = to_device(x)
     for fl in ks:
         for rep in range(3):
