@@ -82,6 +82,28 @@ def test_fuzz_2d(hip, seed):
     assert_same(np.array(yout), ref.astype(out_dtype), exact=(out_dtype == np.float64), rtol=0)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_long_rows(hip, seed):
+    """Long rows in windows far apart: part-of-a-slice blocks, rows split over lane groups."""
+    rng = np.random.default_rng(7000 + seed)
+    n_src, n_dst = int(rng.integers(5000, 150000)), int(rng.integers(1, 700))
+    src, dst, w = make_links(rng, "longband", n_src, n_dst)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    csr = op.export_csr()
+    imask = (rng.random(n_dst) > 0.3).astype(np.int32)
+    frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    dtype = np.float32 if seed % 2 else np.float64
+    x = field(rng, int(rng.integers(1, 30)), n_src, dtype=dtype, nan_frac=0.03, inf_frac=0.005)
+    masked = bool(seed % 3)
+    ref = oracle.apply_c(csr, x, masked, imask, frac, 0.5)
+    t = _lib.APPLY_KERNEL_TILE
+    kernels = [0, _lib.APPLY_KERNEL_SELL] + ([t, t | (15 << 16), t | (3 << 20)] if op.plan_info()["tile_plan"] else [])
+    for fl in kernels:
+        assert_same(op.apply(to_device(x), masked=masked, remap_area_min=0.5, flags=fl).to_host(), ref, exact=True)
+    assert_same(op.apply_host(x, masked=masked, remap_area_min=0.5), ref, exact=True)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_fuzz_levels(hip, seed):
     rng = np.random.default_rng(5000 + seed)
