@@ -6,6 +6,7 @@ Grids and methods outside the native generator raise `NotImplementedError`
 naming the CDO command the reference would have run (cdogenerate.py:285-294).
 """
 import logging
+import os
 import shutil
 
 import numpy as np
@@ -24,8 +25,17 @@ class CdoGenerate:
         self.cdo_extra = tolist(cdo_extra)
         self.cdo_options = tolist(cdo_options)
         self.have_cdo = shutil.which(cdo) is not None
-        self.source_grid = from_xarray(source_grid)
-        self.target_grid = from_xarray(target_grid)
+        self.source_grid = from_xarray(self._open_if_file(source_grid))
+        self.target_grid = from_xarray(self._open_if_file(target_grid))
+
+    @staticmethod
+    def _open_if_file(grid):
+        """A path to a data file stands for the grid of its fields (cdogenerate.py:184, util.py:11-31);
+        other strings are CDO grid names."""
+        if isinstance(grid, str) and os.path.isfile(grid):
+            from .io import open_dataset
+            return open_dataset(grid)
+        return grid
 
     # ------------------------------------------------------------------ grids
     @staticmethod
@@ -111,9 +121,12 @@ class CdoGenerate:
     def areas(self, target=False):
         """Cell areas in m^2 (cdogenerate.py:345-400, `cdo gridarea`) for regular grids."""
         grid = self._grid_of(self.target_grid if target else self.source_grid)
-        if grid.kind != "regular":
-            raise NotImplementedError("areas need a regular grid without `cdo`")
         r = 6371000.0   # CDO's PlanetRadius default
+        if grid.kind != "regular":
+            if getattr(grid, "cdo_type", "") == "healpix":     # equal-area pixels
+                n = grid.lon.size
+                return Dataset({"cell_area": (("cell",), np.full(n, 4.0 * np.pi * r * r / n), {"units": "m2"})})
+            raise NotImplementedError("areas need a regular or HEALPix grid without `cdo`")
         area = (np.diff(np.sin(np.radians(grid.lat_b)))[:, None] *
                 np.radians(np.diff(grid.lon_b))[None, :]) * r * r
         return Dataset({"cell_area": (("lat", "lon"), area, {"units": "m2"})},

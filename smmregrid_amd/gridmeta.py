@@ -70,6 +70,20 @@ class GridInspector:
     def _is_bounds(name):
         return any(m in (name or "") for m in _BOUNDS_MARKERS)
 
+    @staticmethod
+    def get_gridtype_attr(gridtypes, attr):
+        """Flat, duplicate-free list of one attribute over several gridtypes (gridinspector.py:242-254)."""
+        out = []
+        for gridtype in gridtypes:
+            value = getattr(gridtype, attr, None)
+            if isinstance(value, (list, tuple)):
+                out.extend(value)
+            elif isinstance(value, dict):
+                out.extend(value.keys())
+            elif isinstance(value, str):
+                out.append(value)
+        return list(dict.fromkeys(out))
+
     def get_gridtype(self):
         self.grids = []
         if self.cdo_weights:

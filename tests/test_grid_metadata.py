@@ -1,5 +1,7 @@
 """CdoGrid / GridType / GridInspector / GridDetector with the expectations of the reference's
 tests/cdogrid_test.py, tests/gridtype_test.py and tests/gridinspector_test.py (synthetic data)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -102,3 +104,68 @@ def test_grid_detector_kinds():
                             "lon": DataArray(np.zeros(lats.size), dims=("values",))})
     assert det.detect_grid(red) == "GaussianReduced"
     assert det.detect_grid(_field(("a", "b"), (2, 3), {}, "t")) == "Unknown"
+
+
+# ---- the reference's own data files (tests/golden/refdata, read by the built-in NetCDF-4 reader)
+REFDATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refdata")
+
+
+@pytest.mark.parametrize("file_name,expected_grid", [("2t-era5.nc", "Regular"), ("r360x180.nc", "Regular"),
+                                                      ("healpix_0.nc", "Unknown"), ("regional.nc", "Regular")])
+def test_detect_grid_on_reference_files(file_name, expected_grid):
+    """util_test.py:41-67 for the files of tests/data that are committed as fixtures."""
+    from smmregrid_amd.io import open_dataset
+    gridtype = GridInspector(open_dataset(os.path.join(REFDATA, file_name))).get_gridtype()[0]
+    assert gridtype.kind == expected_grid
+
+
+def test_gridinspector_on_2t_era5():
+    """gridinspector_test.py:12-60: Dataset, DataArray and path input; get_gridtype_attr; raises."""
+    from smmregrid_amd.io import open_dataset
+    path = os.path.join(REFDATA, "2t-era5.nc")
+    ds = open_dataset(path)
+    for data in (ds, ds["2t"], path):
+        gi = GridInspector(data, loglevel="debug")
+        grids = gi.get_gridtype()
+        assert len(grids) == 1 and set(grids[0].dims) == {"lon", "lat"}
+        assert set(grids[0].variables.keys()) == {"2t"} and grids[0].kind == "Regular"
+        assert set(gi.get_gridtype_attr(grids, "dims")) == {"lon", "lat"}
+        assert gi.get_gridtype_attr(grids, "variables") == ["2t"]
+        assert gi.get_gridtype_attr(grids, "kind") == ["Regular"]
+    with pytest.raises(TypeError):
+        GridInspector(24)
+    with pytest.raises(FileNotFoundError):
+        GridInspector("not_a_file.nc")
+
+
+# ---- areas (areas_test.py of the reference, for the grids the native generator knows)
+EARTH_SURFACE = 5.101 * 1e8     # km2
+TOLERANCE = EARTH_SURFACE * 0.02
+
+
+def test_basic_areas_source():
+    """areas_test.py:16-31: cell areas of the source file's grid sum to the Earth's surface."""
+    from smmregrid_amd import CdoGenerate
+    gen = CdoGenerate(os.path.join(REFDATA, "2t-era5.nc"), os.path.join(REFDATA, "r360x180.nc"), loglevel="debug")
+    area = gen.areas()
+    assert area["cell_area"].shape == (73, 144)
+    assert area["cell_area"].values.sum() / 1e6 == pytest.approx(EARTH_SURFACE, abs=TOLERANCE)
+    assert (area["cell_area"].values > 0).all()          # pole rows of the 73-point grid included
+
+
+@pytest.mark.parametrize("target,shape", [(os.path.join(REFDATA, "r360x180.nc"), (180, 360)), ("hp32", (12288,)),
+                                          ("r180x90", (90, 180))])
+def test_basic_areas_target(target, shape):
+    """areas_test.py:34-46."""
+    from smmregrid_amd import CdoGenerate
+    area = CdoGenerate(os.path.join(REFDATA, "r360x180.nc"), target, loglevel="debug").areas(target=True)
+    assert area["cell_area"].shape == shape
+    assert area["cell_area"].values.sum() / 1e6 == pytest.approx(EARTH_SURFACE, abs=TOLERANCE)
+
+
+def test_nosource_areas_target():
+    """areas_test.py:49-55."""
+    from smmregrid_amd import CdoGenerate
+    area = CdoGenerate(source_grid=None, target_grid="r180x91", loglevel="debug").areas(target=True)
+    assert area["cell_area"].shape == (91, 180)
+    assert area["cell_area"].values.sum() / 1e6 == pytest.approx(EARTH_SURFACE, abs=TOLERANCE)
