@@ -115,7 +115,9 @@ class Dataset:
                 return var
             coords = OrderedDict(var.coords)
             coords.update(extra)
-            return DataArray(var.data, dims=var.dims, coords=coords, attrs=var.attrs, name=var.name)
+            out = DataArray(var.data, dims=var.dims, coords=coords, name=var.name)
+            out.attrs = var.attrs          # shared, as in xarray: ds['v'].attrs[...] = x changes the Dataset
+            return out
         if name in self.coords:
             return self.coords[name]
         raise KeyError(name)

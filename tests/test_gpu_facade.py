@@ -352,6 +352,28 @@ def test_netcdf4_files_of_the_reference_through_the_builtin_reader(hip):
     assert outr.shape == (1, 45, 90) and np.isfinite(outr.values).all()
 
 
+@pytest.mark.parametrize("method", ["nn", "con"])
+def test_target_grid_given_as_a_data_file(hip, method):
+    """basic_test.py:42-70 with the reference's own files: the target grid is the grid of the fields in
+    tests/data/r360x180.nc (a path), the source a DataArray of 2t-era5.nc; Dataset and DataArray in."""
+    from smmregrid_amd.io import open_dataset
+    golden = os.path.join(os.path.dirname(__file__), "golden", "refdata")
+    tfile = os.path.join(golden, "r360x180.nc")
+    xfield = open_dataset(os.path.join(golden, "2t-era5.nc"))
+    interpolator = Regridder(source_grid=xfield["2t"], target_grid=tfile, loglevel="debug", method=method)
+    xfield["2t"].attrs["test_attr"] = "test_value"
+    interp = interpolator.regrid(xfield)
+    assert interp["2t"].shape == (12, 180, 360) and interp["2t"].attrs["test_attr"] == "test_value"
+    interp = interpolator.regrid(xfield["2t"])
+    assert interp.shape == (12, 180, 360) and interp.attrs["test_attr"] == "test_value"
+    want = Regridder(source_grid=xfield["2t"], target_grid="r360x180", method=method).regrid(xfield["2t"])
+    assert_same(interp.values, want.values, exact=True)            # the file's grid IS r360x180
+    # horizontal_dims given explicitly, one time step (basic_test.py:61-68)
+    one = xfield["2t"].isel(time=0)
+    r2 = Regridder(source_grid=xfield, target_grid=tfile, method=method, horizontal_dims=["lon", "lat"])
+    assert r2.regrid(one).shape == (180, 360)
+
+
 def test_out_dtype_float32_is_the_rounded_float64_result(hip, rng):
     field = tas_field(rng, nt=3)
     w = CdoGenerate("r96x48", "r36x18").weights(method="con")
