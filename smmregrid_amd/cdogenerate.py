@@ -86,7 +86,10 @@ class CdoGenerate:
             raise TypeError('Target grid is not specified, cannot provide any regridding')
         if method not in ["bic", "bil", "con", "con2", "dis", "laf", "nn", "ycon"]:
             raise KeyError(f'Unsupported method {method}')   # cdogenerate.py:73-76
-        src = self._grid_of(self.source_grid)
+        # `-setgrid,<name>` among the extra CDO operators names the source grid of a file that carries
+        # no coordinates (basic_test.py:15-29: healpix_0.nc + '-setgrid,hp1_nested')
+        setgrid = [e.split(",", 1)[1] for e in (self.cdo_extra or []) if str(e).startswith("-setgrid,")]
+        src = gridgen.parse_grid(setgrid[-1]) if setgrid else self._grid_of(self.source_grid)
         dst = self._grid_of(self.target_grid)
         if mask_dim is None:
             ds = gridgen.generate_weights(src, dst, method=method,

@@ -279,7 +279,18 @@ def nearest_weights(src, dst):
     """Nearest source cell (regular source), one link of weight 1 per destination."""
     src, dst = parse_grid(src), parse_grid(dst)
     if src.kind != "regular":
-        raise ValueError("nearest-neighbour generation needs a regular source grid")
+        # cell-centre list (HEALPix, unstructured): nearest by great-circle distance == nearest by
+        # chord length between unit vectors
+        from scipy.spatial import cKDTree
+
+        def unit(lon, lat):
+            lam, phi = np.radians(lon), np.radians(lat)
+            return np.stack([np.cos(phi) * np.cos(lam), np.cos(phi) * np.sin(lam), np.sin(phi)], axis=1)
+        slon, slat = src.centers()
+        lon, lat = dst.centers()
+        _, idx = cKDTree(unit(slon, slat)).query(unit(lon, lat), k=1)
+        d = np.arange(lon.size, dtype=np.int64)
+        return _scrip_dataset(src, dst, idx.astype(np.int64) + 1, d + 1, np.ones(lon.size), "nn")
     nx, ny = src.lon.size, src.lat.size
     lon, lat = dst.centers()
     dlon = 360.0 / nx

@@ -374,6 +374,24 @@ def test_target_grid_given_as_a_data_file(hip, method):
     assert r2.regrid(one).shape == (180, 360)
 
 
+def test_healpix_source_with_setgrid(hip):
+    """basic_test.py:14-29 (method nn): healpix_0.nc carries no coordinates, `-setgrid,hp1_nested`
+    names its grid; nearest neighbour from the 12 HEALPix cells, levels and time kept."""
+    from smmregrid_amd.io import open_dataset
+    golden = os.path.join(os.path.dirname(__file__), "golden", "refdata")
+    tfile = os.path.join(golden, "r360x180.nc")
+    wfield = CdoGenerate(os.path.join(golden, "healpix_0.nc"), tfile, cdo_extra="-setgrid,hp1_nested",
+                         cdo_options=["--force", "-f", "nc"], loglevel="debug").weights(method="nn")
+    assert wfield.sizes["src_grid_size"] == 12 and wfield.sizes["dst_grid_size"] == 360 * 180
+    interpolator = Regridder(weights=wfield, loglevel="debug")
+    xfield = open_dataset(os.path.join(golden, "healpix_0.nc"))
+    rfield = interpolator.regrid(xfield)
+    assert rfield["tas"].shape == (2, 180, 360) and rfield["ta"].shape == (2, 90, 180, 360)
+    # every output value is one of the 12 source values of its time step
+    for t in range(2):
+        assert set(np.unique(rfield["tas"].values[t])) <= set(xfield["tas"].values[t].astype(np.float64))
+
+
 def test_out_dtype_float32_is_the_rounded_float64_result(hip, rng):
     field = tas_field(rng, nt=3)
     w = CdoGenerate("r96x48", "r36x18").weights(method="con")
