@@ -55,6 +55,10 @@ class CdoGenerate:
                 if k in obj.coords:
                     lat = obj.coords[k].values
             if lon is not None and lat is not None and lon.ndim == 1 and lat.ndim == 1:
+                if obj.coords[[k for k in ("lon", "longitude") if k in obj.coords][0]].dims == \
+                        obj.coords[[k for k in ("lat", "latitude") if k in obj.coords][0]].dims:
+                    # lon(cell), lat(cell): a list of cell centres (unstructured, HEALPix with coordinates)
+                    return gridgen.Grid("points", lon, lat, name="cell centres", cdo_type="unstructured")
                 return gridgen.regular_grid_from_centers(lon, lat)   # either latitude direction
         raise NotImplementedError("native weight generation supports CDO grid names "
                                   "(r<NX>x<NY>, hp<N>) and regular lon/lat data only")

@@ -42,12 +42,20 @@ def open_weights(path):
             ds = Dataset(attrs={k: (v.decode() if isinstance(v, bytes) else v)
                                 for k, v in nc._attributes.items()})
             for k, var in nc.variables.items():
-                arr = DataArray(np.array(var[...]), dims=var.dimensions, name=k)
+                attrs = {a: (v.decode() if isinstance(v, bytes) else (v.item() if getattr(v, "size", 0) == 1 else v))
+                         for a, v in var._attributes.items()}
+                values = np.array(var[...])
+                if values.dtype.kind in "iuf" and not values.dtype.isnative:
+                    values = values.astype(values.dtype.newbyteorder("="))
+                values = _cf_decode(values, attrs)
+                for a in ("_FillValue", "missing_value", "scale_factor", "add_offset"):
+                    attrs.pop(a, None)
+                arr = DataArray(values, dims=var.dimensions, name=k, attrs=attrs)
                 if var.dimensions == (k,):
                     ds.coords[k] = arr
                 else:
                     ds[k] = arr
-        return ds
+        return _cf_coordinates(ds)
     if HAVE_XARRAY:
         import xarray
         from .xrlite import from_xarray
@@ -141,6 +149,20 @@ def _open_netcdf4_lite(path, decode=True):
                 ds.coords[name] = arr
             else:
                 ds[name] = arr
+    return _cf_coordinates(ds)
+
+
+def _cf_coordinates(ds):
+    """CF `coordinates` attribute (xarray's decode_coords): variables a field names as its auxiliary
+    coordinates (lon / lat per cell of an unstructured or HEALPix file, 2-D nav_lon / nav_lat) become
+    coordinates of the Dataset, so fields taken from it carry them."""
+    names = []
+    for v in ds.data_vars.values():
+        for n in str(v.attrs.get("coordinates", "")).split():
+            if n in ds._vars and n not in names:
+                names.append(n)
+    for n in names:
+        ds.coords[n] = ds._vars.pop(n)
     return ds
 
 
@@ -175,4 +197,4 @@ def _open_netcdf4_h5py(h5py, path):
                 ds.coords[name] = arr
             else:
                 ds[name] = arr
-    return ds
+    return _cf_coordinates(ds)

@@ -392,6 +392,48 @@ def test_healpix_source_with_setgrid(hip):
         assert set(np.unique(rfield["tas"].values[t])) <= set(xfield["tas"].values[t].astype(np.float64))
 
 
+def test_unstructured_source_file_with_cf_coordinates(hip, rng, tmp_path):
+    """A file in the layout of the reference's tas-healpix2.nc / tos-fesom.nc: lon(cell), lat(cell) named
+    by the field's CF `coordinates` attribute (NetCDF-3, written here with scipy).  The cell-centre list
+    is the source grid; nearest-neighbour weights; values checked against the oracle."""
+    from scipy.io import netcdf_file
+    from smmregrid_amd.io import open_dataset
+    g = gridgen.parse_grid("hp8_nested")
+    perm = rng.permutation(g.lon.size)                    # unstructured: cells in no particular order
+    lon, lat = g.lon[perm], g.lat[perm]
+    tas = (280.0 + 20.0 * np.cos(np.radians(lat))[None, :] + rng.standard_normal((3, lon.size))).astype(np.float32)
+    tas[1, ::17] = 1e20                                   # packed missing values
+    path = str(tmp_path / "unstructured.nc")
+    with netcdf_file(path, "w") as nc:
+        nc.createDimension("time", 3)
+        nc.createDimension("cell", lon.size)
+        for name, vals in (("lon", lon), ("lat", lat)):
+            v = nc.createVariable(name, "d", ("cell",))
+            v[:] = vals
+            v.units = "degrees_east" if name == "lon" else "degrees_north"
+        v = nc.createVariable("tas", "f", ("time", "cell"))
+        v[:] = tas
+        v.coordinates = "lat lon"
+        v._FillValue = np.float32(1e20)
+        v.units = "K"
+    ds = open_dataset(path)
+    assert set(ds.coords) >= {"lon", "lat"} and ds["tas"].attrs["units"] == "K"
+    assert np.isnan(ds["tas"].values[1, ::17]).all() and np.isfinite(ds["tas"].values[0]).all()
+    rg = Regridder(source_grid=path, target_grid="r72x36", method="nn")
+    out = rg.regrid(ds)
+    assert out["tas"].shape == (3, 36, 72)
+    w = rg.grids[0].weights
+    assert w.sizes["src_grid_size"] == lon.size
+    ref = oracle_2d(w, ds["tas"].values.reshape(3, -1), masked=bool(np.asarray(rg.grids[0].masked).any()))
+    assert_same(out["tas"].values.reshape(3, -1), ref, exact=True)
+    # nearest neighbour really is nearest: the chosen source centre is within the HEALPix pixel radius
+    src = w["src_address"].values - 1
+    tl, tp = w["dst_grid_center_lon"].values, w["dst_grid_center_lat"].values      # SCRIP centres are radians
+    sl, sp = np.radians(lon[src]), np.radians(lat[src])
+    cosd = np.sin(tp) * np.sin(sp) + np.cos(tp) * np.cos(sp) * np.cos(tl - sl)
+    assert np.degrees(np.arccos(np.clip(cosd, -1, 1))).max() < 8.0        # nside 8: pixels ~7.3 degrees across
+
+
 def test_out_dtype_float32_is_the_rounded_float64_result(hip, rng):
     field = tas_field(rng, nt=3)
     w = CdoGenerate("r96x48", "r36x18").weights(method="con")
