@@ -41,6 +41,7 @@ WORKLOADS = {
     "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
     "upsample": ("bil", "r360x180", "r1440x721", 1024, "f64"),    # coarse -> fine: Y-write bound
     "nnhi": ("nn", "r3600x1800", "r360x180", 256, "f64"),          # 1 link per row, 1 of 100 source cells used
+    "hpsrc": ("nn", "hp512_nested", "r1440x721", 256, "f32"),       # HEALPix (nested) source, nearest neighbour
     "bilhi": ("bil", "r3600x1800", "r360x180", 256, "f64"),        # 4 links per row, pairs 80 B apart
     "conhi": ("con", "r3600x1800", "r360x180", 256, "f64"),       # 0.1 deg -> 1 deg: ~120 links per row
     "conmid": ("con", "r1440x720", "r360x180", 1024, "f64"),      # 0.25 deg -> 1 deg: 16-25 links per row
