@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SMM_ABI_VERSION 1
+#define SMM_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -147,7 +147,9 @@ int smm_operator_export_csr(smm_operator_t op, int64_t* rowptr, int32_t* col, do
  * Epilogue vectors of the weights file (host pointers, copied to HBM):
  *   dst_imask: int32[n_dst] (regrid.py:510, used when SMM_APPLY_MASKED)
  *   dst_frac : double[n_dst] (regrid.py:509, used when area_min > 0)
- * Either may be NULL to clear it.  Call before any concurrent smm_apply.
+ * Either may be NULL to clear it.  Call before any concurrent smm_apply and before the operator
+ * joins a group (smm_group_create copies the device pointers into the group's level table):
+ * SMM_ERR_INVALID while the operator belongs to a group.  On failure the old vectors stay in force.
  */
 int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask,
                               const double* dst_frac);
@@ -166,9 +168,30 @@ int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t
 int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
                            int64_t* staged_src_elems);
 
-/* per-level set (replaces the list built by weights.py:7-23); borrows the operators */
+/* Launch geometry smm_apply would use for n_batch rows of x_dtype under `flags` (nothing is
+ * launched; for tests and tuning).  kernel: 0 = SELL row-per-lane, 1 = LDS tile; j_per_block: batch
+ * rows walked by one workgroup; rows_per_step: batch rows staged per barrier pair; rows_per_block:
+ * destination rows per workgroup; n_blocks: grid size; lds_bytes: dynamic LDS per workgroup;
+ * big_operator: the links do not stay in L2, walks are lengthened to amortise their re-read.
+ * Any out pointer may be NULL. */
+int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, unsigned flags,
+                             int* kernel, int* j_per_block, int* rows_per_step, int* rows_per_block,
+                             int64_t* n_blocks, int64_t* lds_bytes, int* big_operator);
+
+/* per-level set (replaces the list built by weights.py:7-23); borrows the operators: they must
+ * outlive the group (smm_operator_destroy fails with SMM_ERR_INVALID on a member) */
 int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out);
 int smm_group_destroy(smm_group_t g);
+/* Uploads the device copy of one (level_index, masked_levels) configuration ahead of time, so
+ * that smm_group_apply calls with the same configuration allocate nothing and never block
+ * (stream-capturable).  Configurations stay cached until smm_group_destroy (n_lev * 4 + n_ops
+ * bytes each); a first-seen configuration passed straight to smm_group_apply is uploaded there
+ * (one small hipMalloc + blocking copy, no device synchronisation). */
+int smm_group_prepare(smm_group_t g, int64_t n_lev, const int32_t* level_index,
+                      const uint8_t* masked_levels);
+int smm_group_launch_info(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n_lev, int64_t n_inner,
+                          unsigned flags, int* kernel, int* j_per_block, int* rows_per_step,
+                          int* rows_per_block, int64_t* n_blocks, int64_t* lds_bytes, int* big_operator);
 /* bit 0: every member has an LDS tile plan of the group's block shape, bit 1: the tile kernel is the default */
 int smm_group_plan_info(smm_group_t g, int* kernel_kind, int* slices_per_block);
 

@@ -80,7 +80,14 @@ SIGNATURES = {
     "smm_operator_set_epilogue": [_p, _p, _p],
     "smm_operator_mask_apply": [_p, _p, _p],
     "smm_operator_plan_info": [_p, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "smm_operator_launch_info": [_p, _int, _i64, _uint, ctypes.POINTER(_int), ctypes.POINTER(_int),
+                                 ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_i64),
+                                 ctypes.POINTER(_i64), ctypes.POINTER(_int)],
     "smm_group_create": [_pp, _int, _pp],
+    "smm_group_prepare": [_p, _i64, _p, _p],
+    "smm_group_launch_info": [_p, _int, _i64, _i64, _i64, _uint, ctypes.POINTER(_int), ctypes.POINTER(_int),
+                              ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_i64),
+                              ctypes.POINTER(_i64), ctypes.POINTER(_int)],
     "smm_group_destroy": [_p],
     "smm_group_plan_info": [_p, ctypes.POINTER(_int), ctypes.POINTER(_int)],
     "smm_apply": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _p],

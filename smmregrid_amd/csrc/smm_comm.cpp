@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -44,12 +45,27 @@ Rccl& rccl() {
       return p;
     };
     if (!dlsym(RTLD_DEFAULT, "ncclGetUniqueId")) {
-      for (const char* path : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      // SMM_RCCL_LIB names the library to bind instead of the default search list
+      const char* forced = getenv("SMM_RCCL_LIB");
+      std::string why;
+      auto try_open = [&](const char* path) {
+        (void)dlerror();
         h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+        if (!h) {
+          const char* e = dlerror();   // one call: dlerror() clears the message it returns
+          why = e ? e : "not found";
+        }
+      };
+      if (forced && *forced) {
+        try_open(forced);
+      } else {
+        for (const char* path : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+          try_open(path);
+          if (h) break;
+        }
       }
       if (!h) {
-        r.err = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+        r.err = "cannot load librccl: " + why;
         return;
       }
     }

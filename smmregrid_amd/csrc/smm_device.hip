@@ -19,8 +19,10 @@
 // identical to it.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -114,6 +116,13 @@ struct HostPipe {
     grow_host(hy, cap_hy, need_hy);
     return e;
   }
+  // After a failed chunk: wait for whatever is still queued on both streams (an async D2H into the
+  // caller's Y of the previous chunk), so that nothing writes into caller memory after the return.
+  void quiesce() {
+    for (int i = 0; i < 2; ++i)
+      if (stream[i]) (void)hipStreamSynchronize(stream[i]);
+    (void)hipGetLastError();
+  }
   ~HostPipe() {
     for (int i = 0; i < 2; ++i) {
       if (stream[i]) (void)hipStreamDestroy(stream[i]);
@@ -160,6 +169,7 @@ struct smm_operator {
   std::mutex plan_mu;
   std::mutex pipe_mu;        // smm_apply_host calls on one operator take turns
   HostPipe pipe;
+  std::atomic<int> group_refs{0};  // groups borrowing this operator (their descriptors hold its device pointers)
   int native = 0;            // shape of the operator's own plan (choose_native_plan)
   int native_plan() const { return native; }
   LevelDesc* d_desc = nullptr;  // one-element device copy (native plan)
@@ -189,7 +199,9 @@ struct smm_group {
   bool tile_reuse = false;
   int64_t tile_max_chunks = 0;
   int64_t max_row_nnz = 0;
-  // uploaded (level_index, masked_levels) configurations, keyed by content
+  // uploaded (level_index, masked_levels) configurations, keyed by content.  An entry lives until
+  // smm_group_destroy: a kernel enqueued by another thread may still read it, so nothing is ever
+  // evicted (an entry is n_lev * 4 + n_ops bytes; callers cycle through a few level subsets).
   std::mutex mu;
   std::map<std::string, void*> cfg_cache;
   std::mutex pipe_mu;  // smm_group_apply_host calls on one group take turns
@@ -285,6 +297,12 @@ int ensure_plan(smm_operator* op, int which) {
 using smm_launch::launch_sell;
 using smm_launch::launch_tile;
 
+struct LaunchInfo {
+  bool tile = false, big_operator = false;
+  int j_per_block = 0, rows_per_step = 1, rows_per_block = 0;
+  int64_t n_jtiles = 0, n_blocks = 0, lds_bytes = 0;
+};
+
 // Common launch path for a single operator (descs = op->d_desc) or a group.
 int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t* d_lev_masked,
               int64_t n_src, int64_t n_dst, int tile_which, bool tile_ok, bool tile_preferred,
@@ -292,10 +310,10 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
               int64_t max_row_nnz, const void* x, int x_dtype, int64_t xs_o, int64_t xs_l,
               int64_t xs_i, void* y, int y_dtype, int64_t ys_o, int64_t ys_l, int64_t ys_i,
               int64_t n_outer, int64_t n_lev, int64_t n_inner, double area_min, unsigned flags,
-              hipStream_t s) {
+              hipStream_t s, LaunchInfo* info_only = nullptr) {
   if (n_outer < 0 || n_lev < 0 || n_inner < 0) return fail(SMM_ERR_INVALID, "negative batch size");
   if (n_outer == 0 || n_lev == 0 || n_inner == 0 || n_dst == 0) return SMM_OK;
-  if (!x || !y) return fail(SMM_ERR_INVALID, "null field pointer");
+  if (!info_only && (!x || !y)) return fail(SMM_ERR_INVALID, "null field pointer");
   if ((x_dtype != SMM_F32 && x_dtype != SMM_F64) || (y_dtype != SMM_F32 && y_dtype != SMM_F64))
     return fail(SMM_ERR_UNSUPPORTED, "field dtype must be SMM_F32 or SMM_F64");
   if (!(area_min >= 0.0 && area_min <= 1.0))
@@ -346,6 +364,29 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
     a.n_dblocks = (n_dst + rows - 1) / rows;
     a.sub_shift = tile_which >= 2 ? tile_which - 1 : 0;   // block = 1 / 2^sub_shift of a slice
   }
+  if (info_only) {
+    info_only->tile = use_tile;
+    if (use_tile) {
+      const smm_launch::TileLaunchCfg c =
+          smm_launch::tile_launch_cfg(a, n_lev, tile_which, tile_max_chunks, max_row_nnz, flags, xsz);
+      info_only->j_per_block = c.j_per_block;
+      info_only->n_jtiles = c.n_jtiles;
+      info_only->n_blocks = c.total;
+      info_only->rows_per_step = c.rows;
+      info_only->lds_bytes = (int64_t)c.lds;
+      info_only->big_operator = c.big_operator;
+      info_only->rows_per_block = (int)shape_rows(tile_which);
+    } else {
+      const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
+      const int bt = (a.n_j >= 8 && variant == 1) ? 8 : ((a.n_j >= 4 && variant <= 1) ? 4 : (a.n_j >= 2 ? 2 : 1));
+      info_only->j_per_block = bt;
+      info_only->n_jtiles = (a.n_j + bt - 1) / bt;
+      info_only->n_blocks = a.n_dblocks * info_only->n_jtiles * n_lev;
+      info_only->rows_per_step = bt;
+      info_only->rows_per_block = 256;
+    }
+    return SMM_OK;
+  }
   if (use_tile)
     return SMM_DISPATCH(launch_tile, a, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_flags, fill, flags, s);
   return SMM_DISPATCH(launch_sell, a, n_lev, fill, flags, s);
@@ -372,6 +413,12 @@ void host_copy(void* dst, const void* src, size_t bytes) {
     if (hi > lo) pool.emplace_back([=] { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
   }
   for (auto& th : pool) th.join();
+}
+
+// test hook for the pipelines' error path: SMM_TEST_FAIL_AT_CHUNK=<c> makes chunk c fail
+int64_t test_fail_chunk() {
+  const char* e = getenv("SMM_TEST_FAIL_AT_CHUNK");
+  return (e && *e) ? (int64_t)atoll(e) : -1;
 }
 
 bool is_pinned(const void* p) {
@@ -653,6 +700,8 @@ int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
 
 int smm_operator_destroy(smm_operator_t op) {
   if (!op) return SMM_OK;
+  if (op->group_refs.load() > 0)
+    return fail(SMM_ERR_INVALID, "operator still belongs to a group: destroy the group first");
   DeviceGuard guard(op->device);
   release(op);
   return SMM_OK;
@@ -679,25 +728,49 @@ int smm_operator_export_csr(smm_operator_t op, int64_t* rowptr, int32_t* col, do
 
 int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const double* dst_frac) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
+  // a group's level descriptors hold this operator's imask / frac device pointers
+  if (op->group_refs.load() > 0)
+    return fail(SMM_ERR_INVALID,
+                "operator belongs to a group: set the epilogue vectors before smm_group_create");
   DeviceGuard guard(op->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   const size_t n = (size_t)op->csr.n_dst;
-  (void)hipFree(op->d_imask);
-  (void)hipFree(op->d_frac);
-  op->d_imask = nullptr;
-  op->d_frac = nullptr;
+  // upload the new vectors first: on failure the operator keeps its old state untouched
+  uint8_t* new_imask = nullptr;
+  double* new_frac = nullptr;
   if (dst_imask) {
     std::vector<uint8_t> m(n);
     for (size_t i = 0; i < n; ++i) m[i] = dst_imask[i] != 0;  // .astype(bool), regrid.py:557
-    int rc = upload(&op->d_imask, m);
-    if (rc) return rc;
+    int rc = upload(&new_imask, m);
+    if (rc) {
+      (void)hipFree(new_imask);
+      return rc;
+    }
   }
   if (dst_frac) {
     std::vector<double> f(dst_frac, dst_frac + n);
-    int rc = upload(&op->d_frac, f);
-    if (rc) return rc;
+    int rc = upload(&new_frac, f);
+    if (rc) {
+      (void)hipFree(new_imask);
+      (void)hipFree(new_frac);
+      return rc;
+    }
   }
-  return refresh_desc(op);
+  uint8_t* old_imask = op->d_imask;
+  double* old_frac = op->d_frac;
+  op->d_imask = new_imask;
+  op->d_frac = new_frac;
+  int rc = refresh_desc(op);
+  if (rc) {  // the device descriptor still names the old vectors: keep them
+    op->d_imask = old_imask;
+    op->d_frac = old_frac;
+    (void)hipFree(new_imask);
+    (void)hipFree(new_frac);
+    return rc;
+  }
+  (void)hipFree(old_imask);
+  (void)hipFree(old_frac);
+  return SMM_OK;
 }
 
 int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
@@ -787,6 +860,10 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     return SMM_OK;
   };
 
+  // The chunk loop runs inside a lambda so that any failure can first wait for the copies still
+  // in flight into the caller's buffers (chunk c-1's D2H) before the error is returned.
+  const int64_t fail_at = test_fail_chunk();
+  auto pipeline = [&]() -> int {
   for (int64_t c = 0; c < n_chunks; ++c) {
     const int b = (int)(c & 1);
     const int64_t r0 = c * chunk_rows, rows = std::min(chunk_rows, n_batch - r0);
@@ -794,6 +871,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
       int rc = drain(c - 2);  // buffer b is free again once chunk c-2 has been delivered
       if (rc) return rc;
     }
+    if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (SMM_TEST_FAIL_AT_CHUNK)");
     const char* xsrc = (const char*)x_host + (size_t)r0 * xrow;
     if (!x_direct) {
       if (ldx == S) {
@@ -828,6 +906,10 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     if (rc) return rc;
   }
   return SMM_OK;
+  };
+  const int prc = pipeline();
+  if (prc) pipe.quiesce();   // keeps the thread's error message of the first failure
+  return prc;
 }
 
 int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask) {
@@ -922,6 +1004,7 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
     delete g;
     return rc;
   }
+  for (int i = 0; i < n_ops; ++i) ops[i]->group_refs.fetch_add(1);
   *out = g;
   return SMM_OK;
 }
@@ -938,15 +1021,19 @@ int smm_group_destroy(smm_group_t g) {
   DeviceGuard guard(g->device);
   for (auto& kv : g->cfg_cache) (void)hipFree(kv.second);
   (void)hipFree(g->d_descs);
+  for (smm_operator_t op : g->ops) op->group_refs.fetch_sub(1);
   delete g;
   return SMM_OK;
 }
 
-int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer, int64_t xs_lev,
-                    int64_t xs_inner, void* y, int y_dtype, int64_t ys_outer, int64_t ys_lev,
-                    int64_t ys_inner, int64_t n_outer, int64_t n_lev, int64_t n_inner,
-                    const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min,
-                    unsigned flags, void* stream) {
+extern "C++" {
+// Validates (level_index, masked_levels) against the group and returns the device copy of that
+// configuration, uploading it on first sight.  Entries live until smm_group_destroy.
+static int group_level_cfg(smm_group_t g, int64_t n_lev, const int32_t* level_index,
+                           const uint8_t* masked_levels, double remap_area_min, unsigned flags,
+                           const int32_t** d_map, const uint8_t** d_masked) {
+  *d_map = nullptr;
+  *d_masked = nullptr;
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   if (n_lev < 0) return fail(SMM_ERR_INVALID, "negative level count");
   if (n_lev > 0 && !level_index) return fail(SMM_ERR_INVALID, "null level_index");
@@ -964,11 +1051,10 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
       return fail(SMM_ERR_INVALID, "remap_area_min > 0 requested but a level has no dst_frac");
   }
   if (n_lev == 0) return SMM_OK;
-  DeviceGuard guard(g->device);
-  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
 
-  // device copy of (level_index, masked_levels), cached by content
-  std::string key((const char*)level_index, (size_t)n_lev * sizeof(int32_t));
+  // key: level count, then the map, then (if given) one masked flag per member -- unambiguous
+  std::string key((const char*)&n_lev, sizeof(n_lev));
+  key.append((const char*)level_index, (size_t)n_lev * sizeof(int32_t));
   key.push_back(masked_levels ? 1 : 0);
   if (masked_levels) key.append((const char*)masked_levels, (size_t)n_ops);
   void* d_cfg = nullptr;
@@ -979,6 +1065,8 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
     if (it != g->cfg_cache.end()) {
       d_cfg = it->second;
     } else {
+      // first sight of this configuration (smm_group_prepare does this ahead of time): one small
+      // allocation + blocking copy, no device-wide synchronisation, nothing is ever evicted
       std::vector<char> buf(map_bytes + (size_t)n_ops, 0);
       memcpy(buf.data(), level_index, (size_t)n_lev * 4);
       if (masked_levels) memcpy(buf.data() + map_bytes, masked_levels, (size_t)n_ops);
@@ -986,23 +1074,87 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
       hipError_t e = hipMemcpy(d_cfg, buf.data(), buf.size(), hipMemcpyHostToDevice);
       if (e != hipSuccess) {
         (void)hipFree(d_cfg);
+        (void)hipGetLastError();
         return fail(SMM_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
-      }
-      if (g->cfg_cache.size() >= 64) {  // bound the cache: callers cycle through a few level subsets
-        SMM_HIP(hipDeviceSynchronize());
-        for (auto& kv : g->cfg_cache) (void)hipFree(kv.second);
-        g->cfg_cache.clear();
       }
       g->cfg_cache.emplace(std::move(key), d_cfg);
     }
   }
-  const int32_t* d_map = (const int32_t*)d_cfg;
-  const uint8_t* d_masked = masked_levels ? (const uint8_t*)d_cfg + map_bytes : nullptr;
+  *d_map = (const int32_t*)d_cfg;
+  *d_masked = masked_levels ? (const uint8_t*)d_cfg + map_bytes : nullptr;
+  return SMM_OK;
+}
+}  // extern "C++"
+
+int smm_group_prepare(smm_group_t g, int64_t n_lev, const int32_t* level_index,
+                      const uint8_t* masked_levels) {
+  if (!g) return fail(SMM_ERR_INVALID, "null group");
+  DeviceGuard guard(g->device);
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
+  const int32_t* d_map;
+  const uint8_t* d_masked;
+  return group_level_cfg(g, n_lev, level_index, masked_levels, 0.0, 0u, &d_map, &d_masked);
+}
+
+int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer, int64_t xs_lev,
+                    int64_t xs_inner, void* y, int y_dtype, int64_t ys_outer, int64_t ys_lev,
+                    int64_t ys_inner, int64_t n_outer, int64_t n_lev, int64_t n_inner,
+                    const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min,
+                    unsigned flags, void* stream) {
+  if (!g) return fail(SMM_ERR_INVALID, "null group");
+  DeviceGuard guard(g->device);
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
+  const int32_t* d_map;
+  const uint8_t* d_masked;
+  int rc = group_level_cfg(g, n_lev, level_index, masked_levels, remap_area_min, flags, &d_map, &d_masked);
+  if (rc || n_lev == 0) return rc;
   const smm_operator* op0 = g->ops[0];
   return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_which,
                    g->tile_valid, g->tile_preferred, (g->tile_reuse ? 1 : 0), g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
+}
+
+extern "C++" {
+static void fill_launch_info(const LaunchInfo& li, int* kernel, int* j_per_block, int* rows_per_step,
+                             int* rows_per_block, int64_t* n_blocks, int64_t* lds_bytes, int* big_operator) {
+  if (kernel) *kernel = li.tile ? 1 : 0;
+  if (j_per_block) *j_per_block = li.j_per_block;
+  if (rows_per_step) *rows_per_step = li.rows_per_step;
+  if (rows_per_block) *rows_per_block = li.rows_per_block;
+  if (n_blocks) *n_blocks = li.n_blocks;
+  if (lds_bytes) *lds_bytes = li.lds_bytes;
+  if (big_operator) *big_operator = li.big_operator ? 1 : 0;
+}
+}  // extern "C++"
+
+int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, unsigned flags, int* kernel,
+                             int* j_per_block, int* rows_per_step, int* rows_per_block, int64_t* n_blocks,
+                             int64_t* lds_bytes, int* big_operator) {
+  if (!op) return fail(SMM_ERR_INVALID, "null operator");
+  const int pw = op->native_plan();
+  const smm_operator::TilePlan& pl = op->plan[pw];
+  LaunchInfo li;
+  int rc = run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid, pl.preferred,
+                     (pl.reuse ? 1 : 0), pl.max_chunks, op->csr.max_row_nnz, nullptr, x_dtype, op->csr.n_src, 0, 0,
+                     nullptr, SMM_F64, op->csr.n_dst, 0, 0, n_batch, 1, 1, 0.0, flags, nullptr, &li);
+  if (rc) return rc;
+  fill_launch_info(li, kernel, j_per_block, rows_per_step, rows_per_block, n_blocks, lds_bytes, big_operator);
+  return SMM_OK;
+}
+
+int smm_group_launch_info(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n_lev, int64_t n_inner,
+                          unsigned flags, int* kernel, int* j_per_block, int* rows_per_step,
+                          int* rows_per_block, int64_t* n_blocks, int64_t* lds_bytes, int* big_operator) {
+  if (!g) return fail(SMM_ERR_INVALID, "null group");
+  const smm_operator* op0 = g->ops[0];
+  LaunchInfo li;
+  int rc = run_apply(g->d_descs, nullptr, nullptr, op0->csr.n_src, op0->csr.n_dst, g->tile_which, g->tile_valid,
+                     g->tile_preferred, (g->tile_reuse ? 1 : 0), g->tile_max_chunks, g->max_row_nnz, nullptr,
+                     x_dtype, 0, 0, 0, nullptr, SMM_F64, 0, 0, 0, n_outer, n_lev, n_inner, 0.0, flags, nullptr, &li);
+  if (rc) return rc;
+  fill_launch_info(li, kernel, j_per_block, rows_per_step, rows_per_block, n_blocks, lds_bytes, big_operator);
+  return SMM_OK;
 }
 
 // Host-buffer variant of smm_group_apply: X host (n_outer, n_lev, n_inner, S) C-contiguous,
@@ -1064,6 +1216,8 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
     return SMM_OK;
   };
 
+  const int64_t fail_at = test_fail_chunk();
+  auto pipeline = [&]() -> int {   // see smm_apply_host: errors drain both streams before returning
   for (int64_t c = 0; c < n_chunks; ++c) {
     const int b = (int)(c & 1);
     const int64_t o0 = c * chunk_outer, no = std::min(chunk_outer, n_outer - o0);
@@ -1072,6 +1226,7 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
       int rc = drain(c - 2);
       if (rc) return rc;
     }
+    if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (SMM_TEST_FAIL_AT_CHUNK)");
     const char* xsrc = (const char*)x_host + (size_t)o0 * rows_per_outer * S * xsz;
     const void* h2d_src = xsrc;
     if (!x_direct) {
@@ -1109,6 +1264,10 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
     if (rc) return rc;
   }
   return SMM_OK;
+  };
+  const int prc = pipeline();
+  if (prc) pipe.quiesce();
+  return prc;
 }
 
 }  // extern "C"

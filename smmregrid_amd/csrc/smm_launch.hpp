@@ -53,39 +53,67 @@ int launch_sell(const ApplyArgs& a, int64_t n_lev, bool fill, unsigned flags, hi
   return go(std::integral_constant<int, 1>());
 }
 
-template <typename XT, typename YT>
-int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_chunks,
-                int64_t max_row_nnz, int tile_flags, bool fill, unsigned flags, hipStream_t s) {
-  ApplyArgs args = a;
+// Launch geometry of the tile kernel, shared by the launcher and smm_operator_launch_info.
+struct TileLaunchCfg {
+  int j_per_block = 0;     // batch rows walked by one workgroup
+  int64_t n_jtiles = 0;
+  int64_t total = 0;       // workgroups
+  int xcd_remap = 0;
+  int threads = 0;
+  int np_needed = 0;       // 16-B staging pieces per thread of the widest block
+  int rows = 1;            // batch rows staged per barrier pair (R)
+  size_t tile = 0, lds = 0;
+  bool big_operator = false;
+};
+
+inline TileLaunchCfg tile_launch_cfg(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_chunks,
+                                     int64_t max_row_nnz, unsigned flags, size_t xsz) {
+  TileLaunchCfg c;
   const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
   const unsigned jpb = (flags >> SMM_APPLY_JPB_SHIFT) & 0xFFu;
   // Batch rows walked per workgroup: the prologue (links -> registers) is amortised over
   // them, so heavier rows want longer walks; keep >= ~4096 workgroups to fill 256 CUs.
   // An operator that does not stay in L2 (links x 12 B beyond ~32 MB) is re-read from HBM by every
   // walk: amortise it over long walks whatever the row length.
-  const bool big_operator = a.n_dst * std::max<int64_t>(max_row_nnz, 1) * 12 > (32ll << 20);
-  int64_t walk = jpb ? (int64_t)jpb : (big_operator ? 128 : (max_row_nnz <= 4 ? 4 : 64));
+  c.big_operator = a.n_dst * std::max<int64_t>(max_row_nnz, 1) * 12 > (32ll << 20);
+  int64_t walk = jpb ? (int64_t)jpb : (c.big_operator ? 128 : (max_row_nnz <= 4 ? 4 : 64));
   if (!jpb)
     while (walk > 1 && a.n_dblocks * ((a.n_j + walk - 1) / walk) * n_lev < 4096) walk /= 2;
-  args.j_per_block = (int)std::min<int64_t>(a.n_j, walk);
-  args.n_jtiles = (a.n_j + args.j_per_block - 1) / args.j_per_block;
-  const int64_t total = args.n_dblocks * args.n_jtiles * n_lev;
+  c.j_per_block = (int)std::min<int64_t>(a.n_j, walk);
+  c.n_jtiles = c.j_per_block > 0 ? (a.n_j + c.j_per_block - 1) / c.j_per_block : 0;
+  c.total = a.n_dblocks * c.n_jtiles * n_lev;
+  // runs of 32 consecutive blocks per XCD (variant 6: dispatcher order, 7 / 13: runs of 8 / 128)
+  c.xcd_remap = variant == 6 ? 0 : (variant == 7 ? 8 : (variant == 13 ? 128 : 32));
+  c.tile = (size_t)max_chunks * kChunkElems * xsz;
+  const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * xsz / 16);
+  c.threads = (tile_which ? 1 : kWavesPerBlock) * 64;  // == tile_waves(MAXK) * 64
+  c.np_needed = (int)((max_pieces + c.threads - 1) / c.threads);
+  // Small tiles (one or two 16-B pieces per thread, 4-wave shape): a step of 4 / 2 batch rows per
+  // barrier pair keeps as many bytes in flight as a full tile would (variant 12: off, for A/B runs).
+  c.rows = 1;
+  if (!tile_which && variant != 12) c.rows = c.np_needed <= 1 ? 4 : (c.np_needed <= 2 ? 2 : 1);
+  while (c.rows > 1 && c.rows > c.j_per_block) c.rows /= 2;
+  c.lds = c.tile * (size_t)c.rows;
+  return c;
+}
+
+template <typename XT, typename YT>
+int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_chunks,
+                int64_t max_row_nnz, int tile_flags, bool fill, unsigned flags, hipStream_t s) {
+  ApplyArgs args = a;
+  const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
+  const TileLaunchCfg cfg = tile_launch_cfg(a, n_lev, tile_which, max_chunks, max_row_nnz, flags, sizeof(XT));
+  args.j_per_block = cfg.j_per_block;
+  args.n_jtiles = cfg.n_jtiles;
+  const int64_t total = cfg.total;
   if (total <= 0) return SMM_OK;
   if (total > 0x7fffffffLL) return smm::fail_msg(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
   args.n_blocks = total;
-  // runs of 32 consecutive blocks per XCD (variant 6: dispatcher order, 7 / 13: runs of 8 / 128)
-  args.xcd_remap = variant == 6 ? 0 : (variant == 7 ? 8 : (variant == 13 ? 128 : 32));
-  const size_t tile = (size_t)max_chunks * kChunkElems * sizeof(XT);
-  const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * sizeof(XT) / 16);
-  const int threads = (tile_which ? 1 : kWavesPerBlock) * 64;  // == tile_waves(MAXK) * 64
-  const int np_needed = (int)((max_pieces + threads - 1) / threads);
-  // Small tiles (one or two 16-B pieces per thread, 4-wave shape): a step of 4 / 2 batch rows per
-  // barrier pair keeps as many bytes in flight as a full tile would (variant 12: off, for A/B runs).
-  int rows = 1;
-  if (!tile_which && variant != 12) rows = np_needed <= 1 ? 4 : (np_needed <= 2 ? 2 : 1);
-  while (rows > 1 && rows > args.j_per_block) rows /= 2;
-  args.tile_bytes = (int)tile;
-  const size_t lds = tile * (size_t)rows;
+  args.xcd_remap = cfg.xcd_remap;
+  const int np_needed = cfg.np_needed;
+  const int rows = cfg.rows;
+  args.tile_bytes = (int)cfg.tile;
+  const size_t lds = cfg.lds;
 
   auto go3 = [&](auto k_tag, auto np_tag, auto nt_tag, auto r_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;

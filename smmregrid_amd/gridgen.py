@@ -248,10 +248,19 @@ def _sort_links(src_addr, dst_addr, w):
     return src_addr[order], dst_addr[order], w[order]
 
 
-def bilinear_weights(src, dst):
+def _unit_vectors(lon, lat):
+    lam, phi = np.radians(lon), np.radians(lat)
+    return np.stack([np.cos(phi) * np.cos(lam), np.cos(phi) * np.sin(lam), np.sin(phi)], axis=1)
+
+
+def bilinear_weights(src, dst, src_mask=None):
     """4-point bilinear from a regular lon/lat source (periodic in longitude,
     clamped at the first/last latitude row) to the destination cell centres.
-    Four links per destination cell, zero weights kept (as CDO's genbil does)."""
+    Without a mask: four links per destination cell, zero weights kept (as CDO's genbil does).
+    With ``src_mask`` (0 = masked source cell, e.g. land): masked corners are dropped and the
+    weights of the remaining corners renormalised to sum to 1; a destination cell whose four
+    corners are all masked gets no link (the apply path then yields NaN for it through
+    ``dst_grid_imask``, weights.py:47-52).  CDO's genbil likewise never links a masked source cell."""
     src, dst = parse_grid(src), parse_grid(dst)
     if src.kind != "regular":
         raise ValueError("bilinear generation needs a regular source grid")
@@ -269,28 +278,49 @@ def bilinear_weights(src, dst):
     src4 = np.stack([j0 * nx + i0, j0 * nx + i1, j1 * nx + i0, j1 * nx + i1], axis=1)
     w4 = np.stack([(1 - fx) * (1 - fy), fx * (1 - fy), (1 - fx) * fy, fx * fy], axis=1)
     order = np.argsort(src4, axis=1, kind="stable")      # links sorted by (dst, src) as CDO stores them
-    src_addr = (np.take_along_axis(src4, order, axis=1).ravel() + 1).astype(np.int32)
-    w = np.take_along_axis(w4, order, axis=1).ravel()
-    dst_addr = np.repeat(np.arange(1, lon.size + 1, dtype=np.int32), 4)
-    return _scrip_dataset(src, dst, src_addr, dst_addr, w, "bil")
+    src4 = np.take_along_axis(src4, order, axis=1)
+    w4 = np.take_along_axis(w4, order, axis=1)
+    dst4 = np.repeat(np.arange(1, lon.size + 1, dtype=np.int32)[:, None], 4, axis=1)
+    if src_mask is None:
+        return _scrip_dataset(src, dst, (src4.ravel() + 1).astype(np.int32), dst4.ravel(), w4.ravel(), "bil")
+    imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+    if imask.size != src.size:
+        raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+    valid = imask[src4] != 0
+    wv = np.where(valid, w4, 0.0)
+    tot = wv.sum(axis=1)
+    # valid corners that all carry weight 0 (the point sits on a masked node): share equally
+    flat = (tot == 0.0) & valid.any(axis=1)
+    wv[flat] = valid[flat] / valid[flat].sum(axis=1, keepdims=True)
+    tot[flat] = 1.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        wv = wv / tot[:, None]
+    return _scrip_dataset(src, dst, (src4[valid] + 1).astype(np.int32), dst4[valid], wv[valid], "bil",
+                          src_imask=imask)
 
 
-def nearest_weights(src, dst):
-    """Nearest source cell (regular source), one link of weight 1 per destination."""
+def nearest_weights(src, dst, src_mask=None):
+    """Nearest source cell, one link of weight 1 per destination.  With ``src_mask`` the nearest
+    UNMASKED cell is taken (CDO's gennn searches unmasked cells only)."""
     src, dst = parse_grid(src), parse_grid(dst)
-    if src.kind != "regular":
-        # cell-centre list (HEALPix, unstructured): nearest by great-circle distance == nearest by
-        # chord length between unit vectors
+    imask = None
+    if src_mask is not None:
+        imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+        if imask.size != src.size:
+            raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+    if src.kind != "regular" or imask is not None:
+        # cell-centre list (HEALPix, unstructured) or masked source: nearest by great-circle
+        # distance == nearest by chord length between unit vectors
         from scipy.spatial import cKDTree
-
-        def unit(lon, lat):
-            lam, phi = np.radians(lon), np.radians(lat)
-            return np.stack([np.cos(phi) * np.cos(lam), np.cos(phi) * np.sin(lam), np.sin(phi)], axis=1)
         slon, slat = src.centers()
         lon, lat = dst.centers()
-        _, idx = cKDTree(unit(slon, slat)).query(unit(lon, lat), k=1)
+        cells = np.arange(src.size, dtype=np.int64) if imask is None else np.flatnonzero(imask)
         d = np.arange(lon.size, dtype=np.int64)
-        return _scrip_dataset(src, dst, idx.astype(np.int64) + 1, d + 1, np.ones(lon.size), "nn")
+        if cells.size == 0:
+            return _scrip_dataset(src, dst, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0), "nn",
+                                  src_imask=imask)
+        _, idx = cKDTree(_unit_vectors(slon[cells], slat[cells])).query(_unit_vectors(lon, lat), k=1)
+        return _scrip_dataset(src, dst, cells[idx] + 1, d + 1, np.ones(lon.size), "nn", src_imask=imask)
     nx, ny = src.lon.size, src.lat.size
     lon, lat = dst.centers()
     dlon = 360.0 / nx
@@ -384,9 +414,9 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     if method in ("con", "ycon"):
         ds = conservative_weights(src, dst, src_mask=src_mask, norm=norm)
     elif method == "bil":
-        ds = bilinear_weights(src, dst)
+        ds = bilinear_weights(src, dst, src_mask=src_mask)
     elif method == "nn":
-        ds = nearest_weights(src, dst)
+        ds = nearest_weights(src, dst, src_mask=src_mask)
     else:
         raise ValueError(f"method '{method}' is not available without the cdo binary "
                          "(native generator: con, ycon, bil, nn)")

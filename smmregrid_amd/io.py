@@ -166,7 +166,7 @@ def _cf_coordinates(ds):
     return ds
 
 
-def _open_netcdf4_h5py(h5py, path):
+def _open_netcdf4_h5py(h5py, path, decode=True):
     """NetCDF-4 (HDF5) weights through h5py: variables, their dimension names (from the
     dimension scales netCDF attaches), global and variable attributes."""
     def text(v):
@@ -191,8 +191,15 @@ def _open_netcdf4_h5py(h5py, path):
                 has_scale = len(var.dims[i]) > 0
                 dims.append(var.dims[i][0].name.split("/")[-1] if has_scale
                             else (name if is_scale else f"{name}_dim{i}"))
-            arr = DataArray(np.asarray(var[...]), dims=dims, name=name,
-                            attrs={k: text(v) for k, v in var.attrs.items() if k not in skip})
+            attrs = {k: text(v) for k, v in var.attrs.items() if k not in skip}
+            values = np.asarray(var[...])
+            if decode and values.dtype.kind in "fiu":
+                # same CF decoding as the NetCDF-3 and built-in HDF5 readers: the field must not depend
+                # on which optional package happens to be installed
+                values = _cf_decode(values, attrs)
+                for k in ("_FillValue", "missing_value", "scale_factor", "add_offset"):
+                    attrs.pop(k, None)
+            arr = DataArray(values, dims=dims, name=name, attrs=attrs)
             if is_scale and dims == [name]:
                 ds.coords[name] = arr
             else:

@@ -17,6 +17,17 @@ def _cptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _launch_info(fn, handle, dt, sizes, flags):
+    ints = [ctypes.c_int(0) for _ in range(5)]
+    nb, lds = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.call(fn, handle, dt, *sizes, int(flags), ctypes.byref(ints[0]), ctypes.byref(ints[1]),
+              ctypes.byref(ints[2]), ctypes.byref(ints[3]), ctypes.byref(nb), ctypes.byref(lds),
+              ctypes.byref(ints[4]))
+    return {"kernel": "tile" if ints[0].value else "sell", "j_per_block": ints[1].value,
+            "rows_per_step": ints[2].value, "rows_per_block": ints[3].value, "n_blocks": nb.value,
+            "lds_bytes": lds.value, "big_operator": bool(ints[4].value)}
+
+
 class SparseOperator:
     """(S x D) weights matrix in HBM, built from SCRIP links (weights.py:25-44)."""
 
@@ -126,6 +137,11 @@ class SparseOperator:
         return {"tile_plan": bool(kind.value & 1), "tile_preferred": bool(kind.value & 2),
                 "lds_bytes": lds.value, "staged_src_elems": staged.value, "rows_per_block": kind.value >> 8}
 
+    def launch_info(self, n_batch, dtype=np.float64, flags=0):
+        """Launch geometry `apply` would use for `n_batch` rows (nothing is launched)."""
+        return _launch_info("smm_operator_launch_info", self.handle, dtype_code(np.dtype(dtype)),
+                            (int(n_batch),), flags)
+
     def mask_apply(self, src_imask):
         """weights.py:47-52 on the device: (src_imask . W) < 0.5 ? 0 : 1."""
         src = np.ascontiguousarray(src_imask, dtype=np.int32).ravel()
@@ -219,6 +235,28 @@ class OperatorGroup:
     def __getitem__(self, i):
         return self.operators[i]
 
+    def _level_args(self, level_index, masked_levels, n_lev=None):
+        lev = np.ascontiguousarray(level_index, dtype=np.int32).ravel()
+        if n_lev is not None and lev.size != n_lev:
+            raise ValueError("level_index must have one entry per data level")
+        ml = None
+        if masked_levels is not None:
+            ml = np.ascontiguousarray(masked_levels, dtype=np.uint8).ravel()
+            if ml.size != len(self.operators):
+                raise ValueError("masked_levels must have one entry per group member")
+        return lev, ml
+
+    def prepare(self, level_index, masked_levels=None):
+        """Upload one (level_index, masked_levels) configuration ahead of time: later `apply`
+        calls with it allocate nothing and never block (smm_group_prepare)."""
+        lev, ml = self._level_args(level_index, masked_levels)
+        _lib.call("smm_group_prepare", self.handle, lev.size, _cptr(lev), _cptr(ml))
+        return self
+
+    def launch_info(self, n_outer, n_lev, n_inner=1, dtype=np.float64, flags=0):
+        return _launch_info("smm_group_launch_info", self.handle, dtype_code(np.dtype(dtype)),
+                            (int(n_outer), int(n_lev), int(n_inner)), flags)
+
     def apply(self, x, level_index, masked_levels=None, y=None, masked=False, remap_area_min=0.0,
               transpose=True, out_dtype=np.float64, flags=0, stream=None):
         """x: DeviceArray (n_outer, n_lev, n_inner, S).  Returns
@@ -228,14 +266,7 @@ class OperatorGroup:
             raise ValueError(f"X must be a DeviceArray (n_outer, n_lev, n_inner, {self.n_src})")
         n_outer, n_lev, n_inner, S = x.shape
         D = self.n_dst
-        lev = np.ascontiguousarray(level_index, dtype=np.int32).ravel()
-        if lev.size != n_lev:
-            raise ValueError("level_index must have one entry per data level")
-        ml = None
-        if masked_levels is not None:
-            ml = np.ascontiguousarray(masked_levels, dtype=np.uint8).ravel()
-            if ml.size != len(self.operators):
-                raise ValueError("masked_levels must have one entry per group member")
+        lev, ml = self._level_args(level_index, masked_levels, n_lev)
         if transpose:
             shape = (n_outer, n_inner, n_lev, D)
             ys = (n_inner * n_lev * D, D, n_lev * D)          # (outer, lev, inner) strides
@@ -265,14 +296,7 @@ class OperatorGroup:
         if x.ndim != 4 or x.shape[3] != self.n_src:
             raise ValueError(f"X must be (n_outer, n_lev, n_inner, {self.n_src}), got {x.shape}")
         n_outer, n_lev, n_inner, _ = x.shape
-        lev = np.ascontiguousarray(level_index, dtype=np.int32).ravel()
-        if lev.size != n_lev:
-            raise ValueError("level_index must have one entry per data level")
-        ml = None
-        if masked_levels is not None:
-            ml = np.ascontiguousarray(masked_levels, dtype=np.uint8).ravel()
-            if ml.size != len(self.operators):
-                raise ValueError("masked_levels must have one entry per group member")
+        lev, ml = self._level_args(level_index, masked_levels, n_lev)
         shape = (n_outer, n_inner, n_lev, self.n_dst) if transpose else (n_lev, n_outer, n_inner, self.n_dst)
         out = np.empty(shape, dtype=out_dtype)
         fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)

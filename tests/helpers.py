@@ -64,3 +64,42 @@ def assert_same(y, ref, rtol=1e-6, exact=False):
             "values are not bit identical"
     else:
         np.testing.assert_allclose(y[~ny], ref[~nr], rtol=rtol, atol=0.0)
+
+
+def reorder_links(rng, src, dst, w, split_frac=0.3):
+    """The same weights matrix written as a different link list: a random share of the links is
+    split into two or three duplicate (dst, src) entries whose weights add up to the original,
+    then all links are shuffled.  sparse.COO sums duplicates and sorts coordinates
+    (weights.py:37-39), so every such list describes one matrix; only the order in which the
+    duplicates are summed, and possibly the product's summation order, may differ."""
+    src, dst, w = np.asarray(src), np.asarray(dst), np.asarray(w, dtype=np.float64)
+    pick = rng.random(src.size) < split_frac
+    parts = rng.integers(2, 4, size=src.size)
+    s_out, d_out, w_out = [src[~pick]], [dst[~pick]], [w[~pick]]
+    for k in (2, 3):
+        m = pick & (parts == k)
+        cuts = np.sort(rng.random((int(m.sum()), k - 1)), axis=1)
+        edges = np.concatenate([np.zeros((cuts.shape[0], 1)), cuts, np.ones((cuts.shape[0], 1))], axis=1)
+        share = np.diff(edges, axis=1) * w[m][:, None]          # k pieces summing to w (to rounding)
+        s_out.append(np.repeat(src[m], k))
+        d_out.append(np.repeat(dst[m], k))
+        w_out.append(share.ravel())
+    s2, d2, w2 = np.concatenate(s_out), np.concatenate(d_out), np.concatenate(w_out)
+    perm = rng.permutation(s2.size)
+    return s2[perm].astype(np.int32), d2[perm].astype(np.int32), w2[perm]
+
+
+def max_rel_spread(outputs):
+    """NaN patterns of all outputs must agree; returns the largest relative difference between
+    any output and the first over the finite cells."""
+    base = np.asarray(outputs[0])
+    nan0 = np.isnan(base)
+    worst = 0.0
+    for y in outputs[1:]:
+        y = np.asarray(y)
+        assert np.array_equal(np.isnan(y), nan0), "NaN pattern depends on the link order"
+        ok = ~nan0
+        denom = np.maximum(np.abs(base[ok]), np.finfo(np.float64).tiny)
+        if ok.any():
+            worst = max(worst, float(np.max(np.abs(y[ok] - base[ok]) / denom)))
+    return worst

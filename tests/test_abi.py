@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.smm_abi_version() == 1
+    assert lib.smm_abi_version() == 2
     assert isinstance(lib.smm_last_error(), (bytes, type(None)))
 
 
@@ -53,3 +53,26 @@ def test_no_cpu_fallback_without_device():
     with pytest.raises(_lib.SmmNoDeviceError):
         SparseOperator(4, 4, np.array([1], np.int32), np.array([1], np.int32), np.array([1.0]),
                        device=0)
+
+
+def test_missing_rccl_is_unsupported_not_a_crash():
+    """smm_comm_* with no loadable librccl (SMM_RCCL_LIB points nowhere) returns SMM_ERR_UNSUPPORTED
+    with the loader's message (round 1 called dlerror() twice and dereferenced NULL)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from smmregrid_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "rc = lib.smm_comm_unique_id(buf)\n"
+        "h = ctypes.c_void_p()\n"
+        "rc2 = lib.smm_comm_create(buf, 1, 0, ctypes.byref(h))\n"
+        "print(rc, rc2, lib.smm_last_error().decode())\n" % ROOT)
+    env = dict(os.environ, SMM_RCCL_LIB="/nonexistent/librccl.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, rc2, msg = out.stdout.strip().split(" ", 2)
+    assert int(rc) == _lib.SMM_ERR_UNSUPPORTED and int(rc2) == _lib.SMM_ERR_UNSUPPORTED
+    assert "cannot load librccl" in msg and "nonexistent" in msg

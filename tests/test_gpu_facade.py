@@ -442,3 +442,37 @@ def test_out_dtype_float32_is_the_rounded_float64_result(hip, rng):
     assert y32.dtype == np.float32 and np.array_equal(y32, y64.astype(np.float32))
     with pytest.raises(ValueError):
         Regridder(weights=w, out_dtype=np.int32)
+
+
+@pytest.mark.parametrize("method", ["bil", "nn"])
+def test_masked_source_with_pointwise_methods(hip, rng, method):
+    """A land/sea-masked field (NaN over land) regridded with bil / nn: the generator must keep masked
+    source cells out of the links (as cdo genbil / gennn do), otherwise a bilinear corner of weight
+    < 0.1 on a NaN cell adds w * 1e20 < 1e19, passes the `> 1e19 -> NaN` test of regrid.py:570 and
+    reaches the output as data.  Every output value is NaN or inside the range of the data."""
+    g = gridgen.parse_grid("r96x48")
+    x = (280.0 + 10.0 * rng.standard_normal((3, g.lat.size, g.lon.size)))
+    land = np.zeros((g.lat.size, g.lon.size), bool)
+    land[10:30, 20:50] = True                                  # a continent
+    land[35:38, 70:72] = True                                  # an island
+    land |= rng.random(land.shape) < 0.03                      # scattered single cells
+    x[:, land] = np.nan
+    field = DataArray(x, dims=("time", "lat", "lon"), coords={"time": np.arange(3), "lat": g.lat, "lon": g.lon},
+                      name="tos")
+    gen = CdoGenerate(field, "r60x30")
+    w = gen.weights(method=method)
+    assert np.array_equal(w["src_grid_imask"].values, (~land).ravel().astype(np.int32))
+    assert (w["src_grid_imask"].values[w["src_address"].values - 1] == 1).all()   # no link onto land
+    out = Regridder(weights=w, device=0).regrid(field).values
+    lo, hi = np.nanmin(x), np.nanmax(x)
+    ok = ~np.isnan(out)
+    assert ok.any() and (out[ok] >= lo - 1e-9).all() and (out[ok] <= hi + 1e-9).all()
+    if method == "bil":
+        assert np.isnan(out).any()                             # the continent's interior has no valid corner
+        rows = np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0], minlength=1800)
+        has = np.bincount(w["dst_address"].values - 1, minlength=1800) > 0
+        np.testing.assert_allclose(rows[has], 1.0, rtol=1e-12)  # renormalised over the valid corners
+    else:
+        assert not np.isnan(out).any()                         # nearest unmasked cell always exists
+    ref = oracle_2d(w, x.reshape(3, -1))
+    assert_same(out.reshape(3, -1), ref, exact=True)

@@ -125,3 +125,34 @@ def test_bad_files_fail_loudly(tmp_path):
     e.write_bytes(b"")
     with pytest.raises(hdf5lite.H5Error):
         hdf5lite.File(str(e))
+
+
+def test_h5py_reader_and_builtin_reader_decode_alike():
+    """io.open_weights prefers h5py when it is importable: both NetCDF-4 readers must hand the same
+    decoded field (CF _FillValue / missing_value -> NaN, scale_factor / add_offset) to the regridder.
+    h5py lives only in the image's second interpreter, so the comparison runs there."""
+    import shutil
+    import subprocess
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import h5py, numpy"], capture_output=True).returncode:
+        pytest.skip("no interpreter with h5py on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, glob, numpy as np, h5py\n"
+        "sys.path.insert(0, %r)\n"
+        "from smmregrid_amd import io\n"
+        "n = 0\n"
+        "for f in sorted(glob.glob(%r)):\n"
+        "    a, b = io._open_netcdf4_h5py(h5py, f), io._open_netcdf4_lite(f)\n"
+        "    assert sorted(a._vars) == sorted(b._vars), f\n"
+        "    for k in a._vars:\n"
+        "        x, y = np.asarray(a._vars[k].values), np.asarray(b._vars[k].values)\n"
+        "        assert x.dtype == y.dtype and x.shape == y.shape, (f, k, x.dtype, y.dtype)\n"
+        "        assert np.array_equal(x, y, equal_nan=(x.dtype.kind == 'f')), (f, k)\n"
+        "        assert a._vars[k].dims == b._vars[k].dims and set(a._vars[k].attrs) == set(b._vars[k].attrs), (f, k)\n"
+        "        assert not ({'_FillValue', 'missing_value', 'scale_factor', 'add_offset'} & set(a._vars[k].attrs))\n"
+        "        n += 1\n"
+        "print('compared', n)\n" % (root, os.path.join(root, "tests", "golden", "refdata", "*.nc")))
+    out = subprocess.run([py, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("compared") and int(out.stdout.split()[1]) >= 4

@@ -182,3 +182,41 @@ def test_north_to_south_latitudes_give_the_same_regrid(rng, method):
     xx = rng.standard_normal((1, 72 * 36))
     np.testing.assert_allclose(regrid(wt, xx).reshape(12, 24)[::-1], regrid(wr, xx).reshape(12, 24), rtol=1e-12)
     np.testing.assert_allclose(np.degrees(wt["dst_grid_center_lat"].values[:24]), 82.5)
+
+
+def test_pointwise_generators_honour_the_source_mask(rng):
+    """bil / nn with a land mask: no link may touch a masked source cell (cdo genbil / gennn exclude
+    them); bilinear weights are renormalised over the valid corners; cells without a valid corner
+    get no link; nn picks the nearest unmasked cell; src_grid_imask is written."""
+    from smmregrid_amd import gridgen
+    src, dst = "r72x36", "r40x20"
+    mask = (rng.random(72 * 36) > 0.35).astype(np.int32)
+    mask.reshape(36, 72)[8:20, 10:30] = 0
+    for method in ("bil", "nn"):
+        w = gridgen.generate_weights(src, dst, method=method, src_mask=mask)
+        sa, da, wt = w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values[:, 0]
+        assert np.array_equal(w["src_grid_imask"].values, mask)
+        assert (mask[sa - 1] == 1).all()
+        rows = np.bincount(da - 1, weights=wt, minlength=800)
+        has = np.bincount(da - 1, minlength=800) > 0
+        np.testing.assert_allclose(rows[has], 1.0, rtol=1e-12)
+        assert (wt >= 0).all()
+        if method == "nn":
+            assert has.all() and sa.size == 800
+        else:
+            assert not has.all()                      # interior of the masked block
+            full = gridgen.generate_weights(src, dst, method="bil")
+            # where all four corners are valid the masked and unmasked weights coincide
+            f_sa = full["src_address"].values.reshape(800, 4)
+            all_valid = (mask[f_sa - 1] == 1).all(axis=1)
+            keep = np.isin(da - 1, np.flatnonzero(all_valid))
+            assert np.array_equal(sa[keep], f_sa[all_valid].ravel())
+            np.testing.assert_array_equal(wt[keep], full["remap_matrix"].values[:, 0].reshape(800, 4)[all_valid].ravel())
+    # north-to-south source files: the mask is given in file order
+    g = gridgen.parse_grid(src)
+    import copy
+    gd = copy.copy(g)
+    gd.lat_descending = True
+    wd = gridgen.generate_weights(gd, dst, method="bil", src_mask=mask)
+    assert np.array_equal(wd["src_grid_imask"].values, mask)
+    assert (mask[wd["src_address"].values - 1] == 1).all()

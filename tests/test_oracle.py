@@ -249,3 +249,26 @@ def test_oracle_matches_reference_dask_statements(tag):
     # the float32 field was filled with float32(1e20), not 1e20: a 0.05-weight link to a missing
     # value stays finite and carries exactly that constant
     assert np.isfinite(z["y_float32_m0_a0"]).any()
+
+
+def test_oracle_output_independent_of_link_order(rng):
+    """Same matrix, differently ordered / split link lists (what sparse.COO would canonicalise,
+    weights.py:37-39): both restatements give the same CSR structure and outputs within 1e-12."""
+    from smmregrid_amd import gridgen
+    from tests.helpers import field, max_rel_spread, reorder_links
+    w = gridgen.conservative_weights("r144x72", "r48x24")
+    n_src, n_dst = 144 * 72, 48 * 24
+    src, dst, ww = w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values[:, 0]
+    x = field(rng, 5, n_src, nan_frac=0.01)
+    outs_c, outs_py, structs = [], [], []
+    for k in range(6):
+        s2, d2, w2 = (src, dst, ww) if k == 0 else reorder_links(rng, src, dst, ww)
+        csr_c = oracle.coo_to_csr_c(n_src, n_dst, s2, d2, w2)
+        csr_py = oracle.coo_to_csr(n_src, n_dst, s2, d2, w2)
+        assert np.array_equal(csr_c[0], csr_py[0]) and np.array_equal(csr_c[1], csr_py[1])
+        structs.append((csr_c[0], csr_c[1]))
+        outs_c.append(oracle.apply_c(csr_c, x, False, None, w["dst_grid_frac"].values, 0.5))
+        outs_py.append(oracle.apply(csr_py, x, False, None, w["dst_grid_frac"].values, 0.5))
+    for st in structs[1:]:
+        assert np.array_equal(st[0], structs[0][0]) and np.array_equal(st[1], structs[0][1])
+    assert max_rel_spread(outs_c + outs_py) <= 1e-12
