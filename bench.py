@@ -7,7 +7,11 @@ One "step" = one pass of the hot path over the whole batch of the workload.
 Default workload = config 2 of BASELINE.json (the configuration the metric is
 quoted on): r1440x721 -> r360x180 bilinear, 3600 time steps, f64, X and Y
 resident in HBM.  Other workloads (--workload): cfg3 (masked ocean levels,
-grouped launch), cfg5tile (config-5 geometry, one GPU's share of rows), cfg1.
+grouped launch), cfg5tile (config-5 geometry, one GPU's share of rows), cfg1,
+cfg2sb / cfg2sbp (config 2 with the field kept batch-fastest, X (S, B) or packed
+(U, B), Y still (B, D): the opt-in operand layout for device-resident producers),
+cfg4 / cfg5 (one GPU's share of BASELINE configs 4 / 5: with --gpus 8 these are the
+fixed-total-batch lines of BASELINE.json).
 
 For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
 regrids its own full-size shard of the time axis (weak scaling; batch rows are
@@ -38,6 +42,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 WORKLOADS = {
     # name: (method, source grid, target grid, batch rows, x dtype)
     "cfg2": ("bil", "r1440x721", "r360x180", 3600, "f64"),
+    # config 2 with the operand kept batch-fastest by a device-resident producer (smm_apply_sb):
+    # "sb" = X (S, B), "sbp" = X (U, B) holding only the used source cells
+    "cfg2sb": ("bil", "r1440x721", "r360x180", 3600, "f64", "sb"),
+    "cfg2sbp": ("bil", "r1440x721", "r360x180", 3600, "f64", "sbp"),
+    "cfg5sb": ("con", "r1440x721", "r720x360", 1024, "f64", "sb"),
+    "conmidsb": ("con", "r1440x720", "r360x180", 1024, "f64", "sb"),
     "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
     "upsample": ("bil", "r360x180", "r1440x721", 1024, "f64"),    # coarse -> fine: Y-write bound
     "nnhi": ("nn", "r3600x1800", "r360x180", 256, "f64"),          # 1 link per row, 1 of 100 source cells used
@@ -99,7 +109,8 @@ class Problem2D:
     def __init__(self, name, device, rank, batch=None):
         from smmregrid_amd import SparseOperator, gridgen
         from smmregrid_amd.device import DeviceArray
-        method, sgrid, tgrid, n_batch, self.x_dtype = WORKLOADS[name]
+        method, sgrid, tgrid, n_batch, self.x_dtype = WORKLOADS[name][:5]
+        self.layout = WORKLOADS[name][5] if len(WORKLOADS[name]) > 5 else "bs"
         self.n_batch = batch or n_batch
         if method == "conmask":
             nx, ny, frac = sgrid
@@ -118,11 +129,16 @@ class Problem2D:
                                  w["dst_address"].values, w["remap_matrix"].values, device=device)
         self.op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
         self.np_dt = np.float64 if self.x_dtype == "f64" else np.float32
-        self.x = DeviceArray((self.n_batch, self.n_src), self.np_dt)
+        x_shape = {"bs": (self.n_batch, self.n_src), "sb": (self.n_src, self.n_batch),
+                   "sbp": (self.op.n_used_src, self.n_batch)}[self.layout]
+        self.x = DeviceArray(x_shape, self.np_dt)
         self.x.fill_random(seed=20260723 + 1000003 * rank, mean=250.0, sigma=30.0)
+        if self.layout != "bs":
+            self.op.prepare_sb()
         self.y_shape = (self.n_batch, self.n_dst)
+        lay = {"bs": "X (B, S) native layout", "sb": "X (S, B) batch-fastest", "sbp": "X (U, B) batch-fastest, used cells only"}
         self.desc = (f"{name}: {sgrid}->{tgrid} {method}, {self.n_batch} batch rows per GPU, "
-                     f"{self.x_dtype} in / f64 out, X and Y resident in HBM")
+                     f"{self.x_dtype} in / f64 out, {lay[self.layout]}, Y (B, D), X and Y resident in HBM")
         self.meta = {"S": self.n_src, "D": self.n_dst, "nnz": self.op.nnz, "U": self.op.n_used_src,
                      "plan": self.op.plan_info()}
 
@@ -138,22 +154,39 @@ class Problem2D:
     def line_bytes(self):
         """Bytes of the whole 128-B source lines the links touch (what any kernel must move
         from HBM in the native (B, S) layout) + Y + the operator once."""
+        if self.layout != "bs":
+            return None                   # batch-fastest: every needed cell is a contiguous run
         staged = self.op.plan_info()["staged_src_elems"]
         if not staged:
             return None
         return self.n_batch * (staged * np.dtype(self.np_dt).itemsize + self.n_dst * 8) + self.op.nnz * 12
 
     def run(self, y, flags):
-        self.op.apply(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags)
+        if self.layout == "bs":
+            self.op.apply(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags)
+        else:
+            self.op.apply_sb(self.x, y=y, masked=False, remap_area_min=0.5, packed=self.layout == "sbp",
+                             flags=flags)
 
     def run_rows(self, y, flags, r0, r1):
         """The same product restricted to batch rows [r0, r1) (one tile of the overlapped gather)."""
-        self.op.apply(self.x.rows(r0, r1), y=y.rows(r0, r1), masked=False, remap_area_min=0.5, flags=flags)
+        if self.layout == "bs":
+            self.op.apply(self.x.rows(r0, r1), y=y.rows(r0, r1), masked=False, remap_area_min=0.5, flags=flags)
+            return
+        import ctypes
+        from smmregrid_amd import _lib
+        from smmregrid_amd.device import dtype_code
+        isz = np.dtype(self.np_dt).itemsize          # batch rows are a column range of the (S, B) field
+        fl = flags | (_lib.APPLY_SB_PACKED if self.layout == "sbp" else 0)
+        _lib.call("smm_apply_sb", self.op.handle, ctypes.c_void_p(self.x.ptr + r0 * isz), dtype_code(self.x.dtype),
+                  self.n_batch, ctypes.c_void_p(y.rows(r0, r1).ptr), dtype_code(y.dtype), self.n_dst, r1 - r0,
+                  0.5, fl, None)
 
     def cpu_baseline(self, budget_s):
-        """Oracle (C port of regrid.py:545-570, OpenMP over batch rows) on a bounded sample:
-        a block of distinct batch rows of the same workload, passed repeatedly until about
-        `budget_s` seconds of CPU work have been timed."""
+        """The reference's step sequence (regrid.py:545-570) on this host's cores, over a bounded
+        sample of the same workload (a block of distinct batch rows passed repeatedly).  Three legs
+        (SURVEY 8d): numpy + scipy.sparse on one core, oracle/oracle.c with OpenMP on this GPU's CPU
+        share (16 threads) and on every core the process may use."""
         from oracle import oracle
         w = self.weights
         csr = oracle.coo_to_csr_c(self.n_src, self.n_dst, w["src_address"].values,
@@ -165,17 +198,36 @@ class Problem2D:
         for r in range(rows):
             x[r] = 250.0 + 30.0 * rng.standard_normal(self.n_src, dtype=self.np_dt)
         frac = w["dst_grid_frac"].values
-        oracle.apply_c(csr, x[:threads], False, None, frac, 0.5, threads=threads)  # warm the team
-        passes, spent = 0, 0.0
-        while spent < budget_s and passes < 1000:
-            t0 = time.perf_counter()
-            oracle.apply_c(csr, x, False, None, frac, 0.5, threads=threads)
-            spent += time.perf_counter() - t0
-            passes += 1
-        return {"value": passes * rows * self.n_dst / spent, "unit": "cells/s", "cores": threads,
-                "kind": "port",
-                "sample": f"{rows} of {self.n_batch} batch rows x {passes} passes, oracle/oracle.c "
-                          f"(OpenMP over rows, {threads} threads of {avail} visible), {spent:.1f} s"}
+
+        def timed(fn, n_rows, budget, max_passes=1000):
+            passes, spent = 0, 0.0
+            while spent < budget and passes < max_passes:
+                t0 = time.perf_counter()
+                fn()
+                spent += time.perf_counter() - t0
+                passes += 1
+            return passes * n_rows * self.n_dst / spent, passes, spent
+
+        legs = []
+        # (i) numpy + scipy.sparse, single thread: the closest stand-in for the reference's own
+        # single-threaded per-block product
+        srows = min(rows, 32)
+        v, p, t = timed(lambda: oracle.apply(csr, x[:srows], False, None, frac, 0.5), srows, budget_s * 0.25, 50)
+        legs.append({"value": v, "unit": "cells/s", "cores": 1, "kind": "port",
+                     "impl": "oracle/oracle.py (numpy + scipy.sparse CSR product)",
+                     "sample": f"{srows} of {self.n_batch} batch rows x {p} passes, {t:.1f} s"})
+        # (ii) C port with OpenMP over batch rows: this GPU's CPU share, then every visible core
+        for nt in sorted({threads, avail}):
+            oracle.apply_c(csr, x[:min(rows, nt)], False, None, frac, 0.5, threads=nt)  # warm the team
+            v, p, t = timed(lambda: oracle.apply_c(csr, x, False, None, frac, 0.5, threads=nt), rows,
+                            budget_s * 0.375)
+            legs.append({"value": v, "unit": "cells/s", "cores": nt, "kind": "port",
+                         "impl": "oracle/oracle.c (OpenMP over batch rows)",
+                         "sample": f"{rows} of {self.n_batch} batch rows x {p} passes, {nt} threads of "
+                                   f"{avail} visible (os.cpu_count() = {os.cpu_count()}), {t:.1f} s"})
+        best = max(legs, key=lambda leg: leg["value"])
+        return {"value": best["value"], "unit": "cells/s", "cores": best["cores"], "kind": "port",
+                "sample": best["impl"] + ": " + best["sample"], "legs": legs}
 
 
 class ProblemLevels:
@@ -185,7 +237,7 @@ class ProblemLevels:
         from smmregrid_amd import OperatorGroup, gridgen
         from smmregrid_amd.device import DeviceArray
         from smmregrid_amd.weights import compute_weights_matrix3d
-        _, (nx, ny), tgrid, (n_t, n_lev), self.x_dtype = WORKLOADS[name]
+        _, (nx, ny), tgrid, (n_t, n_lev), self.x_dtype = WORKLOADS[name][:5]
         self.n_t, self.n_lev = batch or n_t, n_lev
         src = gridgen.regular_grid(nx, ny, name=f"tripolar-like {nx}x{ny}")
         masks = gridgen.synthetic_ocean_masks(nx, ny, n_lev)
@@ -246,25 +298,42 @@ class ProblemLevels:
                          masked=True, remap_area_min=0.5, transpose=True, flags=flags)
 
     def cpu_baseline(self, budget_s):
+        """Same three legs as Problem2D.cpu_baseline, level by level as regrid.py:387-418 loops."""
         from oracle import oracle
         threads, avail = cpu_threads()
         csrs = [op.export_csr() for op in self.ops]
         frac = self.weights["dst_grid_frac"].values
-        t_rows = max(threads, 16)
-        passes, spent = 0, 0.0
-        x = np.broadcast_to(self.slab[None], (t_rows,) + self.slab.shape)
-        while spent < budget_s and passes < 100:
-            t0 = time.perf_counter()
+
+        def one_pass(t_rows, fn, **kw):
+            x = np.broadcast_to(self.slab[None], (t_rows,) + self.slab.shape)
             for lv in range(self.n_lev):
-                oracle.apply_c(csrs[lv], np.ascontiguousarray(x[:, lv]), bool(self.masked_levels[lv]),
-                               self.dst_imask[lv], frac[lv], 0.5, threads=threads)
-            spent += time.perf_counter() - t0
-            passes += 1
-        return {"value": passes * t_rows * self.n_lev * self.n_dst / spent, "unit": "cells/s",
-                "cores": threads, "kind": "port",
-                "sample": f"{t_rows} of {self.n_t} time steps x {self.n_lev} levels x {passes} passes, "
-                          f"oracle/oracle.c level by level (OpenMP over rows, {threads} threads of "
-                          f"{avail} visible), {spent:.1f} s"}
+                fn(csrs[lv], np.ascontiguousarray(x[:, lv]), bool(self.masked_levels[lv]),
+                   self.dst_imask[lv], frac[lv], 0.5, **kw)
+
+        def timed(t_rows, budget, max_passes, fn, **kw):
+            passes, spent = 0, 0.0
+            while spent < budget and passes < max_passes:
+                t0 = time.perf_counter()
+                one_pass(t_rows, fn, **kw)
+                spent += time.perf_counter() - t0
+                passes += 1
+            return passes * t_rows * self.n_lev * self.n_dst / spent, passes, spent
+
+        legs = []
+        v, p, t = timed(2, budget_s * 0.25, 10, oracle.apply)
+        legs.append({"value": v, "unit": "cells/s", "cores": 1, "kind": "port",
+                     "impl": "oracle/oracle.py (numpy + scipy.sparse CSR product), level by level",
+                     "sample": f"2 of {self.n_t} time steps x {self.n_lev} levels x {p} passes, {t:.1f} s"})
+        for nt in sorted({threads, avail}):
+            t_rows = max(nt, 16)
+            v, p, t = timed(t_rows, budget_s * 0.375, 100, oracle.apply_c, threads=nt)
+            legs.append({"value": v, "unit": "cells/s", "cores": nt, "kind": "port",
+                         "impl": "oracle/oracle.c level by level (OpenMP over rows)",
+                         "sample": f"{t_rows} of {self.n_t} time steps x {self.n_lev} levels x {p} passes, "
+                                   f"{nt} threads of {avail} visible (os.cpu_count() = {os.cpu_count()}), {t:.1f} s"})
+        best = max(legs, key=lambda leg: leg["value"])
+        return {"value": best["value"], "unit": "cells/s", "cores": best["cores"], "kind": "port",
+                "sample": best["impl"] + ": " + best["sample"], "legs": legs}
 
 
 class TorchDist:
@@ -407,6 +476,18 @@ def stream_copy_gbs(nbytes=2 << 30, reps=5):
     return gbs
 
 
+def kernel_source_sha():
+    """sha256 over the device-side sources: ties a replayed PMC figure to the code that produced it."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "smmregrid_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hpp", ".hip", ".cpp", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_threads():
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     return int(os.environ.get("SMM_CPU_THREADS", min(avail, 16))), avail  # 16 = one GPU's CPU share
@@ -496,10 +577,21 @@ def main():
         k_avg = float(np.mean(kernel_ms)) * 1e-3
         b_alg = prob.alg_bytes()
         achieved = b_alg / k_avg / 1e9
-        traffic = None
+        # PMC traffic cannot be collected inside this run (rocprofv3 counter passes are separate
+        # processes): it is replayed from profiles/traffic.json, but only while the kernel sources
+        # are the ones the PMC pass ran (sha recorded by tools/summarize_pmc.py); else null.
+        traffic, traffic_source = None, None
         if args.traffic_json and os.path.exists(args.traffic_json):
             key = f"{args.workload}/{args.batch or 'default'}/{args.kernel}/{args.variant}"
-            traffic = json.load(open(args.traffic_json)).get(key, {}).get("hbm_bytes_per_launch")
+            entry = json.load(open(args.traffic_json)).get(key)
+            if entry:
+                now = kernel_source_sha()
+                fresh = entry.get("kernel_sha") == now
+                traffic = entry.get("hbm_bytes_per_launch") if fresh else None
+                traffic_source = {"file": os.path.relpath(args.traffic_json, ROOT), "key": key,
+                                  "summary": entry.get("source"), "pmc_kernel_sha": entry.get("kernel_sha"),
+                                  "pmc_git_head": entry.get("git_head"), "current_kernel_sha": now,
+                                  "fresh": fresh}
         cfg = {"workload": prob.desc, "kernel": args.kernel,
                "gather": args.gather if comm else "n/a", "comm": args.comm if comm else "n/a", "device": device_name(local_rank)}
         cfg.update(prob.meta)
@@ -519,6 +611,7 @@ def main():
             "config": cfg,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel_ms": k_avg * 1e3, "algorithmic_bytes": b_alg,
                          "full_stream_bytes": prob.full_stream_bytes(),
                          "line_granular_bytes": prob.line_bytes(),

@@ -60,6 +60,7 @@ enum {
 enum {
   SMM_APPLY_MASKED = 1u << 0,   /* apply dst_imask (regrid.py:553-559); per level in a group */
   SMM_APPLY_NO_FILL = 1u << 1,  /* skip the 1e20 fill: the caller guarantees finite X (results are undefined otherwise) */
+  SMM_APPLY_SB_PACKED = 1u << 2, /* smm_apply_sb: X holds only the used source cells (smm_operator_used_sources order) */
   SMM_APPLY_KERNEL_SELL = 1u << 8, /* force the row-per-lane SELL-64 kernel                  */
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };
@@ -208,6 +209,26 @@ int smm_apply(smm_operator_t op,
               const void* x, int x_dtype, int64_t ldx,
               void* y, int y_dtype, int64_t ldy,
               int64_t n_batch, double remap_area_min, unsigned flags, void* stream);
+
+/*
+ * The same product for fields kept BATCH-FASTEST ("SB" layout) by a device-resident producer:
+ *   x : device, (n_src, ldx) -- the n_batch values of source cell s are contiguous at x + s*ldx
+ *       (ldx >= n_batch); with SMM_APPLY_SB_PACKED x holds only the U used source cells, row r =
+ *       the r-th entry of smm_operator_used_sources (ascending source index)
+ *   y : device, (n_batch, ldy) exactly as smm_apply writes it (regrid.py:550 layout)
+ * In the reference's native (B, S) layout a stencil that needs 16-B pairs on a 32-B stride (config
+ * 2: bilinear 4:1) wastes half of every 128-B line fetched; here every needed source cell is one
+ * contiguous run, so HBM traffic equals the algorithmic bytes.  Results are bit-identical to
+ * smm_apply on the transposed field.  The first call on an operator uploads its canonical CSR
+ * (smm_operator_prepare_sb does that ahead of time); afterwards the call allocates nothing.
+ */
+int smm_operator_prepare_sb(smm_operator_t op);
+/* ascending 0-based indices of the n_used_src source cells that carry a link (host int32[n_used_src]) */
+int smm_operator_used_sources(smm_operator_t op, int32_t* used);
+int smm_apply_sb(smm_operator_t op,
+                 const void* x, int x_dtype, int64_t ldx,
+                 void* y, int y_dtype, int64_t ldy,
+                 int64_t n_batch, double remap_area_min, unsigned flags, void* stream);
 
 /*
  * Same product for fields in HOST memory (what Regridder.apply_weights receives,

@@ -22,6 +22,7 @@ SMM_F64 = 1
 
 APPLY_MASKED = 1 << 0
 APPLY_NO_FILL = 1 << 1
+APPLY_SB_PACKED = 1 << 2
 APPLY_KERNEL_SELL = 1 << 8
 APPLY_KERNEL_TILE = 1 << 9
 
@@ -91,6 +92,9 @@ SIGNATURES = {
     "smm_group_destroy": [_p],
     "smm_group_plan_info": [_p, ctypes.POINTER(_int), ctypes.POINTER(_int)],
     "smm_apply": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _p],
+    "smm_operator_prepare_sb": [_p],
+    "smm_operator_used_sources": [_p, _p],
+    "smm_apply_sb": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _p],
     "smm_apply_host": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _i64],
     "smm_group_apply": [_p, _p, _int, _i64, _i64, _i64, _p, _int, _i64, _i64, _i64,
                         _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],

@@ -41,7 +41,8 @@ namespace smm_launch {
 #define SMM_EXTERN_PAIR(XT, YT)                                                                         \
   extern template int launch_sell<XT, YT>(const ApplyArgs&, int64_t, bool, unsigned, hipStream_t);      \
   extern template int launch_tile<XT, YT>(const ApplyArgs&, int64_t, int, int64_t, int64_t, int, bool, \
-                                          unsigned, hipStream_t);
+                                          unsigned, hipStream_t);                                       \
+  extern template int launch_sb<XT, YT>(const SbArgs&, bool, unsigned, hipStream_t);
 SMM_EXTERN_PAIR(double, double)
 SMM_EXTERN_PAIR(double, float)
 SMM_EXTERN_PAIR(float, double)
@@ -169,6 +170,12 @@ struct smm_operator {
   std::mutex plan_mu;
   std::mutex pipe_mu;        // smm_apply_host calls on one operator take turns
   HostPipe pipe;
+  // plain canonical CSR on the device for the batch-fastest kernel, uploaded on first use
+  bool sb_ready = false;
+  int64_t* d_csr_rowptr = nullptr;
+  int32_t* d_csr_col = nullptr;       // source cell
+  int32_t* d_csr_colp = nullptr;      // rank of the source cell among the used cells (packed X)
+  double* d_csr_val = nullptr;
   std::atomic<int> group_refs{0};  // groups borrowing this operator (their descriptors hold its device pointers)
   int native = 0;            // shape of the operator's own plan (choose_native_plan)
   int native_plan() const { return native; }
@@ -260,6 +267,10 @@ void release(smm_operator* op) {
     (void)hipFree(pl.d_blk_direct);
   }
   (void)hipFree(op->d_desc);
+  (void)hipFree(op->d_csr_rowptr);
+  (void)hipFree(op->d_csr_col);
+  (void)hipFree(op->d_csr_colp);
+  (void)hipFree(op->d_csr_val);
   delete op;
 }
 
@@ -296,6 +307,34 @@ int ensure_plan(smm_operator* op, int which) {
 // smm_launch_inst.hip (one object per pair) and only declared here
 using smm_launch::launch_sell;
 using smm_launch::launch_tile;
+using smm_launch::launch_sb;
+
+// Device copy of the canonical CSR (+ packed column ranks) for the batch-fastest kernel.
+int ensure_sb(smm_operator* op) {
+  std::lock_guard<std::mutex> lock(op->plan_mu);
+  if (op->sb_ready) return SMM_OK;
+  const smm::HostCsr& c = op->csr;
+  std::vector<int32_t> rank((size_t)std::max<int64_t>(c.n_src, 1), -1), colp((size_t)c.nnz);
+  for (int32_t s : c.col) rank[(size_t)s] = 0;
+  int32_t r = 0;
+  for (int64_t s = 0; s < c.n_src; ++s)
+    if (rank[(size_t)s] == 0) rank[(size_t)s] = r++;
+  for (int64_t i = 0; i < c.nnz; ++i) colp[(size_t)i] = rank[(size_t)c.col[(size_t)i]];
+  int rc = SMM_OK;
+  if ((rc = upload(&op->d_csr_rowptr, c.rowptr)) || (rc = upload(&op->d_csr_col, c.col)) ||
+      (rc = upload(&op->d_csr_colp, colp)) || (rc = upload(&op->d_csr_val, c.val))) {
+    (void)hipFree(op->d_csr_rowptr);
+    (void)hipFree(op->d_csr_col);
+    (void)hipFree(op->d_csr_colp);
+    (void)hipFree(op->d_csr_val);
+    op->d_csr_rowptr = nullptr;
+    op->d_csr_col = op->d_csr_colp = nullptr;
+    op->d_csr_val = nullptr;
+    return rc;
+  }
+  op->sb_ready = true;
+  return SMM_OK;
+}
 
 struct LaunchInfo {
   bool tile = false, big_operator = false;
@@ -800,6 +839,67 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid,
                    pl.preferred, (pl.reuse ? 1 : 0), pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
+}
+
+int smm_operator_prepare_sb(smm_operator_t op) {
+  if (!op) return fail(SMM_ERR_INVALID, "null operator");
+  DeviceGuard guard(op->device);
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
+  return ensure_sb(op);
+}
+
+int smm_operator_used_sources(smm_operator_t op, int32_t* used) {
+  if (!op) return fail(SMM_ERR_INVALID, "null operator");
+  if (!used && op->csr.n_used_src > 0) return fail(SMM_ERR_INVALID, "null output");
+  std::vector<uint8_t> seen((size_t)std::max<int64_t>(op->csr.n_src, 1), 0);
+  for (int32_t s : op->csr.col) seen[(size_t)s] = 1;
+  int64_t k = 0;
+  for (int64_t s = 0; s < op->csr.n_src; ++s)
+    if (seen[(size_t)s]) used[k++] = (int32_t)s;
+  return SMM_OK;
+}
+
+int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype,
+                 int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags, void* stream) {
+  if (!op) return fail(SMM_ERR_INVALID, "null operator");
+  if (n_batch < 0) return fail(SMM_ERR_INVALID, "negative batch size");
+  if (n_batch == 0 || op->csr.n_dst == 0) return SMM_OK;
+  if (!x || !y) return fail(SMM_ERR_INVALID, "null field pointer");
+  if ((x_dtype != SMM_F32 && x_dtype != SMM_F64) || (y_dtype != SMM_F32 && y_dtype != SMM_F64))
+    return fail(SMM_ERR_UNSUPPORTED, "field dtype must be SMM_F32 or SMM_F64");
+  if (ldx < n_batch || ldy < op->csr.n_dst)
+    return fail(SMM_ERR_INVALID, "ldx smaller than the batch or ldy smaller than the destination grid");
+  if (!(remap_area_min >= 0.0 && remap_area_min <= 1.0))
+    return fail(SMM_ERR_INVALID, "remap_area_min must be within [0, 1]");  // regrid.py:124-125
+  if ((flags & SMM_APPLY_MASKED) && !op->d_imask)
+    return fail(SMM_ERR_INVALID, "masked apply requested but the operator has no dst_imask");
+  if (remap_area_min > 0.0 && !op->d_frac)
+    return fail(SMM_ERR_INVALID, "remap_area_min > 0 requested but the operator has no dst_frac");
+  const size_t xsz = x_dtype == SMM_F64 ? 8 : 4, ysz = y_dtype == SMM_F64 ? 8 : 4;
+  if ((uintptr_t)x % xsz || (uintptr_t)y % ysz) return fail(SMM_ERR_INVALID, "field pointer is not element aligned");
+  DeviceGuard guard(op->device);
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
+  int rc = ensure_sb(op);   // first call uploads the CSR (smm_operator_prepare_sb does it ahead of time)
+  if (rc) return rc;
+  SbArgs a{};
+  a.rowptr = op->d_csr_rowptr;
+  a.col = (flags & SMM_APPLY_SB_PACKED) ? op->d_csr_colp : op->d_csr_col;
+  a.val = op->d_csr_val;
+  a.imask = op->d_imask;
+  a.frac = op->d_frac;
+  a.x = x;
+  a.y = y;
+  a.ldx = ldx;
+  a.ldy = ldy;
+  a.n_batch = n_batch;
+  a.n_dst = op->csr.n_dst;
+  a.area_min = remap_area_min;
+  a.masked = (flags & SMM_APPLY_MASKED) ? 1 : 0;
+  const bool fill = !(flags & SMM_APPLY_NO_FILL);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == SMM_F64)
+    return y_dtype == SMM_F64 ? launch_sb<double, double>(a, fill, flags, s) : launch_sb<double, float>(a, fill, flags, s);
+  return y_dtype == SMM_F64 ? launch_sb<float, double>(a, fill, flags, s) : launch_sb<float, float>(a, fill, flags, s);
 }
 
 // ---- host-buffer path: chunked, double-buffered H2D -> kernel -> D2H pipeline

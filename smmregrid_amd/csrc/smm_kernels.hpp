@@ -61,6 +61,22 @@ struct ApplyArgs {
   int sub_shift;     // single-wave tile kernel: a block owns 64 >> sub_shift rows of its slice
 };
 
+// arguments of the batch-fastest kernel (kernel C below)
+struct SbArgs {
+  const int64_t* rowptr;   // [n_dst + 1] canonical CSR
+  const int32_t* col;      // [nnz] source cell, or its rank among the used cells (packed X)
+  const double* val;       // [nnz]
+  const uint8_t* imask;    // [n_dst] or null
+  const double* frac;      // [n_dst] or null
+  const void* x;           // (n_rows_x, ldx): row = source cell, batch entry fastest
+  void* y;                 // (n_batch, ldy)
+  int64_t ldx, ldy, n_batch, n_dst;
+  int64_t n_dtiles, n_btiles, n_blocks;
+  double area_min;
+  int masked;
+  int xcd_remap;
+};
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
@@ -750,6 +766,176 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       __syncthreads();
     }
     if (kDeferStore && row_live) flush_pending();
+  }
+}
+
+// ------------------------------------------------------------------ kernel C
+// Batch-fastest operand layout ("SB"): X is (S, B) -- the B batch values of one source cell are
+// contiguous -- and Y is still written (B, D) as the reference lays it out (regrid.py:550).  In
+// the native (B, S) layout a bilinear 4:1 stencil needs 16-B pairs on a 32-B stride, so half of
+// every fetched 128-B line is wasted (element-granular fraction capped at ~0.55).  With
+// the batch fastest every needed source cell is a contiguous run: fetched bytes == algorithmic
+// bytes, and every link is one coalesced 1-KiB wave load (64 lanes x 16 B).
+//
+// One wave owns a tile of TD destination rows x BT = 64 * VEC batch entries.  Links are wave
+// uniform: column / weight come through scalar loads straight from the canonical CSR (no SELL
+// padding, ragged rows cost nothing), the tile's links are walked as one flat sequence in batches
+// of U loads (two batches in flight), and a row's sum is finished -- fill on load, epilogue on
+// flush -- when the walk crosses its end.  Accumulation is per row in ascending source order with
+// separate multiply and add: bit-identical to the oracle.  Finished rows go to an LDS tile
+// [TD][BT] that is read back transposed, so that Y is written in runs of TD consecutive
+// destination cells per batch row (TD = 16 doubles = one 128-B line).
+
+template <typename XT, typename YT, int TD, int U, bool FILL>
+__global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
+  constexpr int VEC = 2;                    // batch entries per lane
+  constexpr int BT = 64 * VEC;              // batch entries per tile
+  constexpr int PAD = 16 / (int)sizeof(YT); // LDS row padding: one 16-B slot (conflict-free transposed reads)
+  constexpr int LROW = BT + PAD;
+  static_assert(TD % 2 == 0 && 128 % TD == 0 && TD <= 64, "store phase: TD / 2 lanes per batch row");
+  __shared__ __attribute__((aligned(16))) YT tile[TD * LROW];
+  typedef XT xvec __attribute__((ext_vector_type(VEC)));
+  typedef xvec xvec_u __attribute__((aligned(sizeof(XT))));   // element-aligned (any ldx / base)
+
+  const int lane = threadIdx.x;
+  uint32_t bid = blockIdx.x;   // grids stay below 2^31 blocks: 32-bit index arithmetic
+  if (a.xcd_remap > 0) {   // runs of consecutive tiles (neighbours in space) share one XCD's L2
+    const uint32_t C = (uint32_t)a.xcd_remap, round = 8 * C;
+    if (bid < ((uint32_t)a.n_blocks / round) * round) {
+      const uint32_t xcd = bid & 7, slot = bid >> 3;
+      bid = (slot / C) * round + xcd * C + (slot % C);
+    }
+  }
+  const uint32_t bt32 = bid / (uint32_t)a.n_dtiles;
+  const int64_t dt = bid - bt32 * (uint32_t)a.n_dtiles, bt = bt32;
+  const int64_t d0 = dt * TD;
+  const int rows = (int)(a.n_dst - d0 < TD ? a.n_dst - d0 : TD);
+  const int64_t b0 = bt * BT;
+  // lanes past the batch end load the last valid pair (in bounds) and store nothing
+  int64_t bl = b0 + (int64_t)lane * VEC;
+  const int64_t b_last = a.n_batch >= VEC ? a.n_batch - VEC : 0;
+  const bool tiny_batch = a.n_batch < VEC;
+  if (bl > b_last) bl = b_last;
+  const XT* __restrict__ xl = (const XT*)a.x + bl;
+
+  const int64_t p0 = a.rowptr[d0], p1 = a.rowptr[d0 + rows];
+  int d_local = 0;
+  int64_t row_end = a.rowptr[d0 + 1];
+  int64_t row_end_next = a.rowptr[d0 + (rows > 1 ? 2 : 1)];   // scalar prefetch, one row ahead
+  double acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
+
+  // regrid.py:553-565 per destination row, gathered once per tile (lane r looks at row r) into a
+  // wave-uniform bit mask: a vector load inside flush_row would make every row end wait for all
+  // outstanding X loads
+  bool dead_lane = false;
+  if (lane < rows) {
+    if (a.masked && a.imask) dead_lane = a.imask[d0 + lane] == 0;
+    if (a.area_min > 0.0 && a.frac) dead_lane = dead_lane || (a.frac[d0 + lane] < a.area_min);
+  }
+  const unsigned long long dead_mask = __ballot(dead_lane);
+
+  auto flush_row = [&]() {
+    const bool dead = (dead_mask >> d_local) & 1ull;   // wave-uniform
+    YT out[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      out[v] = (YT)epilogue(acc[v], dead);
+      acc[v] = 0.0;
+    }
+    typedef YT yvec __attribute__((ext_vector_type(VEC)));
+    yvec o;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = out[v];
+    *(yvec*)(&tile[d_local * LROW + lane * VEC]) = o;
+    ++d_local;
+    row_end = row_end_next;
+    const int nxt = d_local + 2 <= rows ? d_local + 2 : rows;
+    row_end_next = a.rowptr[d0 + nxt];
+  };
+
+  xvec xv[2][U];
+  double w[2][U];
+  auto load_batch = [&](int buf, int64_t base) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t p = base + u;
+      if (p > p1 - 1) p = p1 - 1;            // padding repeats the tile's last link (valid address)
+      const int64_t c = a.col[p];
+      w[buf][u] = a.val[p];
+      xv[buf][u] = *(const xvec_u*)(xl + c * a.ldx);
+    }
+  };
+  auto consume = [&](int buf, int64_t base) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = base + u;
+      if (p < p1) {                           // wave-uniform
+        while (row_end <= p) flush_row();     // rows ending before this link (empty rows included)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          XT e = xv[buf][u][v];
+          if (FILL) e = __builtin_isfinite(e) ? e : (XT)1e20;   // regrid.py:545-547, dtype's own 1e20
+          const double prod = w[buf][u] * (double)e;
+          acc[v] = acc[v] + prod;
+        }
+      }
+    }
+  };
+
+  if (p1 > p0 && !tiny_batch) {
+    load_batch(0, p0);
+    for (int64_t base = p0; base < p1; base += 2 * U) {
+      if (base + U < p1) load_batch(1, base + U);
+      consume(0, base);
+      if (base + 2 * U < p1) load_batch(0, base + 2 * U);
+      if (base + U < p1) consume(1, base + U);
+    }
+  } else if (p1 > p0) {
+    // fewer batch entries than one lane's vector: element-wise walk (never on a hot path)
+    for (int64_t p = p0; p < p1; ++p) {
+      while (row_end <= p) flush_row();
+      const int64_t c = a.col[p];
+      const double wv = a.val[p];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const int64_t b = b0 + (int64_t)lane * VEC + v;
+        XT e = ((const XT*)a.x)[c * a.ldx + (b < a.n_batch ? b : a.n_batch - 1)];
+        if (FILL) e = __builtin_isfinite(e) ? e : (XT)1e20;
+        const double prod = wv * (double)e;
+        acc[v] = acc[v] + prod;
+      }
+    }
+  }
+  while (d_local < rows) flush_row();
+  __syncthreads();
+
+  // transposed read-back: TD / 2 lanes cover one batch row's TD destination cells (two per lane)
+  constexpr int LPB = TD / 2;            // lanes per batch row
+  constexpr int BPI = 64 / LPB;          // batch rows per store instruction
+  const int dp = lane % LPB, bsub = lane / LPB;
+  const int64_t dd = d0 + 2 * dp;
+  YT* __restrict__ yb = (YT*)a.y + dd;
+#pragma unroll 4
+  for (int i = 0; i < BT / BPI; ++i) {
+    const int bloc = i * BPI + bsub;
+    const int64_t b = b0 + bloc;
+    const YT v0 = tile[(2 * dp) * LROW + bloc];
+    const YT v1 = tile[(2 * dp + 1) * LROW + bloc];
+    if (b < a.n_batch) {
+      YT* dst = yb + b * a.ldy;
+      if (dd + 1 < a.n_dst) {
+        typedef YT y2 __attribute__((ext_vector_type(2)));
+        typedef y2 y2_u __attribute__((aligned(sizeof(YT))));
+        y2 o;
+        o[0] = v0;
+        o[1] = v1;
+        __builtin_nontemporal_store(o, (y2_u*)dst);
+      } else if (dd < a.n_dst) {
+        __builtin_nontemporal_store(v0, dst);
+      }
+    }
   }
 }
 

@@ -169,6 +169,41 @@ class SparseOperator:
                   float(remap_area_min), fl, _stream_handle(stream))
         return y
 
+    def used_sources(self):
+        """Ascending 0-based indices of the source cells that carry a link (length n_used_src):
+        the row order of a packed batch-fastest field (apply_sb(..., packed=True))."""
+        used = np.empty(self.n_used_src, dtype=np.int32)
+        _lib.call("smm_operator_used_sources", self.handle, _cptr(used))
+        return used
+
+    def prepare_sb(self):
+        """Upload the canonical CSR the batch-fastest kernel reads (else done by the first apply_sb)."""
+        _lib.call("smm_operator_prepare_sb", self.handle)
+        return self
+
+    def apply_sb(self, x, y=None, masked=False, remap_area_min=0.0, packed=False, out_dtype=np.float64,
+                 flags=0, stream=None):
+        """The same product for a device-resident field kept batch-fastest: x of shape (S, B) -- or
+        (n_used_src, B) with packed=True, rows in `used_sources()` order -- holds the B batch values
+        of each source cell contiguously.  Y is (B, D) as `apply` returns it, bit-identical to
+        ``apply`` on the transposed field; HBM traffic equals the algorithmic bytes because every
+        needed source cell is one contiguous run (smm_apply_sb)."""
+        if not isinstance(x, DeviceArray):
+            raise TypeError("SparseOperator.apply_sb takes a DeviceArray")
+        rows = self.n_used_src if packed else self.n_src
+        if x.ndim != 2 or x.shape[0] != rows:
+            raise ValueError(f"X must be ({rows}, B), got {x.shape}")
+        n_batch = x.shape[1]
+        if y is None:
+            y = DeviceArray((n_batch, self.n_dst), out_dtype)
+        elif y.shape != (n_batch, self.n_dst):
+            raise ValueError(f"Y must be ({n_batch}, {self.n_dst}), got {y.shape}")
+        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0) | (_lib.APPLY_SB_PACKED if packed else 0)
+        _lib.call("smm_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), max(n_batch, 1),
+                  ctypes.c_void_p(y.ptr), dtype_code(y.dtype), self.n_dst, n_batch, float(remap_area_min), fl,
+                  _stream_handle(stream))
+        return y
+
     def apply_host(self, x, out=None, masked=False, remap_area_min=0.0, out_dtype=np.float64,
                    flags=0, chunk_rows=0):
         """Same product for a host (numpy) array of shape (B, S): the rows stream through the

@@ -1,0 +1,118 @@
+"""The batch-fastest ("SB") operand layout: X (S, B) -- or packed (U, B) -- in, Y (B, D) out,
+bit-identical to the oracle (regrid.py:545-570) and to the native-layout kernels."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from smmregrid_amd import SparseOperator, _lib, gridgen, to_device
+from smmregrid_amd.device import DeviceArray
+from tests.helpers import assert_same, field, ragged_links, random_links
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sb(op, x_bs, masked=False, amin=0.0, packed=False, out_dtype=np.float64, flags=0):
+    """x_bs: host (B, S) as the oracle takes it; the device gets its transpose."""
+    xt = np.ascontiguousarray(x_bs.T)
+    if packed:
+        xt = np.ascontiguousarray(xt[op.used_sources()])
+    return op.apply_sb(to_device(xt), masked=masked, remap_area_min=amin, packed=packed, out_dtype=out_dtype,
+                       flags=flags).to_host()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("packed", [False, True])
+def test_sb_random_matrix(hip, rng, dtype, packed):
+    n_src, n_dst = 4096, 1003                      # D not a multiple of the 16-row tile
+    src, dst, w = random_links(rng, n_src, n_dst, 6000)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    csr = op.export_csr()
+    imask = (rng.random(n_dst) > 0.2).astype(np.int32)
+    frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    assert np.array_equal(op.used_sources(), np.unique(csr[1]))
+    for n_batch in (1, 2, 3, 5, 64, 127, 128, 129, 300):
+        x = field(rng, n_batch, n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.004)
+        for masked, amin in [(False, 0.0), (True, 0.0), (True, 0.5), (False, 0.9)]:
+            y = run_sb(op, x, masked, amin, packed)
+            assert_same(y, oracle.apply_c(csr, x, masked, imask, frac, amin), exact=True)
+
+
+def test_sb_ragged_and_empty_rows(hip, rng):
+    n_src, n_dst = 3000, 777
+    src, dst, w = ragged_links(rng, n_src, n_dst, max_len=60)     # rows of 0..60 links, many empty
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    x = field(rng, 70, n_src, nan_frac=0.05)
+    ref = oracle.apply_c(op.export_csr(), x)
+    assert_same(run_sb(op, x), ref, exact=True)
+    assert_same(run_sb(op, x, flags=1 << 16), ref, exact=True)    # 4-load batches
+    # no links at all: every cell is epilogue(0) = 0
+    op0 = SparseOperator(50, 40, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), device=0)
+    assert (run_sb(op0, field(rng, 5, 50)) == 0.0).all()
+    # f32 store is the rounded f64 result
+    y32 = run_sb(op, x, out_dtype=np.float32)
+    assert y32.dtype == np.float32
+    assert_same(y32, ref.astype(np.float32), exact=True)
+
+
+def test_sb_structured_weights_match_native_layout(hip, rng):
+    for method, s, d in [("bil", "r180x90", "r90x45"), ("con", "r144x72", "r36x18"), ("bil", "r96x48", "hp8"),
+                         ("nn", "r64x32", "r20x10"), ("con", "r90x45", "r120x60")]:
+        w = gridgen.generate_weights(s, d, method=method)
+        op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                            w["dst_address"].values, w["remap_matrix"].values, device=0)
+        op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
+        x = field(rng, 37, op.n_src, nan_frac=0.01)
+        native = op.apply(to_device(x), remap_area_min=0.5).to_host()
+        for packed in (False, True):
+            assert_same(run_sb(op, x, False, 0.5, packed), native, exact=True)
+
+
+def test_sb_row_pitches_and_errors(hip, rng):
+    n_src, n_dst, B = 600, 130, 50
+    src, dst, w = random_links(rng, n_src, n_dst, 900)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    x = field(rng, B, n_src)
+    ref = oracle.apply_c(op.export_csr(), x)
+    ldx, ldy = B + 7, n_dst + 3                      # odd pitches: 16-B loads / stores are element aligned only
+    xw = np.full((n_src, ldx), np.nan)
+    xw[:, :B] = x.T
+    yw = np.full((B, ldy), -7.0)
+    dx, dy = to_device(xw), to_device(yw)
+    _lib.call("smm_apply_sb", op.handle, ctypes.c_void_p(dx.ptr), _lib.SMM_F64, ldx, ctypes.c_void_p(dy.ptr),
+              _lib.SMM_F64, ldy, B, 0.0, 0, None)
+    got = dy.to_host()
+    assert_same(got[:, :n_dst], ref, exact=True)
+    assert (got[:, n_dst:] == -7.0).all()
+    with pytest.raises(_lib.SmmError):               # ldx smaller than the batch
+        _lib.call("smm_apply_sb", op.handle, ctypes.c_void_p(dx.ptr), _lib.SMM_F64, B - 1, ctypes.c_void_p(dy.ptr),
+                  _lib.SMM_F64, ldy, B, 0.0, 0, None)
+    with pytest.raises(_lib.SmmError):               # masked without an imask
+        op.apply_sb(to_device(np.ascontiguousarray(x.T)), masked=True)
+    with pytest.raises(ValueError):
+        op.apply_sb(DeviceArray((n_src + 1, B), np.float64))
+
+
+def test_sb_config2_geometry(hip):
+    """r1440x721 -> r360x180 bilinear at full grid size, B = 300 (two full batch tiles + a ragged one):
+    sampled rows against the oracle, every row against the native-layout kernel."""
+    w = gridgen.bilinear_weights("r1440x721", "r360x180")
+    op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                        w["dst_address"].values, w["remap_matrix"].values, device=0)
+    op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
+    B, U = 300, op.n_used_src
+    assert U == 259200
+    xp = DeviceArray((U, B), np.float64).fill_random(seed=5, mean=250.0, sigma=30.0)     # packed batch-fastest
+    xph = xp.to_host()
+    xph[::1001, 7] = np.nan
+    xp.copy_from_host(xph)
+    y = op.apply_sb(xp, remap_area_min=0.5, packed=True).to_host()
+    x_bs = np.zeros((B, op.n_src))                   # the same field in the native layout
+    x_bs[:, op.used_sources()] = xph.T
+    native = op.apply(to_device(x_bs), remap_area_min=0.5).to_host()
+    assert_same(y, native, exact=True)
+    rows = [0, 7, 127, 128, 255, 256, 299]
+    assert_same(y[rows], oracle.apply_c(op.export_csr(), x_bs[rows], False, None, w["dst_grid_frac"].values, 0.5),
+                exact=True)

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--key", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--traffic", required=True)
+    ap.add_argument("--git-head", default=os.environ.get("SMM_GIT_HEAD"),
+                    help="commit the profiled tree was built from (the GPU box has no .git)")
     a = ap.parse_args()
     fetch, nf = mean_counter(a.fetch, a.kernel)["FETCH_SIZE"]
     write, nw = mean_counter(a.write, a.kernel)["WRITE_SIZE"]
@@ -54,7 +56,14 @@ def main():
     out["hbm_bytes_per_launch"] = out["fetch_bytes"] + out["write_bytes"]
     json.dump(out, open(a.out, "w"), indent=1)
     traffic = json.load(open(a.traffic)) if os.path.exists(a.traffic) else {}
-    traffic[a.key] = {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": os.path.basename(a.out)}
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha
+    out["kernel_sha"] = kernel_source_sha()
+    out["git_head"] = a.git_head
+    json.dump(out, open(a.out, "w"), indent=1)
+    traffic[a.key] = {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": os.path.basename(a.out),
+                      "kernel_sha": out["kernel_sha"], "git_head": a.git_head}
     json.dump(traffic, open(a.traffic, "w"), indent=1)
     print(json.dumps(out))
 
