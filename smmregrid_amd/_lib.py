@@ -131,7 +131,12 @@ def load():
                        "or `make -C smmregrid_amd/csrc`. There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)
+        fn = getattr(lib, name, None)
+        if fn is None:
+            # timing experiments load older builds of the library side by side (tools/exp/ab_libs.sh)
+            if os.environ.get("SMM_LIB_ALLOW_MISSING"):
+                continue
+            raise SmmError(SMM_ERR_UNSUPPORTED, f"{LIB_PATH} does not export {name}: stale build, run build()")
         fn.restype = _int
         fn.argtypes = argtypes
     for name, (restype, argtypes) in SPECIAL.items():

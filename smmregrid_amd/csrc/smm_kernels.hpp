@@ -80,6 +80,7 @@ struct SbArgs {
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
+typedef u32x4 u32x4_t;
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
 #ifndef SMM_CHUNK_ELEMS
@@ -95,6 +96,20 @@ __device__ __forceinline__ double load_fixed(const T* __restrict__ p, bool fill)
   // dtype's own cast of 1e20 (float32(1e20) for an f32 field).
   const T f = (T)1e20;
   return (double)((fill && !__builtin_isfinite(v)) ? f : v);
+}
+
+// The same fill applied to a whole 16-B staging piece on its way into LDS: the tile then holds
+// finite values and the link loop gathers without a test per link (a 48-link row tests 48 gathered
+// values per batch row, its 15 staging pieces hold 30).
+template <typename XT>
+__device__ __forceinline__ u32x4_t fix_piece(u32x4_t piece) {
+  constexpr int N = 16 / (int)sizeof(XT);
+  XT e[N];
+  __builtin_memcpy(e, &piece, 16);
+#pragma unroll
+  for (int q = 0; q < N; ++q) e[q] = __builtin_isfinite(e[q]) ? e[q] : (XT)1e20;
+  __builtin_memcpy(&piece, e, 16);
+  return piece;
 }
 
 __device__ __forceinline__ double epilogue(double v, bool dead) {
@@ -281,8 +296,8 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
   const bool row_live = in_blk && d < a.n_dst && (!SPLIT || grp == n_grp - 1);
   const bool slice_live = slice * 64 < a.n_dst;
 
-  // MAXK > 0: the row's links live in registers across batch rows (LDS indices are
-  // < 8192, two per register); MAXK == 0 (rows longer than 48 links): re-read per row.
+  // MAXK > 0: the row's links live in registers across batch rows (LDS byte offsets are
+  // < 65536, two per register); MAXK == 0 (rows longer than 48 links): re-read per row.
   constexpr int KREG = MAXK > 0 ? MAXK : 2;
   int len = 0, nslots = 0;
   uint32_t lc2[KREG / 2];
@@ -311,7 +326,8 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       const int k0 = min(first + k, nslots - 1), k1 = min(first + k + 1, nslots - 1);
       const uint32_t c0 = (uint32_t)cp[(int64_t)k0 * 64];
       const uint32_t c1 = (uint32_t)cp[(int64_t)k1 * 64];
-      lc2[k / 2] = (k < len ? c0 : cpad) | ((k + 1 < len ? c1 : cpad) << 16);
+      // two 16-bit LDS BYTE offsets per register (tiles are <= 64 KiB)
+      lc2[k / 2] = ((k < len ? c0 : cpad) | ((k + 1 < len ? c1 : cpad) << 16)) * (uint32_t)sizeof(XT);
       // Slots past the row's length get weight +0.0 and the LDS index of the row's first link: the
       // running sum is never -0.0 (it starts at +0.0) and the staged value is finite after the fill,
       // so acc + 0*x == acc bit for bit and the walk loop needs no per-link select.  (Without the
@@ -350,12 +366,13 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
 
   // Pieces [wave*64 + k*256, +64) belong to this wave in round k.  poff = element offset of
   // the piece inside a batch row (clamped so that the 16-B load stays inside the row),
-  // shift = elements by which the clamp moved it (non-zero only for the row's last piece),
-  // pvalid bit k = the piece exists.
-  const int np_w = __builtin_amdgcn_readfirstlane(
+  // shift = elements by which the clamp moved it (non-zero only for the row's last piece).
+  // Lanes past the block's last piece (and pieces wholly beyond the row) load offset 0 of the row
+  // and write their natural LDS slot, which no link refers to.
+  int np_w = __builtin_amdgcn_readfirstlane(
       npieces > wave * 64 ? (npieces - wave * 64 + T - 1) / T : 0);
   int32_t poff[NP];
-  unsigned pvalid = 0, shifted = 0;
+  unsigned shifted = 0;
   int shift_amt = 0;
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -367,7 +384,6 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       const int sub = pc - ch * pieces_per_chunk;
       int64_t e0 = (int64_t)chunk_src[ch] * kChunkElems + (int64_t)sub * kElemsPerPiece;
       if (p < npieces && e0 < a.n_src) {
-        pvalid |= 1u << k;
         if (e0 + kElemsPerPiece > a.n_src) {
           const int64_t e1 = a.n_src >= kElemsPerPiece ? a.n_src - kElemsPerPiece : 0;
           shifted |= 1u << k;
@@ -468,20 +484,32 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       const XT* __restrict__ xrow = (const XT*)a.x + xoff;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
-          const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
-          v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
-        }
+        if (k >= np_w) break;  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
+        const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
+        v[k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
       }
     };
     // the row-end piece (clamped load, see above) exists in at most one block per row: keep its
     // element shuffle out of the common path with a wave-uniform branch
     const bool any_shifted = __builtin_amdgcn_readfirstlane((int)__any(shifted != 0)) != 0;
+    // Every lane writes its pieces to their natural slots (tid + k*T): the LDS request is rounded up
+    // to whole rounds of T pieces (tile_launch_cfg), so lanes past the tile's last piece write into
+    // padding nobody reads and the writes need no per-lane predicate (wave-uniform k < np_w only).
     auto store_tile = [&]() {
       if (!any_shifted) {
+        if (fill) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-          if (k < np_w && ((pvalid >> k) & 1u)) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = v[k];
+          for (int k = 0; k < NP; ++k) {
+            if (k >= np_w) break;
+            *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = fix_piece<XT>(v[k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            if (k >= np_w) break;
+            *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = v[k];
+          }
+        }
         return;
       }
 #pragma unroll
@@ -502,7 +530,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             }
             __builtin_memcpy(&piece, out, 16);
           }
-          if ((pvalid >> k) & 1u) *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = piece;
+          *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = fill ? fix_piece<XT>(piece) : piece;
         }
       }
     };
@@ -529,6 +557,18 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
         yrow[d] = pend_out;
     };
     for (int64_t j = j_begin; j < j_end; ++j) {
+      // The counts are loop invariant, and hipcc would keep one 64-bit predicate per piece / link
+      // group (k < np_w, k0 < wmax) live across the walk -- dozens of SGPR pairs, spilled to VGPR
+      // lanes and read back in front of every piece.  Opaque copies make it compare the scalar again.
+      asm volatile("" : "+s"(np_w), "+s"(wmax));
+      // Likewise it would unpack the LDS offsets once, into one VGPR per link (48 instead of 24): with
+      // 16 staging pieces that tips the 48-link kernels over 256 VGPRs, and the spill it chose was the
+      // last two prefetched pieces -- a scratch store behind s_waitcnt vmcnt(0) right after the
+      // prefetch was issued, i.e. no overlap of the link loop with the loads at all.
+      if (MAXK > 16) {
+#pragma unroll
+        for (int q = 0; q < KREG / 2; ++q) asm volatile("" : "+v"(lc2[q]));
+      }
       store_tile();
       if (kDeferStore && row_live && j > j_begin) flush_pending();
       __syncthreads();
@@ -554,7 +594,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                   const int k = k0 + kk;
                   const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
                                               : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-                  xv[kk] = load_fixed(lds_x + li, fill);
+                  xv[kk] = (double)*(const XT*)((const char*)lds_x + li);
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -584,7 +624,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                 const int k = k0 + kk;
                 const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
                                             : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-                xv[kk] = load_fixed(lds_x + li, fill);  // unconditional: index 0 for unused slots
+                xv[kk] = (double)*(const XT*)((const char*)lds_x + li);  // unconditional: offset 0 for unused slots; finite since staging
               }
 #pragma unroll
               for (int kk = 0; kk < 4; ++kk) {
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
               wv[q] = vp[(int64_t)kc * 64];
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) xv[q] = load_fixed(lds_x + (k0 + q < len ? li[q] : 0), fill);
+            for (int q = 0; q < 8; ++q) xv[q] = (double)lds_x[k0 + q < len ? li[q] : 0];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               const double p = wv[q] * xv[q];
@@ -632,22 +672,31 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
       const XT* __restrict__ xrow = (const XT*)a.x + xoff;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
-        if (k < np_w) {  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
-          const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
-          v[r][k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
-        }
+        if (k >= np_w) break;  // wave-uniform; invalid lanes read offset 0 of the row (in bounds, unused)
+        const u32x4_u* src = (const u32x4_u*)(xrow + poff[k]);
+        v[r][k] = (NT & 1) ? __builtin_nontemporal_load(src) : *src;
       }
     };
     // the row-end piece (clamped load, see above) exists in at most one block per row: keep its
     // element shuffle out of the common path with a wave-uniform branch
     const bool any_shifted = __builtin_amdgcn_readfirstlane((int)__any(shifted != 0)) != 0;
     const int tile_bytes = R > 1 ? a.tile_bytes : 0;  // LDS region of batch row r of a step: r * tile_bytes
-    auto store_tile = [&](int r) {
+    auto store_tile = [&](int r) {   // unconditional natural-slot writes, fill on the way in (see R == 1)
       char* region = smem + r * tile_bytes;
       if (!any_shifted) {
+        if (fill) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-          if (k < np_w && ((pvalid >> k) & 1u)) *(u32x4*)(region + (size_t)(tid + k * T) * 16) = v[r][k];
+          for (int k = 0; k < NP; ++k) {
+            if (k >= np_w) break;
+            *(u32x4*)(region + (size_t)(tid + k * T) * 16) = fix_piece<XT>(v[r][k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NP; ++k) {
+            if (k >= np_w) break;
+            *(u32x4*)(region + (size_t)(tid + k * T) * 16) = v[r][k];
+          }
+        }
         return;
       }
 #pragma unroll
@@ -668,7 +717,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             }
             __builtin_memcpy(&piece, out, 16);
           }
-          if ((pvalid >> k) & 1u) *(u32x4*)(region + (size_t)(tid + k * T) * 16) = piece;
+          *(u32x4*)(region + (size_t)(tid + k * T) * 16) = fill ? fix_piece<XT>(piece) : piece;
         }
       }
     };
@@ -706,6 +755,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
         yrow[d] = pend_out;
     };
     for (int64_t jb = j_begin; jb < j_end; jb += R) {
+      asm volatile("" : "+s"(np_w), "+s"(wmax));   // see the R == 1 walk
 #pragma unroll
       for (int r = 0; r < R; ++r) store_tile(r);
       if (kDeferStore && row_live && jb > j_begin) flush_pending();
@@ -732,7 +782,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                   const int k = k0 + kk;
                   const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
                                               : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-                  xv[kk] = load_fixed(lds_r + li, fill);  // unconditional: index 0 for unused slots
+                  xv[kk] = (double)*(const XT*)((const char*)lds_r + li);  // unconditional: offset 0 for unused slots; finite since staging
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -750,7 +800,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
               const int kc = min(k, nslots - 1);
               const bool on = k < len;
               const int32_t li = cp[(int64_t)kc * 64];
-              const double xv = load_fixed(lds_r + (on ? li : 0), fill);
+              const double xv = (double)lds_r[on ? li : 0];
               const double p = vp[(int64_t)kc * 64] * xv;
               const double sum = acc + p;
               acc = on ? sum : acc;
@@ -815,6 +865,9 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   int64_t bl = b0 + (int64_t)lane * VEC;
   const int64_t b_last = a.n_batch >= VEC ? a.n_batch - VEC : 0;
   const bool tiny_batch = a.n_batch < VEC;
+  // odd batch size: the lane holding the last entry loads the pair one element earlier and takes
+  // its second element (lanes further out have no valid entry at all)
+  const bool shift1 = !tiny_batch && bl == a.n_batch - 1;
   if (bl > b_last) bl = b_last;
   const XT* __restrict__ xl = (const XT*)a.x + bl;
 
@@ -875,7 +928,7 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
         while (row_end <= p) flush_row();     // rows ending before this link (empty rows included)
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          XT e = xv[buf][u][v];
+          XT e = (v == 0 && shift1) ? xv[buf][u][1] : xv[buf][u][v];
           if (FILL) e = __builtin_isfinite(e) ? e : (XT)1e20;   // regrid.py:545-547, dtype's own 1e20
           const double prod = w[buf][u] * (double)e;
           acc[v] = acc[v] + prod;

@@ -84,10 +84,12 @@ inline TileLaunchCfg tile_launch_cfg(const ApplyArgs& a, int64_t n_lev, int tile
   c.total = a.n_dblocks * c.n_jtiles * n_lev;
   // runs of 32 consecutive blocks per XCD (variant 6: dispatcher order, 7 / 13: runs of 8 / 128)
   c.xcd_remap = variant == 6 ? 0 : (variant == 7 ? 8 : (variant == 13 ? 128 : 32));
-  c.tile = (size_t)max_chunks * kChunkElems * xsz;
   const int64_t max_pieces = max_chunks * (int64_t)(kChunkElems * xsz / 16);
   c.threads = (tile_which ? 1 : kWavesPerBlock) * 64;  // == tile_waves(MAXK) * 64
   c.np_needed = (int)((max_pieces + c.threads - 1) / c.threads);
+  // whole rounds of one 16-B piece per thread: every lane stores its pieces unpredicated, the
+  // last round's surplus lands in padding
+  c.tile = (size_t)std::max(c.np_needed, 1) * c.threads * 16;
   // Small tiles (one or two 16-B pieces per thread, 4-wave shape): a step of 4 / 2 batch rows per
   // barrier pair keeps as many bytes in flight as a full tile would (variant 12: off, for A/B runs).
   c.rows = 1;
