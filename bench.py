@@ -69,7 +69,11 @@ WORKLOADS = {
     "cfg3L35": ("conmask", (1442, 1021, 0.35), "r360x180", 1024, "f64"),
     "cfg3L05": ("conmask", (1442, 1021, 0.05), "r360x180", 1024, "f64"),
     # masked levels: (method, source nx x ny, target, (time steps, levels), x dtype)
-    "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
+    # "pad": field rows start on 128-B lines (row pitch rounded up to 16 doubles) -- the pitch the
+    # library's own H2D staging uses (smm_group_apply_host); "cfg3c": rows packed back to back, every
+    # row of the 1442x1021 grid then starts mid-line (S * 8 B = 80 mod 128)
+    "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "pad"),
+    "cfg3c": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
     "cfg3s": ("con3d", (1442, 1021), "r360x180", (16, 8), "f64"),
 }
 
@@ -258,18 +262,23 @@ class ProblemLevels:
         slab = (10.0 + 5.0 * rng.standard_normal((n_lev, self.n_src), dtype=np.float32)).astype(np.float64)
         slab[masks == 0] = np.nan
         self.slab, self.masks = slab, masks
-        self.x = DeviceArray((self.n_t, n_lev, 1, self.n_src), np.float64)
-        self.x.rows(0, 1).copy_from_host(slab.reshape(1, n_lev, 1, self.n_src))
+        self.padded = len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "pad"
+        ldx = -(-self.n_src // 16) * 16 if self.padded else self.n_src
+        self.x = DeviceArray((self.n_t, n_lev, 1, ldx), np.float64)
+        first = np.zeros((1, n_lev, 1, ldx))
+        first[0, :, 0, :self.n_src] = slab
+        self.x.rows(0, 1).copy_from_host(first)
         from smmregrid_amd import _lib
         import ctypes
         for t in range(1, self.n_t):
             _lib.call("smm_memcpy_d2d", ctypes.c_void_p(self.x.rows(t, t + 1).ptr),
-                      ctypes.c_void_p(self.x.ptr), slab.nbytes, None)
+                      ctypes.c_void_p(self.x.ptr), first.nbytes, None)
         self.y_shape = (self.n_t, 1, n_lev, self.n_dst)
         self.np_dt = np.float64
         nnz = sum(op.nnz for op in self.ops)
         self.desc = (f"{name}: {nx}x{ny} tripolar-like -> {tgrid} conservative, {self.n_t} time steps x "
-                     f"{n_lev} masked levels per GPU, f64, remap_area_min 0.5, grouped launch")
+                     f"{n_lev} masked levels per GPU, f64, remap_area_min 0.5, grouped launch, X (T, L, S) "
+                     + (f"with rows on 128-B lines (pitch {ldx})" if self.padded else "packed"))
         self.meta = {"S": self.n_src, "D": self.n_dst, "nnz_total": nnz, "levels": n_lev,
                      "max_row_nnz": max(op.max_row_nnz for op in self.ops),
                      "plan": self.ops[0].plan_info()}

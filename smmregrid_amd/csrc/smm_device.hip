@@ -677,6 +677,9 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr) {
     // own block shape: 256 rows for rows of <= 16 links; else one slice, or the largest part of a
     // slice whose footprint fits the LDS budget and is used well enough (plan valid and preferred)
     op->native = op->csr.max_row_nnz > 16 ? 1 : 0;
+#ifdef SMM_EXP_WAVES4
+    if (op->csr.max_row_nnz <= 48) op->native = 0;
+#endif
     if ((rc = ensure_plan(op, op->native))) {
       release(op);
       return rc;
@@ -920,7 +923,10 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
 
   const size_t xsz = x_dtype == SMM_F64 ? 8 : 4, ysz = y_dtype == SMM_F64 ? 8 : 4;
   const size_t xrow = (size_t)ldx * xsz, yrow = (size_t)ldy * ysz;   // host row pitches
-  const size_t xrow_d = (((size_t)S * xsz + 15) / 16) * 16;            // device rows 16-B aligned
+  // device rows start on 128-B lines: the tile plan stages whole lines of a row, and a row that
+  // starts mid-line makes every staged run of chunks straddle one line more (config 3's 1442x1021
+  // source: +17 % fetched bytes when its rows are packed back to back)
+  const size_t xrow_d = (((size_t)S * xsz + 127) / 128) * 128;
   const int64_t ldx_d = (int64_t)(xrow_d / xsz);
   if (chunk_rows <= 0) {
     chunk_rows = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(xrow_d, 1)));
@@ -1276,7 +1282,7 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
 
   const size_t xsz = x_dtype == SMM_F64 ? 8 : 4, ysz = y_dtype == SMM_F64 ? 8 : 4;
-  const size_t xrow_d = (((size_t)S * xsz + 15) / 16) * 16;   // device rows 16-B aligned
+  const size_t xrow_d = (((size_t)S * xsz + 127) / 128) * 128;   // device rows start on 128-B lines (see smm_apply_host)
   const int64_t ldx_d = (int64_t)(xrow_d / xsz);
   const int64_t rows_per_outer = n_lev * n_inner;
   const size_t x_outer_d = (size_t)rows_per_outer * xrow_d;   // device bytes per outer index

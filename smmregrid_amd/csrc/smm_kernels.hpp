@@ -241,7 +241,11 @@ typedef u32x4 u32x4_u __attribute__((aligned(4)));  // 16-B piece that may start
 // Rows with more than 16 links run one wave (64 destination rows) per workgroup: their source
 // tiles are large, and single-wave workgroups need no workgroup barrier, so the waves of a CU
 // drift apart and overlap each other's HBM waits.
+#ifdef SMM_EXP_WAVES4   // timing experiment: 4-wave workgroups (256 consecutive rows, one shared tile) for heavy rows too
+constexpr int tile_waves(int maxk) { return maxk > 0 ? kWavesPerBlock : 1; }
+#else
 constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPerBlock : 1; }
+#endif
 
 //
 // R > 1 (small tiles only): R batch rows are staged, consumed and stored per barrier pair, each in
@@ -611,10 +615,10 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             acc = (grp == g + 1) ? handed : acc;
           }
 #ifdef SMM_EXP_SKIP_COMPUTE
-        } else if (false) {
-#else
-        } else if (MAXK > 0) {
+        } else if (true) {   // timing-only ablation: one LDS read instead of the link loop
+          acc = (double)lds_x[lane];
 #endif
+        } else if (MAXK > 0) {
 #pragma unroll
           for (int k0 = 0; k0 < KREG; k0 += 4) {
             if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static
@@ -769,10 +773,11 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
           const XT* lds_r = (const XT*)(smem + r * tile_bytes);
           double acc = 0.0;
 #ifdef SMM_EXP_SKIP_COMPUTE
-          if (false) {
-#else
-          if (MAXK > 0) {
+          if (true) {   // timing-only ablation: one LDS read instead of the link loop
+            acc = (double)lds_r[lane];
+          } else
 #endif
+          if (MAXK > 0) {
 #pragma unroll
             for (int k0 = 0; k0 < KREG; k0 += 4) {
               if (k0 < wmax) {  // wave-uniform guard: whole groups of slots are skipped, indices stay static

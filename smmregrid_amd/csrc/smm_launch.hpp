@@ -134,6 +134,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   const int64_t per_grp = (max_row_nnz + n_grp - 1) / n_grp;
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
+#ifndef SMM_EXP_WAVES4
     if constexpr (MAXK == 32 || MAXK == 48) {
       if (split) {
         hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, true>),
@@ -142,6 +143,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
         return SMM_OK;
       }
     }
+#endif
     if constexpr (MAXK > 0 && MAXK <= 16) {
       if (rows == 4) return go3(k_tag, std::integral_constant<int, 1>(), nt_tag, std::integral_constant<int, 4>());
       if (rows == 2) return go3(k_tag, std::integral_constant<int, 2>(), nt_tag, std::integral_constant<int, 2>());
@@ -152,6 +154,10 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
     if (!tile_which) {
       if (max_row_nnz <= 4) return fn(std::integral_constant<int, 4>());
       if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
+#ifdef SMM_EXP_WAVES4
+      if (max_row_nnz > 32) return fn(std::integral_constant<int, 48>());
+      if (max_row_nnz > 16) return fn(std::integral_constant<int, 32>());
+#endif
       return fn(std::integral_constant<int, 16>());
     }
     if (variant == 14) return fn(std::integral_constant<int, 0>());  // tuning: stream the links

@@ -153,11 +153,12 @@ class SparseOperator:
 
     def apply(self, x, y=None, masked=False, remap_area_min=0.0, out_dtype=np.float64,
               flags=0, stream=None):
-        """Y = epilogue(fill(X) . W) for a device-resident X of shape (B, S)."""
+        """Y = epilogue(fill(X) . W) for a device-resident X of shape (B, S), or (B, ldx) with a
+        padded row pitch ldx >= S (rows that start on 128-B lines are staged without straddling)."""
         if not isinstance(x, DeviceArray):
             raise TypeError("SparseOperator.apply takes a DeviceArray (use Regridder for host data)")
-        if x.ndim != 2 or x.shape[1] != self.n_src:
-            raise ValueError(f"X must be (B, {self.n_src}), got {x.shape}")
+        if x.ndim != 2 or x.shape[1] < self.n_src:
+            raise ValueError(f"X must be (B, >= {self.n_src}), got {x.shape}")
         n_batch = x.shape[0]
         if y is None:
             y = DeviceArray((n_batch, self.n_dst), out_dtype)
@@ -165,7 +166,7 @@ class SparseOperator:
             raise ValueError(f"Y must be ({n_batch}, {self.n_dst}), got {y.shape}")
         fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
         _lib.call("smm_apply", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype),
-                  self.n_src, ctypes.c_void_p(y.ptr), dtype_code(y.dtype), self.n_dst, n_batch,
+                  x.shape[1], ctypes.c_void_p(y.ptr), dtype_code(y.dtype), self.n_dst, n_batch,
                   float(remap_area_min), fl, _stream_handle(stream))
         return y
 
@@ -294,11 +295,13 @@ class OperatorGroup:
 
     def apply(self, x, level_index, masked_levels=None, y=None, masked=False, remap_area_min=0.0,
               transpose=True, out_dtype=np.float64, flags=0, stream=None):
-        """x: DeviceArray (n_outer, n_lev, n_inner, S).  Returns
+        """x: DeviceArray (n_outer, n_lev, n_inner, S) -- or (..., ldx) with a padded row pitch ldx >= S.  Returns
         (n_outer, n_inner, n_lev, D) when transpose (regrid.py:420-427) else
         (n_lev, n_outer, n_inner, D) (the concat order, regrid.py:410)."""
-        if not isinstance(x, DeviceArray) or x.ndim != 4 or x.shape[3] != self.n_src:
-            raise ValueError(f"X must be a DeviceArray (n_outer, n_lev, n_inner, {self.n_src})")
+        if not isinstance(x, DeviceArray) or x.ndim != 4 or x.shape[3] < self.n_src:
+            raise ValueError(f"X must be a DeviceArray (n_outer, n_lev, n_inner, >= {self.n_src})")
+        # the last axis may be a padded row pitch (>= S): rows that start on 128-B lines (a multiple
+        # of 16 doubles / 32 floats) are staged without straddling lines
         n_outer, n_lev, n_inner, S = x.shape
         D = self.n_dst
         lev, ml = self._level_args(level_index, masked_levels, n_lev)
