@@ -363,31 +363,19 @@ class TorchDist:
         return DeviceArray(shape, np.float64, ptr=self.y_t.data_ptr())
 
     def prepare_gather(self, y, root=0, tiles=8):
-        """Tiled gather: the shard is cut into row tiles; tile k is gathered (async, on RCCL's own
-        stream) while the kernel of tile k+1 runs.  The root receives into a ring of two tile
-        buffers per rank -- a consumer would drain them -- so the full Y of all ranks never has to
-        fit on one GPU (config 5: 211 GB)."""
+        """Tiled gather (smmregrid_amd.distributed.TiledRingGather): tile k is gathered (async, on
+        RCCL's own stream) while the kernel of tile k+1 runs; the root receives into a ring of two
+        tile buffers per rank, so the full Y of all ranks never has to fit on one GPU."""
+        from smmregrid_amd.distributed import TiledRingGather
         self.root = root
-        n = self.y_t.shape[0]
-        per = -(-n // max(1, min(tiles, n)))
-        self.tiles = [(r0, min(n, r0 + per)) for r0 in range(0, n, per)]
-        self.ring = None
-        if self.rank == root:
-            self.ring = [[self.torch.empty((per,) + tuple(self.y_t.shape[1:]), dtype=self.torch.float64,
-                                           device=self.dev) for _ in range(self.world)] for _ in range(2)]
-        self.pending = []
+        self.ring = TiledRingGather(self.dist, self.torch, self.y_t, root=root, tiles=tiles, slots=2)
+        self.tiles = self.ring.tiles
 
     def gather_tile(self, k):
-        r0, r1 = self.tiles[k]
-        if len(self.pending) >= 2:                 # the ring slot about to be reused must have landed
-            self.pending.pop(0).wait()
-        recv = [buf[:r1 - r0] for buf in self.ring[k % 2]] if self.rank == self.root else None
-        self.pending.append(self.dist.gather(self.y_t[r0:r1], recv, dst=self.root, async_op=True))
+        self.ring.gather_tile(k)
 
     def finish_gather(self):
-        for work in self.pending:
-            work.wait()
-        self.pending = []
+        self.ring.finish()
 
     def barrier(self):
         self.dist.barrier()

@@ -1,19 +1,30 @@
 """CdoGenerate -- same constructor / method names as the reference's
-cdogenerate.py:21-23, :101-103, :345; the weights are produced by the native
-generator (`gridgen`) because the hot path this package accelerates only
-*consumes* weights and no ``cdo`` binary exists in the target environment.
-Grids and methods outside the native generator raise `NotImplementedError`
-naming the CDO command the reference would have run (cdogenerate.py:285-294).
+cdogenerate.py:21-23, :101-103, :345.
+
+With a ``cdo`` binary on the box the weights come from it, exactly as in the reference:
+``cdo [options] gen<method>,<target> [extra] [-sellevidx,<k>] <source> <weights file>`` with
+``REMAP_EXTRAPOLATE`` / ``CDO_REMAP_NORM`` in the environment (cdogenerate.py:277-294), one run
+per level for masked 3-D fields (:179-228), the result read back through `io.open_weights`.
+Without it -- where this package is built and benchmarked -- the native generator (`gridgen`)
+produces them for the grids and methods it knows, and says so in a WARNING: its weights are
+not CDO's (a different cell geometry near coasts and poles).  Either way the hot path only
+*consumes* the weights.
 """
 import logging
 import os
 import shutil
+import subprocess
+import sys
+import tempfile
 
 import numpy as np
 
 from . import gridgen
+from .gridmeta import CdoGrid
 from .gridtype import GridType, tolist
-from .xrlite import DataArray, Dataset, from_xarray
+from .xrlite import DataArray, Dataset, from_xarray, is_xarray
+
+NATIVE_METHODS = ("con", "ycon", "bil", "nn")
 
 
 class CdoGenerate:
@@ -25,6 +36,13 @@ class CdoGenerate:
         self.cdo_extra = tolist(cdo_extra)
         self.cdo_options = tolist(cdo_options)
         self.have_cdo = shutil.which(cdo) is not None
+        self.env = os.environ.copy()                       # cdogenerate.py:61-66
+        if cdo_download_path:
+            self.env["CDO_DOWNLOAD_PATH"] = cdo_download_path
+        if cdo_icon_grids:
+            self.env["CDO_ICON_GRIDS"] = cdo_icon_grids
+        # what the caller handed over (a path, a CDO grid name or a data object) is what `cdo` is given
+        self._source_arg, self._target_arg = source_grid, target_grid
         self.source_grid = from_xarray(self._open_if_file(source_grid))
         self.target_grid = from_xarray(self._open_if_file(target_grid))
 
@@ -88,8 +106,26 @@ class CdoGenerate:
             mask_dim = vertical_dim
         if self.target_grid is None:
             raise TypeError('Target grid is not specified, cannot provide any regridding')
+        if self.source_grid is None:
+            raise TypeError('Source grid is not specified, cannot provide any regridding')
         if method not in ["bic", "bil", "con", "con2", "dis", "laf", "nn", "ycon"]:
-            raise KeyError(f'Unsupported method {method}')   # cdogenerate.py:73-76
+            raise ValueError('The remap method provided is not supported!')          # cdogenerate.py:73-76
+        if remap_norm not in ["fracarea", "destarea"]:
+            raise ValueError('The remap normalization provided is not supported!')   # cdogenerate.py:77-78
+        if self.have_cdo:
+            return self._weights_with_cdo(method, extrapolate, remap_norm, mask_dim, nproc)
+        # ---- no cdo binary on this box: native generator
+        self.loggy.warning("no '%s' binary found: weights come from the native generator, they are not "
+                           "CDO's (cell geometry differs near coasts and poles)", self.cdo)
+        if method not in NATIVE_METHODS:
+            raise NotImplementedError(f"method '{method}' needs the cdo binary (`cdo gen{method},<target> <source> "
+                                      f"<weights>`); the native generator knows {', '.join(NATIVE_METHODS)}")
+        if not extrapolate:
+            raise NotImplementedError("extrapolate=False (REMAP_EXTRAPOLATE=off) needs the cdo binary; the "
+                                      "native generator always maps every target point")
+        if self.cdo_options or [e for e in self.cdo_extra if not str(e).startswith("-setgrid,")]:
+            self.loggy.warning("cdo_options / cdo_extra %s %s are ignored without the cdo binary",
+                               self.cdo_options, self.cdo_extra)
         # `-setgrid,<name>` among the extra CDO operators names the source grid of a file that carries
         # no coordinates (basic_test.py:15-29: healpix_0.nc + '-setgrid,hp1_nested')
         setgrid = [e.split(",", 1)[1] for e in (self.cdo_extra or []) if str(e).startswith("-setgrid,")]
@@ -109,6 +145,83 @@ class CdoGenerate:
                      for i in range(len(levels))]
         ds = gridgen.stack_level_weights(per_level, levels, mask_dim=mask_dim, method=method)
         return self._with_masked_flag(ds, mask_dim)
+
+    # ------------------------------------------------------------------ cdo subprocess path
+    def _prepare_grid(self, grid, target=False):
+        """cdogenerate.py:80-99: a data object is written to a temporary NetCDF file, a CDO grid
+        name becomes `-const,1,<grid>` for the source and stays as it is for the target, any other
+        string is a file path.  Returns (argument for the cdo command line, temp file or None)."""
+        if is_xarray(grid):
+            tmp = tempfile.NamedTemporaryFile(delete=False, suffix=".nc")
+            tmp.close()
+            grid.to_netcdf(tmp.name)
+            return tmp.name, tmp.name
+        if isinstance(grid, (Dataset, DataArray)):
+            from .io import write_netcdf3
+            tmp = tempfile.NamedTemporaryFile(delete=False, suffix=".nc")
+            tmp.close()
+            write_netcdf3(grid, tmp.name)
+            return tmp.name, tmp.name
+        if isinstance(grid, str):
+            if CdoGrid(grid).grid_kind and not target:
+                return f"-const,1,{grid}", None
+            return grid, None
+        raise TypeError('Grid must be a CDO grid string, a file path, or an xarray Dataset/DataArray.')
+
+    def _cdo_generate_weights(self, sgrid, tgrid, method, extrapolate, remap_norm, cdo_extra_vertical=None):
+        """One `cdo gen<method>` run (cdogenerate.py:234-303) -> weights Dataset."""
+        from .io import open_weights
+        env = dict(self.env)
+        env["REMAP_EXTRAPOLATE"] = "on" if extrapolate else "off"
+        env["CDO_REMAP_NORM"] = remap_norm
+        with tempfile.NamedTemporaryFile(suffix=".nc") as weight_file:
+            command = [self.cdo, *(self.cdo_options or []), f"gen{method},{tgrid}",
+                       *((self.cdo_extra or []) + (tolist(cdo_extra_vertical) or [])), sgrid, weight_file.name]
+            self.loggy.debug("Final CDO command: %s", command)
+            try:
+                subprocess.check_output(command, stderr=subprocess.STDOUT, env=env)
+            except subprocess.CalledProcessError as err:
+                print(err.output.decode(errors="replace"), file=sys.stderr)
+                raise
+            return open_weights(weight_file.name)
+
+    def _weights_with_cdo(self, method, extrapolate, remap_norm, mask_dim, nproc):
+        return self._with_masked_flag(self._cdo_weights(method, extrapolate, remap_norm, mask_dim, nproc),
+                                      mask_dim)
+
+    def _cdo_weights(self, method, extrapolate, remap_norm, mask_dim, nproc):
+        """The weights as `cdo` wrote them (2-D), or stacked per level in the layout of
+        cdogenerate.py:310-343 (3-D); host work only."""
+        sgrid, s_tmp = self._prepare_grid(self._source_arg)
+        tgrid, t_tmp = self._prepare_grid(self._target_arg, target=True)
+        try:
+            if not mask_dim:
+                return self._cdo_generate_weights(sgrid, tgrid, method, extrapolate, remap_norm)
+            src = self.source_grid
+            if isinstance(src, Dataset):
+                if mask_dim not in src.sizes:
+                    raise KeyError(f'Cannot find vertical dim {mask_dim} in {list(src.sizes)}')
+                src = next(v for v in src.data_vars.values() if mask_dim in v.dims)
+            elif not isinstance(src, DataArray) or mask_dim not in src.dims:
+                raise KeyError(f'Cannot find vertical dim {mask_dim} in the source grid')
+            levels = src.coords[mask_dim].values if mask_dim in src.coords else np.arange(src.sizes[mask_dim])
+            nvert = len(levels)
+            self.loggy.info('Vertical dimension has length: %s', nvert)
+
+            def one(lev):   # the reference forks a process per level around the same subprocess (:197-217)
+                return self._cdo_generate_weights(sgrid, tgrid, method, extrapolate, remap_norm,
+                                                  cdo_extra_vertical=[f"-sellevidx,{lev + 1}"])
+            if nproc and nproc > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=int(nproc)) as pool:
+                    per_level = list(pool.map(one, range(nvert)))
+            else:
+                per_level = [one(lev) for lev in range(nvert)]
+            return gridgen.stack_level_weights(per_level, levels, mask_dim=mask_dim, method=method)
+        finally:
+            for tmp in (s_tmp, t_tmp):
+                if tmp and os.path.exists(tmp):
+                    os.remove(tmp)
 
     @staticmethod
     def _with_masked_flag(ds, mask_dim):

@@ -73,3 +73,67 @@ def regrid_sharded(x_rows, apply_fn, n_dst, group=None, gather="root", root=0):
         if b > a:
             out[a:b] = part[:b - a].cpu().numpy()
     return out
+
+
+def tile_bounds(n_rows, tiles):
+    """Row tiles of the overlapped gather: at most `tiles` tiles of ceil(n_rows / tiles) rows, the
+    last one short when the tile size does not divide the rows."""
+    n_rows = int(n_rows)
+    if n_rows <= 0:
+        return []
+    per = -(-n_rows // max(1, min(int(tiles), n_rows)))
+    return [(r0, min(n_rows, r0 + per)) for r0 in range(0, n_rows, per)]
+
+
+class TiledRingGather:
+    """Gather of every rank's Y shard to `root`, tiled and overlapped with the compute.
+
+    The shard (a torch tensor, rows first) is cut into row tiles; `gather_tile(k)` starts the
+    asynchronous gather of tile k -- on the GPU box it travels over RCCL/xGMI while the kernel of
+    tile k + 1 runs.  The root receives into a RING of `slots` tile buffers per rank, not into one
+    buffer of the full size: the gathered Y of all ranks never has to fit on one GPU (BASELINE
+    config 5: 211 GB).  A ring slot is reused only after the gather that last filled it has
+    completed AND the consumer has drained it (`on_tile(k, parts)` is called on the root with the
+    per-rank views of tile k exactly once, in tile order).
+
+    Works with any torch.distributed backend (nccl == RCCL on the GPU box, gloo in CPU tests).
+    """
+
+    def __init__(self, dist, torch, shard, root=0, tiles=8, slots=2, group=None, on_tile=None):
+        self.dist, self.torch, self.group = dist, torch, group
+        self.shard, self.root, self.slots = shard, int(root), int(slots)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.tiles = tile_bounds(shard.shape[0], tiles)
+        self.on_tile = on_tile
+        per = max((r1 - r0 for r0, r1 in self.tiles), default=0)
+        self.ring = None
+        if self.rank == self.root:
+            self.ring = [[torch.empty((per,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+                          for _ in range(self.world)] for _ in range(self.slots)]
+        self.pending = []          # (tile index, work handle), oldest first
+        self.gathered_bytes = 0    # bytes received by the root from OTHER ranks (with_gather accounting)
+        self.delivered = 0         # tiles handed to on_tile
+
+    def _retire(self):
+        k, work = self.pending.pop(0)
+        work.wait()
+        if self.rank == self.root:
+            r0, r1 = self.tiles[k]
+            parts = [buf[:r1 - r0] for buf in self.ring[k % self.slots]]
+            self.gathered_bytes += (self.world - 1) * parts[0].numel() * parts[0].element_size()
+            if self.on_tile is not None:
+                self.on_tile(k, parts)
+        self.delivered += 1
+
+    def gather_tile(self, k):
+        """Start the gather of tile k (call after the compute of tile k has been enqueued)."""
+        r0, r1 = self.tiles[k]
+        while len(self.pending) >= self.slots:      # the slot about to be reused must be drained
+            self._retire()
+        recv = [buf[:r1 - r0] for buf in self.ring[k % self.slots]] if self.rank == self.root else None
+        work = self.dist.gather(self.shard[r0:r1], recv, dst=self.root, group=self.group, async_op=True)
+        self.pending.append((k, work))
+
+    def finish(self):
+        while self.pending:
+            self._retire()

@@ -465,7 +465,7 @@ def stack_level_weights(weights_list, levels, mask_dim="lev", method="con"):
         if name not in first:
             continue
         v0 = first[name]
-        if "num_links" in v0.dims:
+        if "num_links" in v0.dims or "numLinks" in v0.dims:   # CDO writes either name (cdogenerate.py:315)
             shape = (L, nl_max) + tuple(v0.shape[1:])
             out = np.zeros(shape, dtype=v0.values.dtype)
             for i, w in enumerate(weights_list):

@@ -22,6 +22,43 @@ def save_weights(weights, path):
     np.savez_compressed(path, **payload)
 
 
+def write_netcdf3(ds, path):
+    """Dataset / DataArray -> NetCDF-3 (64-bit offset) with ``scipy.io.netcdf_file``: what the
+    reference obtains from ``xarray.to_netcdf`` when it hands a grid to ``cdo``
+    (cdogenerate.py:82-87).  NaN in floating fields is written as such with ``_FillValue = NaN``
+    so that CDO sees the land/sea mask as missing values."""
+    from scipy.io import netcdf_file
+    if isinstance(ds, DataArray):
+        da = ds
+        ds = Dataset({da.name or "field": da}, coords=dict(da.coords))
+    with netcdf_file(path, "w", version=2) as nc:
+        for k, v in ds.attrs.items():
+            setattr(nc, k, v if isinstance(v, (int, float, str)) else str(v))
+        sizes = {}
+        for v in ds.variables.values():
+            for d, n in zip(v.dims, v.shape):
+                sizes.setdefault(d, int(n))
+        for d, n in sizes.items():
+            nc.createDimension(d, n)
+        for k, v in ds.variables.items():
+            values = np.asarray(v.values)
+            if values.dtype == np.int64:
+                values = values.astype(np.int32)       # classic NetCDF has no 64-bit integers
+            if values.dtype == bool:
+                values = values.astype(np.int8)
+            if values.dtype.kind not in "fiuS":
+                continue                               # object / datetime coordinates are not grid data
+            var = nc.createVariable(k, values.dtype.newbyteorder(">") if values.dtype.kind != "S" else "c",
+                                    tuple(v.dims))
+            var[...] = values
+            for a, av in v.attrs.items():
+                if isinstance(av, (int, float, str, np.generic)):
+                    setattr(var, a, av)
+            if values.dtype.kind == "f" and np.isnan(values).any():
+                var._FillValue = values.dtype.type(np.nan)
+    return path
+
+
 def open_weights(path):
     if str(path).endswith(".npz"):
         z = np.load(path, allow_pickle=False)

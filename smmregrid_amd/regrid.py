@@ -7,8 +7,10 @@ Inputs may be xarray objects (when xarray is importable) or the lite
 containers of `smmregrid_amd.xrlite`; the result has the type of the input.
 A field whose ``data`` is a `DeviceArray` stays in HBM (no host copies).
 
-Unlike the reference the result is eager (numpy- or HBM-backed), not a lazy
-dask graph.
+By default the result is eager (numpy- or HBM-backed).  ``Regridder(..., lazy=True)`` gives the
+reference's contract (regrid.py:29-30): nothing is launched before ``.values`` / ``.compute()``;
+a dask-backed field comes back dask-backed with the chunking of its kept dimensions preserved
+(`lazy.map_batch_blocks`), any other field as a `lazy.LazyArray`.
 """
 import logging
 import math
@@ -18,6 +20,7 @@ import numpy as np
 
 from .device import DeviceArray
 from .gridtype import GridType, tolist
+from .lazy import LazyArray, is_dask, map_batch_blocks
 from .operator import OperatorGroup
 from .weights import (_level_slice, check_mask, compute_weights_matrix, compute_weights_matrix3d,
                       mask_weights)
@@ -51,7 +54,8 @@ class Regridder(object):
     def __init__(self, source_grid=None, target_grid=None, weights=None,
                  method='con', remap_area_min=DEFAULT_AREA_MIN, transpose=True, mask_dim=None,
                  vertical_dim=None, horizontal_dims=None, cdo_extra=None, cdo_options=None,
-                 check_nan=False, cdo='cdo', loglevel='WARNING', device=None, out_dtype=np.float64):
+                 check_nan=False, cdo='cdo', loglevel='WARNING', device=None, out_dtype=np.float64,
+                 lazy=False):
         if (source_grid is None or target_grid is None) and (weights is None):
             raise ValueError("Either weights or source_grid/target_grid must be supplied")
 
@@ -65,6 +69,7 @@ class Regridder(object):
         self.loglevel = loglevel
         self.transpose = transpose
         self.device = device
+        self.lazy = bool(lazy)
         # the reference always yields float64 (result_type(x, f64)); float32 is an opt-in narrowing store
         self.out_dtype = np.dtype(out_dtype)
         if self.out_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
@@ -309,23 +314,37 @@ class Regridder(object):
         masked = bool(np.asarray(masked).any()) if np.ndim(masked) else bool(masked)
 
         src = source_data.data
-        if isinstance(src, DeviceArray):
-            x = src.reshape(n_batch, -1)
-            if x.shape[1] != op.n_src:
-                raise ValueError(f"source grid has {x.shape[1]} cells, weights expect {op.n_src}")
-            y = op.apply(x, masked=masked, remap_area_min=self.remap_area_min, out_dtype=self.out_dtype)
-            out_data = y.reshape(*(kept_shape + tgt_shape))
-        else:
-            host = np.asarray(src)
+        area_min, out_dtype = self.remap_area_min, self.out_dtype
+
+        def apply_rows(host):
+            """(rows, S) host block -> (rows, D): chunks stream through the library's H2D / kernel /
+            D2H pipeline."""
+            host = np.asarray(host)
             if host.dtype not in (np.float32, np.float64):
                 host = host.astype(np.float64)  # result_type(x, f64), regrid.py:550
-            host = np.ascontiguousarray(host).reshape(n_batch, -1)
+            host = np.ascontiguousarray(host)
             if host.shape[1] != op.n_src:
                 raise ValueError(f"source grid has {host.shape[1]} cells, weights expect {op.n_src}")
-            # host field: chunks stream through the library's H2D / kernel / D2H pipeline
-            out = op.apply_host(host, masked=masked, remap_area_min=self.remap_area_min,
-                                out_dtype=self.out_dtype)
-            out_data = out.reshape(kept_shape + tgt_shape)
+            return op.apply_host(host, masked=masked, remap_area_min=area_min, out_dtype=out_dtype)
+
+        def compute():
+            if isinstance(src, DeviceArray):
+                x = src.reshape(n_batch, -1)
+                if x.shape[1] != op.n_src:
+                    raise ValueError(f"source grid has {x.shape[1]} cells, weights expect {op.n_src}")
+                y = op.apply(x, masked=masked, remap_area_min=area_min, out_dtype=out_dtype)
+                return y.reshape(*(kept_shape + tgt_shape))
+            host = src.compute() if isinstance(src, LazyArray) else np.asarray(src)
+            return apply_rows(host.reshape(n_batch, -1)).reshape(kept_shape + tgt_shape)
+
+        if self.lazy and is_dask(src):
+            # dask in, dask out: one task per block of the kept dimensions (regrid.py:538-541)
+            out_data = map_batch_blocks(src, len(source_data.dims) - len(kept_dims), tgt_shape, apply_rows,
+                                        dtype=out_dtype)
+        elif self.lazy:
+            out_data = LazyArray(kept_shape + tgt_shape, out_dtype, compute)
+        else:
+            out_data = compute()
 
         return self._finish(out_data, kept_dims + tgt_dims, source_data, kept_dims, weights,
                             tgt_shape, tgt_dims)
@@ -380,24 +399,26 @@ class Regridder(object):
 
         src = source_data.data
         S, D = group.n_src, group.n_dst
-        if isinstance(src, DeviceArray):
-            x = src.reshape(n_outer, n_lev, n_inner, -1)
-            y = group.apply(x, level_index, masked_levels, masked=any_masked,
-                            remap_area_min=self.remap_area_min, transpose=self.transpose,
-                            out_dtype=self.out_dtype)
-            out_data = y.reshape(*out_shape)
-        else:
-            host = np.asarray(src)
+        area_min, out_dtype, transpose = self.remap_area_min, self.out_dtype, self.transpose
+
+        def compute():
+            if isinstance(src, DeviceArray):
+                x = src.reshape(n_outer, n_lev, n_inner, -1)
+                y = group.apply(x, level_index, masked_levels, masked=any_masked, remap_area_min=area_min,
+                                transpose=transpose, out_dtype=out_dtype)
+                return y.reshape(*out_shape)
+            host = src.compute() if isinstance(src, LazyArray) else np.asarray(src)   # a dask field is computed here
             if host.dtype not in (np.float32, np.float64):
                 host = host.astype(np.float64)
             host = np.ascontiguousarray(host).reshape(n_outer, n_lev, n_inner, -1)
             if host.shape[3] != S:
                 raise ValueError(f"source grid has {host.shape[3]} cells, weights expect {S}")
             # host field: chunks of the outer axis stream through the group's pipeline
-            out = group.apply_host(host, level_index, masked_levels, masked=any_masked,
-                                   remap_area_min=self.remap_area_min, transpose=self.transpose,
-                                   out_dtype=self.out_dtype)
-            out_data = out.reshape(out_shape)
+            out = group.apply_host(host, level_index, masked_levels, masked=any_masked, remap_area_min=area_min,
+                                   transpose=transpose, out_dtype=out_dtype)
+            return out.reshape(out_shape)
+
+        out_data = LazyArray(out_shape, out_dtype, compute) if self.lazy else compute()
 
         kept_for_coords = kept_dims
         w2d = weights

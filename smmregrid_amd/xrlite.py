@@ -188,7 +188,11 @@ def from_xarray(obj):
         coords = OrderedDict()
         for k, c in obj.coords.items():
             coords[k] = DataArray(np.asarray(c.values), dims=c.dims, attrs=dict(c.attrs), name=k)
-        return DataArray(obj.data if isinstance(obj.data, np.ndarray) else np.asarray(obj.values),
+        # a dask-backed field keeps its dask array (Regridder(lazy=True) maps the apply over its blocks;
+        # the eager path computes it when it reads the field)
+        raw = obj.data
+        keep = isinstance(raw, np.ndarray) or (hasattr(raw, "dask") and hasattr(raw, "chunks"))
+        return DataArray(raw if keep else np.asarray(obj.values),
                          dims=obj.dims, coords=coords, attrs=dict(obj.attrs), name=obj.name)
     ds = Dataset(attrs=dict(obj.attrs))
     for k, c in obj.coords.items():
@@ -196,6 +200,23 @@ def from_xarray(obj):
     for k, v in obj.data_vars.items():
         ds[k] = from_xarray(v)
     return ds
+
+
+def _lazy_payload(data):
+    """What an xarray.DataArray should wrap: dask arrays stay dask; a deferred `LazyArray` becomes a
+    one-chunk dask array when dask is importable (the launch still waits for .compute()), else it is
+    computed; DeviceArray / numpy go through as host values."""
+    if hasattr(data, "dask") and hasattr(data, "chunks"):
+        return data
+    from .lazy import LazyArray
+    if isinstance(data, LazyArray) and not data.computed:
+        try:
+            import dask
+            import dask.array as da
+            return da.from_delayed(dask.delayed(data.compute)(), shape=data.shape, dtype=data.dtype)
+        except ImportError:
+            pass
+    return data.to_host() if hasattr(data, "to_host") else np.asarray(data)
 
 
 def to_xarray(obj):
@@ -206,7 +227,7 @@ def to_xarray(obj):
         if obj.data is None:
             return _xarray.DataArray(data=None)
         coords = {k: (c.dims, c.values, c.attrs) for k, c in obj.coords.items()}
-        return _xarray.DataArray(obj.values, dims=obj.dims, coords=coords, attrs=obj.attrs,
+        return _xarray.DataArray(_lazy_payload(obj.data), dims=obj.dims, coords=coords, attrs=obj.attrs,
                                  name=obj.name)
     if isinstance(obj, Dataset):
         return _xarray.Dataset({k: to_xarray(v) for k, v in obj.data_vars.items()},

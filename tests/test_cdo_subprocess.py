@@ -1,0 +1,129 @@
+"""CdoGenerate's `cdo` subprocess path (reference cdogenerate.py:234-303, :179-228) against a
+stand-in binary: the command line, the environment, the read-back and the 3-D stacking layout."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from smmregrid_amd import CdoGenerate, DataArray, gridgen
+from tests.fake_cdo.make_fake_cdo import install
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def fake_cdo(tmp_path, monkeypatch):
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    install(str(bindir), ROOT)
+    log = tmp_path / "cdo_calls.jsonl"
+    monkeypatch.setenv("FAKE_CDO_LOG", str(log))
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+
+    def calls():
+        return [json.loads(line) for line in open(log)] if log.exists() else []
+    return calls
+
+
+def test_2d_command_line_environment_and_readback(fake_cdo, tmp_path):
+    gen = CdoGenerate("r32x16", "r16x8", cdo_options=["-f", "nc"], cdo_extra=["-b", "F64"],
+                      cdo_download_path=str(tmp_path))
+    assert gen.have_cdo
+    w = gen._cdo_weights("con", extrapolate=False, remap_norm="destarea", mask_dim=None, nproc=1)
+    (call,) = fake_cdo()
+    argv = call["argv"]
+    # cdo [options] gen<method>,<target> [extra] <source> <weights file>   (cdogenerate.py:285-294)
+    assert argv[:2] == ["-f", "nc"] and argv[2] == "gencon,r16x8" and argv[3:5] == ["-b", "F64"]
+    assert argv[5] == "-const,1,r32x16"                       # CDO grid name as source (cdogenerate.py:90-92)
+    assert argv[6].endswith(".nc") and len(argv) == 7
+    assert call["REMAP_EXTRAPOLATE"] == "off" and call["CDO_REMAP_NORM"] == "destarea"   # :277-279
+    assert call["CDO_DOWNLOAD_PATH"] == str(tmp_path)         # :63-64
+    ref = gridgen.generate_weights("r32x16", "r16x8", method="con", norm="destarea")
+    for k in ("src_address", "dst_address", "remap_matrix", "dst_grid_frac", "src_grid_imask", "dst_grid_dims"):
+        assert np.array_equal(w[k].values, ref[k].values), k
+    assert w.attrs["title"] == "fake cdo weights"             # it really is the file cdo wrote
+    assert not os.path.exists(argv[6])                        # the temporary weights file is gone
+
+
+def test_source_given_as_data_is_written_to_a_temporary_file(fake_cdo):
+    g = gridgen.parse_grid("r24x12")
+    x = np.ones((2, 12, 24))
+    x[:, 3:6, 5:9] = np.nan
+    field = DataArray(x, dims=("time", "lat", "lon"), coords={"time": np.arange(2), "lat": g.lat, "lon": g.lon},
+                      name="tos")
+    gen = CdoGenerate(field, "r12x6")
+    w = gen._cdo_weights("con", True, "fracarea", None, 1)
+    (call,) = fake_cdo()
+    src_file = call["argv"][-2]
+    assert src_file.endswith(".nc") and not os.path.exists(src_file)      # written, used, removed
+    assert call["REMAP_EXTRAPOLATE"] == "on" and call["CDO_REMAP_NORM"] == "fracarea"
+    mask = np.isfinite(x[0]).astype(np.int32).ravel()
+    assert np.array_equal(w["src_grid_imask"].values, mask)               # the NaN mask reached cdo
+    assert (mask[w["src_address"].values - 1] == 1).all()
+
+
+def test_3d_one_run_per_level_and_stacked_layout(fake_cdo):
+    g = gridgen.parse_grid("r24x12")
+    L = 3
+    x = np.ones((2, L, 12, 24))
+    for lev in range(L):
+        x[:, lev, 2:4 + 2 * lev, 3:8 + lev] = np.nan             # the mask grows with depth
+    field = DataArray(x, dims=("time", "lev", "lat", "lon"),
+                      coords={"time": np.arange(2), "lev": np.array([5.0, 50.0, 500.0]), "lat": g.lat, "lon": g.lon},
+                      name="thetao")
+    gen = CdoGenerate(field, "r12x6")
+    w = gen._cdo_weights("con", True, "fracarea", "lev", nproc=2)
+    calls = fake_cdo()
+    assert len(calls) == L
+    assert sorted(a for c in calls for a in c["argv"] if a.startswith("-sellevidx")) == \
+        ["-sellevidx,1", "-sellevidx,2", "-sellevidx,3"]                   # cdogenerate.py:204
+    # layout of cdogenerate.py:310-343: link arrays zero-padded to the longest level + link_length
+    ll = w["link_length"].values
+    assert ll.shape == (L,) and ll[0] > ll[1] > ll[2]
+    assert w["src_address"].shape == (L, ll.max()) and w["remap_matrix"].shape == (L, ll.max(), 1)
+    assert w["dst_grid_frac"].shape == (L, 72) and w["src_grid_imask"].shape == (L, 288)
+    assert np.array_equal(w.coords["lev"].values, [5.0, 50.0, 500.0])
+    for lev in range(L):
+        assert (w["src_address"].values[lev, ll[lev]:] == 0).all()
+        mask = np.isfinite(x[0, lev]).astype(np.int32).ravel()
+        assert np.array_equal(w["src_grid_imask"].values[lev], mask)
+    assert w["dst_grid_dims"].shape == (2,)                               # level-independent variables stay 2-D
+
+
+def test_without_cdo_the_native_generator_says_so(monkeypatch, caplog):
+    monkeypatch.setenv("PATH", "/nonexistent")
+    gen = CdoGenerate("r32x16", "r16x8")
+    assert not gen.have_cdo
+    with pytest.raises(ValueError):
+        gen.weights(method="bogus")
+    with pytest.raises(ValueError):
+        gen.weights(method="con", remap_norm="bogus")
+    with pytest.raises(NotImplementedError, match="needs the cdo binary"):
+        gen.weights(method="bic")
+    with pytest.raises(NotImplementedError, match="extrapolate=False"):
+        gen.weights(method="bil", extrapolate=False)
+
+
+@pytest.mark.gpu
+def test_regridder_uses_cdo_when_present(hip, fake_cdo, rng):
+    """Regridder(source, target) on a box that has `cdo`: weights come from the subprocess, the mask
+    pre-compute and the apply run on the GPU, results match the oracle on those weights."""
+    from oracle import oracle
+    from smmregrid_amd import Regridder
+    from tests.helpers import assert_same
+    g = gridgen.parse_grid("r48x24")
+    x = 280.0 + 10.0 * rng.standard_normal((3, 24, 48))
+    x[:, 5:12, 10:22] = np.nan
+    field = DataArray(x, dims=("time", "lat", "lon"), coords={"time": np.arange(3), "lat": g.lat, "lon": g.lon},
+                      name="tos")
+    rg = Regridder(source_grid=field, target_grid="r24x12", method="con", device=0)
+    assert len(fake_cdo()) == 1 and fake_cdo()[0]["argv"][0] == "gencon,r24x12"
+    out = rg.regrid(field)
+    w = rg.grids[0].weights
+    assert w.attrs["title"] == "fake cdo weights" and "dst_grid_masked" in w
+    csr = oracle.coo_to_csr_c(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                              w["dst_address"].values, w["remap_matrix"].values)
+    imask = oracle.mask_apply_c(csr, w["src_grid_imask"].values)
+    ref = oracle.apply_c(csr, x.reshape(3, -1), oracle.check_mask(imask), imask, w["dst_grid_frac"].values, 0.5)
+    assert_same(out.values.reshape(3, -1), ref, exact=True)

@@ -87,3 +87,80 @@ def test_shard_bounds_cover_rows_exactly():
             assert sum(shard_sizes(n, world)) == n
     assert shard_sizes(8760, 8) == [1095] * 8           # BASELINE config 4
     assert shard_sizes(101928, 8) == [12741] * 8        # BASELINE config 5
+
+
+def _ring_worker(rank, world, port, n_rows, tiles, slots, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from smmregrid_amd.distributed import TiledRingGather, tile_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = 13
+        shard = torch.zeros((n_rows, D), dtype=torch.float64)
+        seen, errors = [], []
+
+        def value(r, step, rows):          # what rank r's shard holds in these rows at this step
+            base = torch.arange(rows[0], rows[1], dtype=torch.float64)[:, None] * 100.0
+            return base + torch.arange(D, dtype=torch.float64)[None, :] + 1e6 * r + 1e4 * step
+
+        step_now = [0]
+
+        def on_tile(k, parts):
+            r0, r1 = bounds[k]
+            seen.append(k)
+            if len(parts) != world:
+                errors.append(f"tile {k}: {len(parts)} parts")
+            for r, part in enumerate(parts):
+                if part.shape != (r1 - r0, D) or not torch.equal(part, value(r, step_now[0], (r0, r1))):
+                    errors.append(f"step {step_now[0]} tile {k} rank {r}: wrong rows in the ring slot")
+
+        bounds = tile_bounds(n_rows, tiles)
+        ring = TiledRingGather(dist, torch, shard, root=0, tiles=tiles, slots=slots, on_tile=on_tile)
+        assert ring.tiles == bounds
+        for step in range(2):              # the ring is reused across steps as bench.py does
+            step_now[0] = step
+            for k, (r0, r1) in enumerate(bounds):
+                shard[r0:r1] = value(rank, step, (r0, r1))    # stands for the kernel of tile k
+                ring.gather_tile(k)
+                # a slot is never handed out while its previous tile is undelivered
+                assert len(ring.pending) <= slots
+            ring.finish()
+            assert not ring.pending
+        ret[rank] = (errors, seen, ring.gathered_bytes, ring.delivered, len(bounds),
+                     None if ring.ring is None else (len(ring.ring), ring.ring[0][0].shape[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows,tiles,slots", [(37, 5, 2), (8, 8, 2), (5, 8, 2), (64, 4, 3), (1, 8, 2)])
+def test_world2_gloo_tiled_ring_gather(n_rows, tiles, slots):
+    """The gather schedule bench.py times as `with_gather`, on 2 gloo ranks: tiles that do not divide
+    the rows, ring slots reused within and across steps, every tile delivered once and in order with
+    the right rows of the right rank, and the byte accounting bench.py reports."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [mp.get_context("spawn").Process(target=_ring_worker, args=(r, world, port, n_rows, tiles, slots, ret))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        from smmregrid_amd.distributed import tile_bounds
+        bounds = tile_bounds(n_rows, tiles)
+        assert bounds[0][0] == 0 and bounds[-1][1] == n_rows and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+        assert len(bounds) <= tiles
+        errors, seen, gathered, delivered, n_tiles, ring_shape = ret[0]
+        assert errors == []
+        assert seen == list(range(len(bounds))) * 2                    # each tile once per step, in order
+        # with_gather accounting: the root receives (world - 1) shards of n_rows x D doubles per step
+        assert gathered == 2 * (world - 1) * n_rows * 13 * 8
+        assert delivered == 2 * len(bounds) and n_tiles == len(bounds)
+        assert ring_shape == (slots, max(b - a for a, b in bounds))   # ring of tile-sized slots, not the full Y
+        errors1, seen1, gathered1, delivered1, _, ring1 = ret[1]
+        assert errors1 == [] and seen1 == [] and gathered1 == 0 and ring1 is None and delivered1 == 2 * len(bounds)
