@@ -197,7 +197,7 @@ class Problem2D:
                                   w["dst_address"].values, w["remap_matrix"].values)
         threads, avail = cpu_threads()
         rng = np.random.default_rng(20260723)
-        rows = int(min(self.n_batch, max(threads * 8, 128)))
+        rows = int(min(self.n_batch, max(threads * 8, avail, 128)))   # >= one row per thread of the widest leg
         x = np.empty((rows, self.n_src), dtype=self.np_dt)
         for r in range(rows):
             x[r] = 250.0 + 30.0 * rng.standard_normal(self.n_src, dtype=self.np_dt)
@@ -225,6 +225,8 @@ class Problem2D:
             oracle.apply_c(csr, x[:min(rows, nt)], False, None, frac, 0.5, threads=nt)  # warm the team
             v, p, t = timed(lambda: oracle.apply_c(csr, x, False, None, frac, 0.5, threads=nt), rows,
                             budget_s * 0.375)
+            # (more threads than the process's CPU quota -- a 16-CPU share of a 256-thread host on the
+            # GPU box -- oversubscribes: that leg reports what "all visible cores" really delivers here)
             legs.append({"value": v, "unit": "cells/s", "cores": nt, "kind": "port",
                          "impl": "oracle/oracle.c (OpenMP over batch rows)",
                          "sample": f"{rows} of {self.n_batch} batch rows x {p} passes, {nt} threads of "

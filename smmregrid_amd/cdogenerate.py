@@ -33,8 +33,8 @@ class CdoGenerate:
         self.loggy = logging.getLogger("smmregrid.CdoGenerate")
         self.loggy.setLevel(getattr(logging, str(loglevel).upper(), logging.WARNING))
         self.cdo = cdo
-        self.cdo_extra = tolist(cdo_extra)
-        self.cdo_options = tolist(cdo_options)
+        self.cdo_extra = tolist(cdo_extra) or []        # util.py:47-53: None -> []
+        self.cdo_options = tolist(cdo_options) or []
         self.have_cdo = shutil.which(cdo) is not None
         self.env = os.environ.copy()                       # cdogenerate.py:61-66
         if cdo_download_path:
@@ -175,8 +175,8 @@ class CdoGenerate:
         env["REMAP_EXTRAPOLATE"] = "on" if extrapolate else "off"
         env["CDO_REMAP_NORM"] = remap_norm
         with tempfile.NamedTemporaryFile(suffix=".nc") as weight_file:
-            command = [self.cdo, *(self.cdo_options or []), f"gen{method},{tgrid}",
-                       *((self.cdo_extra or []) + (tolist(cdo_extra_vertical) or [])), sgrid, weight_file.name]
+            command = [self.cdo, *self.cdo_options, f"gen{method},{tgrid}",
+                       *(self.cdo_extra + (tolist(cdo_extra_vertical) or [])), sgrid, weight_file.name]
             self.loggy.debug("Final CDO command: %s", command)
             try:
                 subprocess.check_output(command, stderr=subprocess.STDOUT, env=env)

@@ -82,8 +82,10 @@ def test_constructor_and_call_errors(hip, rng):
     bad = DataArray(np.zeros((3, 5)), dims=("time", "station"), name="q")
     with pytest.raises(KeyError):
         rg.apply_weights(bad, w, horizontal_dims=["lon", "lat"])  # regrid.py:519-524
-    with pytest.raises(KeyError):
-        CdoGenerate("r96x48", "r36x18").weights(method="foo")   # cdogenerate.py:73-76
+    with pytest.raises(ValueError):
+        CdoGenerate("r96x48", "r36x18").weights(method="foo")   # cdogenerate.py:70-76 (_safe_check)
+    with pytest.raises(ValueError):
+        CdoGenerate("r96x48", "r36x18").weights(remap_norm="foo")   # cdogenerate.py:77-78
 
 
 def test_remap_area_min_counts_monotone(hip, rng):
