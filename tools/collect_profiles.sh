@@ -5,7 +5,7 @@
 # Per workload: the bench line, the rocprofv3 kernel-trace stats of the same command and (with "pmc")
 # the FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ passes, each in its own run as the pool requires.
 set -e
-tag=${1:-r01}
+tag=${1:-r02}
 wls=${2:-cfg2}
 pmc=${3:-}
 root=$PWD
@@ -27,7 +27,7 @@ for wl in $wls; do
     (cd /tmp && rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $d/rdreq -- python3 \
         $root/bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > /dev/null)
     python3 tools/summarize_pmc.py --fetch $d/fetch --write $d/write --rdreq $d/rdreq --key $wl/default/auto/0 \
-        --out $out/${tag}_${wl}_pmc_summary.json --traffic $out/traffic.json > /dev/null
+        --out $out/${tag}_${wl}_pmc_summary.json --traffic $out/traffic.json --git-head "${SMM_GIT_HEAD:-unknown}" > /dev/null
   fi
   echo "done $wl"
 done
