@@ -261,6 +261,11 @@ template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SP
 __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   constexpr int WPB = tile_waves(MAXK);
   constexpr int T = WPB * 64;
+  // Where the 1e20 fill happens: rows of more than 16 links test the staging pieces on their way into
+  // LDS (a 48-link row would test 48 gathered values per batch row, its ~15 pieces hold 30); short
+  // rows gather few values from comparatively many staged ones (config 4: 4 links, 8 staged f32 per
+  // lane and step) and test what they gather.
+  constexpr bool kFixAtStage = (MAXK == 0 || MAXK > 16);
   static_assert(!SPLIT || (WPB == 1 && R == 1 && MAXK > 0), "split rows: single-wave, single-row steps");
   static_assert(R == 1 || (MAXK > 0 && MAXK <= 16), "multi-row steps exist for the 4-wave shape only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     // padding nobody reads and the writes need no per-lane predicate (wave-uniform k < np_w only).
     auto store_tile = [&]() {
       if (!any_shifted) {
-        if (fill) {
+        if (kFixAtStage && fill) {
 #pragma unroll
           for (int k = 0; k < NP; ++k) {
             if (k >= np_w) break;
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             }
             __builtin_memcpy(&piece, out, 16);
           }
-          *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = fill ? fix_piece<XT>(piece) : piece;
+          *(u32x4*)(smem + (size_t)(tid + k * T) * 16) = (kFixAtStage && fill) ? fix_piece<XT>(piece) : piece;
         }
       }
     };
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                   const int k = k0 + kk;
                   const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
                                               : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-                  xv[kk] = (double)*(const XT*)((const char*)lds_x + li);
+                  xv[kk] = load_fixed((const XT*)((const char*)lds_x + li), fill && !kFixAtStage);
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                 const int k = k0 + kk;
                 const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
                                             : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-                xv[kk] = (double)*(const XT*)((const char*)lds_x + li);  // unconditional: offset 0 for unused slots; finite since staging
+                xv[kk] = load_fixed((const XT*)((const char*)lds_x + li), fill && !kFixAtStage);  // unconditional: offset 0 for unused slots
               }
 #pragma unroll
               for (int kk = 0; kk < 4; ++kk) {
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     auto store_tile = [&](int r) {   // unconditional natural-slot writes, fill on the way in (see R == 1)
       char* region = smem + r * tile_bytes;
       if (!any_shifted) {
-        if (fill) {
+        if (kFixAtStage && fill) {
 #pragma unroll
           for (int k = 0; k < NP; ++k) {
             if (k >= np_w) break;
@@ -721,7 +726,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
             }
             __builtin_memcpy(&piece, out, 16);
           }
-          *(u32x4*)(region + (size_t)(tid + k * T) * 16) = fill ? fix_piece<XT>(piece) : piece;
+          *(u32x4*)(region + (size_t)(tid + k * T) * 16) = (kFixAtStage && fill) ? fix_piece<XT>(piece) : piece;
         }
       }
     };
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                   const int k = k0 + kk;
                   const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16)
                                               : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-                  xv[kk] = (double)*(const XT*)((const char*)lds_r + li);  // unconditional: offset 0 for unused slots; finite since staging
+                  xv[kk] = load_fixed((const XT*)((const char*)lds_r + li), fill && !kFixAtStage);  // unconditional: offset 0 for unused slots
                 }
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
               const int kc = min(k, nslots - 1);
               const bool on = k < len;
               const int32_t li = cp[(int64_t)kc * 64];
-              const double xv = (double)lds_r[on ? li : 0];
+              const double xv = load_fixed(lds_r + (on ? li : 0), fill && !kFixAtStage);
               const double p = vp[(int64_t)kc * 64] * xv;
               const double sum = acc + p;
               acc = on ? sum : acc;
