@@ -134,6 +134,28 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz,
 int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
                             const int32_t* col, const double* val, int device,
                             smm_operator_t* out);
+/*
+ * The same two constructors with the shape of the destination grid (SCRIP `dst_grid_dims`, fastest
+ * dimension first, `regrid.py:572-579`) and the destination layout of the device structures:
+ *   SMM_LAYOUT_ROWS    consecutive destination cells per wavefront (what the plain constructors build)
+ *   SMM_LAYOUT_PATCHES 2-D grids: a 4-wave workgroup owns a patch of 4 grid rows x 64 grid columns and
+ *                      stages ONE source tile for it, so the source rows between vertically adjacent
+ *                      destination rows are fetched once per workgroup instead of once per wavefront
+ *                      (conservative remaps with 17..48 links per row: ~10 % less HBM traffic)
+ *   SMM_LAYOUT_AUTO    patches when the grid is 2-D, rows carry 17..48 links, padding the grid to whole
+ *                      patches costs <= 12.5 % and the patch plan stages >= 4 % fewer lines
+ * Results do not depend on the layout (bit-identical).  The members of a group must share one layout:
+ * create the first level with SMM_LAYOUT_AUTO, read the choice with smm_operator_plan_info (bit 2)
+ * and create the others with it.  dst_dims may be NULL (rank 0): same as the plain constructors.
+ */
+enum { SMM_LAYOUT_AUTO = 0, SMM_LAYOUT_ROWS = 1, SMM_LAYOUT_PATCHES = 2 };
+int smm_operator_create_grid(int64_t n_src, int64_t n_dst, int64_t nnz,
+                             const int32_t* src_addr_1based, const int32_t* dst_addr_1based,
+                             const double* w, const int32_t* dst_dims, int dst_rank, int layout,
+                             int device, smm_operator_t* out);
+int smm_operator_create_csr_grid(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
+                                 const int32_t* col, const double* val, const int32_t* dst_dims,
+                                 int dst_rank, int layout, int device, smm_operator_t* out);
 int smm_operator_destroy(smm_operator_t op);
 
 /* sizes after duplicate-summing; n_used_src = distinct source cells with >= 1 link (U) */
@@ -164,7 +186,8 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask,
 int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask);
 
 /* kernel selection the library made for this operator -- kernel_kind bit 0: an LDS tile plan
- * exists, bit 1: it is the default kernel (else SELL row-per-lane), bits 8..: destination rows
+ * exists, bit 1: it is the default kernel (else SELL row-per-lane), bit 2: destination patches
+ * (SMM_LAYOUT_PATCHES), bits 8..: destination rows
  * per block of the plan (256, 64, or 32 / 16 / 8 for rows with very wide footprints) */
 int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
                            int64_t* staged_src_elems);

@@ -23,6 +23,7 @@ SMM_F64 = 1
 APPLY_MASKED = 1 << 0
 APPLY_NO_FILL = 1 << 1
 APPLY_SB_PACKED = 1 << 2
+LAYOUT_AUTO, LAYOUT_ROWS, LAYOUT_PATCHES = 0, 1, 2
 APPLY_KERNEL_SELL = 1 << 8
 APPLY_KERNEL_TILE = 1 << 9
 
@@ -75,6 +76,8 @@ SIGNATURES = {
     "smm_fill_random": [_p, _int, _i64, ctypes.c_uint64, _dbl, _dbl, _p],
     "smm_operator_create": [_i64, _i64, _i64, _p, _p, _p, _int, _pp],
     "smm_operator_create_csr": [_i64, _i64, _p, _p, _p, _int, _pp],
+    "smm_operator_create_grid": [_i64, _i64, _i64, _p, _p, _p, _p, _int, _int, _int, _pp],
+    "smm_operator_create_csr_grid": [_i64, _i64, _p, _p, _p, _p, _int, _int, _int, _pp],
     "smm_operator_destroy": [_p],
     "smm_operator_info": [_p] + [ctypes.POINTER(_i64)] * 5,
     "smm_operator_export_csr": [_p, _p, _p, _p],

@@ -158,6 +158,45 @@ bool adopt_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_
   return true;
 }
 
+void build_patch_slots(int64_t nx, int64_t ny, int patch_rows, SlotMap& out) {
+  out = SlotMap();
+  const int64_t ncb = (nx + 63) / 64, nrb = (ny + patch_rows - 1) / patch_rows;
+  out.identity = false;
+  out.n_slots = nrb * ncb * patch_rows * 64;
+  out.row_of_slot.assign((size_t)out.n_slots, -1);
+  int64_t s = 0;
+  for (int64_t jb = 0; jb < nrb; ++jb)
+    for (int64_t ib = 0; ib < ncb; ++ib)
+      for (int w = 0; w < patch_rows; ++w)
+        for (int lane = 0; lane < 64; ++lane, ++s) {
+          const int64_t j = jb * patch_rows + w, i = ib * 64 + lane;
+          if (j < ny && i < nx) out.row_of_slot[(size_t)s] = (int32_t)(j * nx + i);
+        }
+}
+
+void permute_csr(const HostCsr& csr, const SlotMap& slots, HostCsr& out) {
+  out = HostCsr();
+  out.n_src = csr.n_src;
+  out.n_dst = slots.n_slots;
+  out.nnz = csr.nnz;
+  out.n_used_src = csr.n_used_src;
+  out.max_row_nnz = csr.max_row_nnz;
+  out.rowptr.assign((size_t)slots.n_slots + 1, 0);
+  out.col.resize((size_t)csr.nnz);
+  out.val.resize((size_t)csr.nnz);
+  int64_t p = 0;
+  for (int64_t s = 0; s < slots.n_slots; ++s) {
+    const int32_t r = slots.row_of_slot[(size_t)s];
+    if (r >= 0) {
+      const int64_t a = csr.rowptr[(size_t)r], b = csr.rowptr[(size_t)r + 1];
+      std::copy(csr.col.begin() + a, csr.col.begin() + b, out.col.begin() + p);
+      std::copy(csr.val.begin() + a, csr.val.begin() + b, out.val.begin() + p);
+      p += b - a;
+    }
+    out.rowptr[(size_t)s + 1] = p;
+  }
+}
+
 void build_sell(const HostCsr& csr, HostSell& out) {
   const int64_t n_slices = (csr.n_dst + 63) / 64;
   out.n_slices = n_slices;

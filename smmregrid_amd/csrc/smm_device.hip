@@ -144,7 +144,18 @@ constexpr int shape_rows(int which) { return which == 0 ? 256 : (64 >> (which - 
 
 struct smm_operator {
   int device = -1;
-  smm::HostCsr csr;
+  smm::HostCsr csr;          // canonical: row = destination cell (export, info, batch-fastest kernel)
+  // Destination slot order of the SELL / tile-plan structures below (smm_internal.h SlotMap): rows, or
+  // 4 x 64 patches of a 2-D destination grid.  With patches `pcsr` is the CSR in slot order and every
+  // per-row device array below (rowlen, imask, frac) is indexed by slot.
+  bool use_slots = false;
+  smm::SlotMap slots;
+  smm::HostCsr pcsr;
+  int32_t* d_row_of = nullptr;
+  uint8_t* d_imask_rows = nullptr;   // row-order copies for the batch-fastest kernel (patch order only)
+  double* d_frac_rows = nullptr;
+  int64_t dst_nx = 0, dst_ny = 0;    // destination grid dims when given at create time
+  const smm::HostCsr& kcsr() const { return use_slots ? pcsr : csr; }   // what the kernels see
   int64_t n_slices = 0, n_slots = 0;
   int64_t* d_slice_off = nullptr;
   int32_t* d_col = nullptr;
@@ -192,6 +203,7 @@ struct smm_operator {
     L.chunk_src = plan[which].d_chunk_src;
     L.lcol = plan[which].d_lcol;
     L.blk_direct = plan[which].d_blk_direct;
+    L.row_of = d_row_of;
     return L;
   }
 };
@@ -267,6 +279,9 @@ void release(smm_operator* op) {
     (void)hipFree(pl.d_blk_direct);
   }
   (void)hipFree(op->d_desc);
+  (void)hipFree(op->d_row_of);
+  (void)hipFree(op->d_imask_rows);
+  (void)hipFree(op->d_frac_rows);
   (void)hipFree(op->d_csr_rowptr);
   (void)hipFree(op->d_csr_col);
   (void)hipFree(op->d_csr_colp);
@@ -283,8 +298,8 @@ int ensure_plan(smm_operator* op, int which) {
   // LDS / staging-register budget: 64 KiB per 4-wave block, 16 KiB per single-wave block (whatever
   // part of the slice's rows it owns)
   const int64_t budget = which == 0 ? kTileMaxChunks : kTileMaxChunks / kWavesPerBlock;
-  smm::build_tile_plan(op->csr, op->sell_shape, shape_rows(which), kChunkElems, budget, hp);
-  smm::tighten_tile_plan(op->csr, hp, budget);
+  smm::build_tile_plan(op->kcsr(), op->sell_shape, shape_rows(which), kChunkElems, budget, hp);
+  smm::tighten_tile_plan(op->kcsr(), hp, budget);
   pl.built = true;
   if (!hp.valid) return SMM_OK;
   int rc = SMM_OK;
@@ -628,8 +643,52 @@ int smm_fill_random(void* dst, int dtype, int64_t n, uint64_t seed, double mean,
 
 // Shared by the two constructors: `fill_csr` builds op->csr (false + err on invalid input).
 extern "C++" {
+// Decides the destination slot order of a new operator (host work only).  Patches need a 2-D
+// destination grid; in SMM_LAYOUT_AUTO they are taken for rows of 17..48 links when they pad the
+// grid by <= 12.5 % and their tile plan stages >= 4 % fewer lines than the row-order plan.
+static int choose_layout(smm_operator* op, const int32_t* dst_dims, int dst_rank, int layout) {
+  if (layout != SMM_LAYOUT_AUTO && layout != SMM_LAYOUT_ROWS && layout != SMM_LAYOUT_PATCHES)
+    return fail(SMM_ERR_INVALID, "layout must be SMM_LAYOUT_AUTO, SMM_LAYOUT_ROWS or SMM_LAYOUT_PATCHES");
+  const smm::HostCsr& csr = op->csr;
+  bool can = false;
+  if (dst_dims && dst_rank == 2 && dst_dims[0] > 0 && dst_dims[1] > 0 &&
+      (int64_t)dst_dims[0] * dst_dims[1] == csr.n_dst) {
+    op->dst_nx = dst_dims[0];   // SCRIP dst_grid_dims: fastest first
+    op->dst_ny = dst_dims[1];
+    can = true;
+  }
+  if (layout == SMM_LAYOUT_PATCHES && !can)
+    return fail(SMM_ERR_INVALID, "SMM_LAYOUT_PATCHES needs dst_dims of rank 2 whose product is n_dst");
+  if (!can || layout == SMM_LAYOUT_ROWS) return SMM_OK;
+  if (layout == SMM_LAYOUT_AUTO && !(csr.max_row_nnz > 16 && csr.max_row_nnz <= 48)) return SMM_OK;
+  smm::SlotMap map;
+  smm::build_patch_slots(op->dst_nx, op->dst_ny, kWavesPerBlock, map);
+  if (layout == SMM_LAYOUT_AUTO && map.n_slots * 8 > csr.n_dst * 9) return SMM_OK;   // > 12.5 % padding
+  smm::HostCsr pcsr;
+  smm::permute_csr(csr, map, pcsr);
+  if (layout == SMM_LAYOUT_AUTO) {
+    smm::HostSell si, sp;
+    smm::HostTilePlan hi, hp;
+    smm::build_sell(csr, si);
+    smm::build_tile_plan(csr, si, shape_rows(1), kChunkElems, kTileMaxChunks / kWavesPerBlock, hi);
+    smm::build_sell(pcsr, sp);
+    smm::build_tile_plan(pcsr, sp, shape_rows(0), kChunkElems, kTileMaxChunks, hp);
+    smm::tighten_tile_plan(pcsr, hp, kTileMaxChunks);
+    const int64_t np = (hp.max_block_chunks * 8 + kThreads - 1) / kThreads;   // 16-B pieces per thread (f64)
+    const bool good = hp.valid && np <= 16 &&
+                      hp.total_distinct * 10 >= hp.total_chunks * (int64_t)hp.chunk_elems &&
+                      (!hi.valid || hp.total_chunks * 100 <= hi.total_chunks * 96);
+    if (!good) return SMM_OK;
+  }
+  op->use_slots = true;
+  op->slots = std::move(map);
+  op->pcsr = std::move(pcsr);
+  return SMM_OK;
+}
+
 template <typename F>
-static int create_operator(int device, smm_operator_t* out, F fill_csr) {
+static int create_operator(int device, smm_operator_t* out, F fill_csr, const int32_t* dst_dims = nullptr,
+                           int dst_rank = 0, int layout = SMM_LAYOUT_AUTO) {
   if (!out) return fail(SMM_ERR_INVALID, "null out handle");
   *out = nullptr;
   int ndev = 0;
@@ -654,8 +713,14 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr) {
       delete op;
       return fail(SMM_ERR_INVALID, err);
     }
+    int lrc = choose_layout(op, dst_dims, dst_rank, layout);
+    if (lrc) {
+      delete op;
+      return lrc;
+    }
+    const smm::HostCsr& kc = op->kcsr();
     smm::HostSell sell;
-    smm::build_sell(op->csr, sell);
+    smm::build_sell(kc, sell);
 
     DeviceGuard guard(device);
     if (!guard.ok) {
@@ -676,19 +741,29 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr) {
     op->sell_shape.rowlen = std::move(sell.rowlen);
     // own block shape: 256 rows for rows of <= 16 links; else one slice, or the largest part of a
     // slice whose footprint fits the LDS budget and is used well enough (plan valid and preferred)
-    op->native = op->csr.max_row_nnz > 16 ? 1 : 0;
-#ifdef SMM_EXP_WAVES4
-    if (op->csr.max_row_nnz <= 48) op->native = 0;
-#endif
+    if (op->use_slots && (rc = upload(&op->d_row_of, op->slots.row_of_slot))) {
+      release(op);
+      return rc;
+    }
+    // destination patches: a 4-wave workgroup owns a 4 x 64 patch (shape 0) also for rows of 17..48 links
+    op->native = (kc.max_row_nnz > 16 && !(op->use_slots && kc.max_row_nnz <= 48)) ? 1 : 0;
     if ((rc = ensure_plan(op, op->native))) {
       release(op);
       return rc;
+    }
+    if (op->native == 0 && kc.max_row_nnz > 16 &&
+        !(op->plan[0].valid && op->plan[0].max_chunks * 8 <= 16 * kThreads)) {
+      op->native = 1;   // forced patches whose 4-wave tile does not fit: single-wave blocks on the slot order
+      if ((rc = ensure_plan(op, op->native))) {
+        release(op);
+        return rc;
+      }
     }
     if (op->native == 1) {
       // rows beyond 48 links: start at the shape whose lane groups can keep the whole row in
       // registers (split rows) -- streaming the links from L2 is ~2x slower; else from one slice
       int w_first = 1;
-      while (w_first < kNumShapes - 1 && op->csr.max_row_nnz > 48ll << (w_first - 1)) ++w_first;
+      while (w_first < kNumShapes - 1 && kc.max_row_nnz > 48ll << (w_first - 1)) ++w_first;
       bool found = false;
       for (int pass = 0; pass < 2 && !found; ++pass) {
         for (int w = pass == 0 ? w_first : 1; w < (pass == 0 ? kNumShapes : w_first) && !found; ++w) {
@@ -733,11 +808,27 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
   });
 }
 
+int smm_operator_create_grid(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src_addr_1based,
+                             const int32_t* dst_addr_1based, const double* w, const int32_t* dst_dims,
+                             int dst_rank, int layout, int device, smm_operator_t* out) {
+  return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
+    return smm::build_csr(n_src, n_dst, nnz, src_addr_1based, dst_addr_1based, w, csr, err);
+  }, dst_dims, dst_rank, layout);
+}
+
 int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
                             const double* val, int device, smm_operator_t* out) {
   return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
     return smm::adopt_csr(n_src, n_dst, rowptr, col, val, csr, err);
   });
+}
+
+int smm_operator_create_csr_grid(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
+                                 const double* val, const int32_t* dst_dims, int dst_rank, int layout,
+                                 int device, smm_operator_t* out) {
+  return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
+    return smm::adopt_csr(n_src, n_dst, rowptr, col, val, csr, err);
+  }, dst_dims, dst_rank, layout);
 }
 
 int smm_operator_destroy(smm_operator_t op) {
@@ -778,23 +869,45 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   const size_t n = (size_t)op->csr.n_dst;
   // upload the new vectors first: on failure the operator keeps its old state untouched
-  uint8_t* new_imask = nullptr;
-  double* new_frac = nullptr;
+  uint8_t *new_imask = nullptr, *new_imask_rows = nullptr;
+  double *new_frac = nullptr, *new_frac_rows = nullptr;
+  auto drop_new = [&]() {
+    (void)hipFree(new_imask);
+    (void)hipFree(new_imask_rows);
+    (void)hipFree(new_frac);
+    (void)hipFree(new_frac_rows);
+  };
+  const std::vector<int32_t>& row_of = op->slots.row_of_slot;   // patch order: kernels index by slot
   if (dst_imask) {
     std::vector<uint8_t> m(n);
     for (size_t i = 0; i < n; ++i) m[i] = dst_imask[i] != 0;  // .astype(bool), regrid.py:557
-    int rc = upload(&new_imask, m);
+    int rc = SMM_OK;
+    if (op->use_slots) {
+      std::vector<uint8_t> ms(row_of.size(), 1);
+      for (size_t k = 0; k < row_of.size(); ++k)
+        if (row_of[k] >= 0) ms[k] = m[(size_t)row_of[k]];
+      if (!(rc = upload(&new_imask, ms))) rc = upload(&new_imask_rows, m);
+    } else {
+      rc = upload(&new_imask, m);
+    }
     if (rc) {
-      (void)hipFree(new_imask);
+      drop_new();
       return rc;
     }
   }
   if (dst_frac) {
     std::vector<double> f(dst_frac, dst_frac + n);
-    int rc = upload(&new_frac, f);
+    int rc = SMM_OK;
+    if (op->use_slots) {
+      std::vector<double> fs(row_of.size(), 1.0);
+      for (size_t k = 0; k < row_of.size(); ++k)
+        if (row_of[k] >= 0) fs[k] = f[(size_t)row_of[k]];
+      if (!(rc = upload(&new_frac, fs))) rc = upload(&new_frac_rows, f);
+    } else {
+      rc = upload(&new_frac, f);
+    }
     if (rc) {
-      (void)hipFree(new_imask);
-      (void)hipFree(new_frac);
+      drop_new();
       return rc;
     }
   }
@@ -806,12 +919,15 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
   if (rc) {  // the device descriptor still names the old vectors: keep them
     op->d_imask = old_imask;
     op->d_frac = old_frac;
-    (void)hipFree(new_imask);
-    (void)hipFree(new_frac);
+    drop_new();
     return rc;
   }
   (void)hipFree(old_imask);
   (void)hipFree(old_frac);
+  (void)hipFree(op->d_imask_rows);
+  (void)hipFree(op->d_frac_rows);
+  op->d_imask_rows = new_imask_rows;
+  op->d_frac_rows = new_frac_rows;
   return SMM_OK;
 }
 
@@ -820,7 +936,8 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   const smm_operator::TilePlan& pl = op->plan[op->native_plan()];
   if (kernel_kind)
-    *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0) | (shape_rows(op->native_plan()) << 8);
+    *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0) | (op->use_slots ? 4 : 0) |
+                   (shape_rows(op->native_plan()) << 8);
   if (lds_bytes) *lds_bytes = pl.valid ? pl.max_chunks * kChunkElems * 8 : 0;
   if (staged_src_elems) *staged_src_elems = pl.valid ? pl.total_chunks * kChunkElems : 0;
   return SMM_OK;
@@ -839,7 +956,7 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   const int pw = op->native_plan();
   const smm_operator::TilePlan& pl = op->plan[pw];
-  return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid,
+  return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->kcsr().n_dst, pw, pl.valid,
                    pl.preferred, (pl.reuse ? 1 : 0), pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
@@ -888,8 +1005,8 @@ int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, voi
   a.rowptr = op->d_csr_rowptr;
   a.col = (flags & SMM_APPLY_SB_PACKED) ? op->d_csr_colp : op->d_csr_col;
   a.val = op->d_csr_val;
-  a.imask = op->d_imask;
-  a.frac = op->d_frac;
+  a.imask = op->use_slots ? op->d_imask_rows : op->d_imask;   // kernel C indexes by destination cell
+  a.frac = op->use_slots ? op->d_frac_rows : op->d_frac;
   a.x = x;
   a.y = y;
   a.ldx = ldx;
@@ -994,7 +1111,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     }
     const int pw = op->native_plan();
     const smm_operator::TilePlan& pl = op->plan[pw];
-    int rc = run_apply(op->d_desc, nullptr, nullptr, S, D, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
+    int rc = run_apply(op->d_desc, nullptr, nullptr, S, op->kcsr().n_dst, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
                        pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
                        ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
                        pipe.stream[b]);
@@ -1046,7 +1163,7 @@ int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t
     cleanup();
     return fail(SMM_ERR_HIP, "hipMemcpy failed in smm_operator_mask_apply");
   }
-  rc = run_apply(op->d_desc, nullptr, nullptr, S, D, 0, false, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
+  rc = run_apply(op->d_desc, nullptr, nullptr, S, op->kcsr().n_dst, 0, false, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
                  std::max<int64_t>(S, 1), 0, 0, dy, SMM_F64, D, 0, 0, 1, 1, 1, 0.0,
                  SMM_APPLY_NO_FILL, nullptr);
   if (rc == SMM_OK) {
@@ -1073,6 +1190,10 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
     if (ops[i]->device != ops[0]->device || ops[i]->csr.n_src != ops[0]->csr.n_src ||
         ops[i]->csr.n_dst != ops[0]->csr.n_dst)
       return fail(SMM_ERR_INVALID, "group members must share device and grid sizes");
+    // one launch covers all levels: one destination slot order for all members
+    if (ops[i]->use_slots != ops[0]->use_slots || ops[i]->kcsr().n_dst != ops[0]->kcsr().n_dst)
+      return fail(SMM_ERR_INVALID, "group members must share the destination layout: create them with the same "
+                                   "SMM_LAYOUT_* (smm_operator_create_grid)");
   }
   smm_group* g = new (std::nothrow) smm_group();
   if (!g) return fail(SMM_ERR_ALLOC, "out of host memory");
@@ -1215,7 +1336,7 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
   int rc = group_level_cfg(g, n_lev, level_index, masked_levels, remap_area_min, flags, &d_map, &d_masked);
   if (rc || n_lev == 0) return rc;
   const smm_operator* op0 = g->ops[0];
-  return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_which,
+  return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->kcsr().n_dst, g->tile_which,
                    g->tile_valid, g->tile_preferred, (g->tile_reuse ? 1 : 0), g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
@@ -1241,7 +1362,7 @@ int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, un
   const int pw = op->native_plan();
   const smm_operator::TilePlan& pl = op->plan[pw];
   LaunchInfo li;
-  int rc = run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid, pl.preferred,
+  int rc = run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->kcsr().n_dst, pw, pl.valid, pl.preferred,
                      (pl.reuse ? 1 : 0), pl.max_chunks, op->csr.max_row_nnz, nullptr, x_dtype, op->csr.n_src, 0, 0,
                      nullptr, SMM_F64, op->csr.n_dst, 0, 0, n_batch, 1, 1, 0.0, flags, nullptr, &li);
   if (rc) return rc;
@@ -1255,7 +1376,7 @@ int smm_group_launch_info(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   const smm_operator* op0 = g->ops[0];
   LaunchInfo li;
-  int rc = run_apply(g->d_descs, nullptr, nullptr, op0->csr.n_src, op0->csr.n_dst, g->tile_which, g->tile_valid,
+  int rc = run_apply(g->d_descs, nullptr, nullptr, op0->csr.n_src, op0->kcsr().n_dst, g->tile_which, g->tile_valid,
                      g->tile_preferred, (g->tile_reuse ? 1 : 0), g->tile_max_chunks, g->max_row_nnz, nullptr,
                      x_dtype, 0, 0, 0, nullptr, SMM_F64, 0, 0, 0, n_outer, n_lev, n_inner, 0.0, flags, nullptr, &li);
   if (rc) return rc;

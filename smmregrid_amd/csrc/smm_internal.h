@@ -35,6 +35,22 @@ struct HostSell {
   std::vector<double> val;          // n_slots (padding: 0.0)
 };
 
+// Destination slot order.  The device structures (SELL slices, tile-plan blocks) are built over
+// "slots": by default slot == destination row; for a 2-D destination grid whose rows are heavy the
+// slots follow PATCHES of `patch_rows` grid rows x 64 grid columns, one grid row of a patch per SELL
+// slice (= wavefront), so that the `patch_rows` waves of a workgroup share ONE staged source tile
+// whose halo -- the source rows between vertically adjacent destination rows -- is fetched once
+// instead of once per wave.  Patches at the grid's right / upper edge are padded with empty slots
+// (row_of_slot == -1).
+struct SlotMap {
+  bool identity = true;
+  int64_t n_slots = 0;
+  std::vector<int32_t> row_of_slot;   // [n_slots] destination row, or -1
+};
+void build_patch_slots(int64_t nx, int64_t ny, int patch_rows, SlotMap& out);
+// CSR whose row s is row row_of_slot[s] of `csr` (empty for padding slots); n_dst = n_slots.
+void permute_csr(const HostCsr& csr, const SlotMap& slots, HostCsr& out);
+
 // Returns false and fills err on invalid input.
 bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
                const int32_t* dst1, const double* w, HostCsr& out, std::string& err);

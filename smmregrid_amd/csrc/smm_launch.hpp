@@ -134,8 +134,13 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   const int64_t per_grp = (max_row_nnz + n_grp - 1) / n_grp;
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
-#ifndef SMM_EXP_WAVES4
     if constexpr (MAXK == 32 || MAXK == 48) {
+      if (!tile_which) {   // heavy rows in 4-wave workgroups (destination patches): one shared tile per 256 slots
+        hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, false, 4>),
+                           dim3((unsigned)total), dim3(kWavesPerBlock * 64), lds, s, args, fill);
+        SMM_LAUNCH_HIP(hipGetLastError());
+        return SMM_OK;
+      }
       if (split) {
         hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, true>),
                            dim3((unsigned)total), dim3(64), lds, s, args, fill);
@@ -143,22 +148,19 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
         return SMM_OK;
       }
     }
-#endif
     if constexpr (MAXK > 0 && MAXK <= 16) {
       if (rows == 4) return go3(k_tag, std::integral_constant<int, 1>(), nt_tag, std::integral_constant<int, 4>());
       if (rows == 2) return go3(k_tag, std::integral_constant<int, 2>(), nt_tag, std::integral_constant<int, 2>());
     }
     return go3(k_tag, np_tag, nt_tag, std::integral_constant<int, 1>());
   };
-  auto with_k = [&](auto fn) -> int {  // plan shape 0 <-> MAXK <= 16 (4 waves), shape 1 <-> MAXK >= 32 / 0 (1 wave)
+  auto with_k = [&](auto fn) -> int {  // plan shape 0 <-> 4 waves (MAXK <= 16, or 32 / 48 on destination patches), shape 1.. <-> 1 wave
     if (!tile_which) {
       if (max_row_nnz <= 4) return fn(std::integral_constant<int, 4>());
       if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
-#ifdef SMM_EXP_WAVES4
-      if (max_row_nnz > 32) return fn(std::integral_constant<int, 48>());
-      if (max_row_nnz > 16) return fn(std::integral_constant<int, 32>());
-#endif
-      return fn(std::integral_constant<int, 16>());
+      if (max_row_nnz <= 16) return fn(std::integral_constant<int, 16>());
+      if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
+      return fn(std::integral_constant<int, 48>());   // shape 0 is only planned for rows of <= 48 links
     }
     if (variant == 14) return fn(std::integral_constant<int, 0>());  // tuning: stream the links
     if (split) return per_grp <= 32 ? fn(std::integral_constant<int, 32>()) : fn(std::integral_constant<int, 48>());

@@ -17,6 +17,20 @@ def _cptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
+_LAYOUTS = {"auto": _lib.LAYOUT_AUTO, "rows": _lib.LAYOUT_ROWS, "patches": _lib.LAYOUT_PATCHES}
+
+
+def _grid_args(dst_dims, layout):
+    if layout not in _LAYOUTS:
+        raise ValueError(f"layout must be one of {sorted(_LAYOUTS)}")
+    if dst_dims is None:
+        if layout == "patches":
+            raise ValueError("layout='patches' needs dst_dims")
+        return None, 0, _LAYOUTS[layout]
+    dims = np.ascontiguousarray(dst_dims, dtype=np.int32).ravel()
+    return dims, int(dims.size), _LAYOUTS[layout]
+
+
 def _launch_info(fn, handle, dt, sizes, flags):
     ints = [ctypes.c_int(0) for _ in range(5)]
     nb, lds = ctypes.c_int64(0), ctypes.c_int64(0)
@@ -31,7 +45,12 @@ def _launch_info(fn, handle, dt, sizes, flags):
 class SparseOperator:
     """(S x D) weights matrix in HBM, built from SCRIP links (weights.py:25-44)."""
 
-    def __init__(self, n_src, n_dst, src_address, dst_address, remap_matrix, device=None):
+    def __init__(self, n_src, n_dst, src_address, dst_address, remap_matrix, device=None, dst_dims=None,
+                 layout="auto"):
+        """dst_dims: shape of the destination grid as the weights file gives it (`dst_grid_dims`,
+        fastest dimension first); with it the library may lay the device structures out in 4 x 64
+        patches of a 2-D target grid (`layout`: "auto" | "rows" | "patches", smm_operator_create_grid).
+        Results do not depend on the layout; the members of an OperatorGroup must share one."""
         src = np.ascontiguousarray(src_address, dtype=np.int32).ravel()
         dst = np.ascontiguousarray(dst_address, dtype=np.int32).ravel()
         w = np.asarray(remap_matrix, dtype=np.float64)
@@ -44,8 +63,10 @@ class SparseOperator:
             device = current_device()
         self.device = int(device)
         h = ctypes.c_void_p()
-        _lib.call("smm_operator_create", int(n_src), int(n_dst), int(src.size), _cptr(src),
-                  _cptr(dst), _cptr(w), self.device, ctypes.byref(h))
+        dims, rank, lay = _grid_args(dst_dims, layout)
+        _lib.call("smm_operator_create_grid", int(n_src), int(n_dst), int(src.size), _cptr(src),
+                  _cptr(dst), _cptr(w), _cptr(dims), rank, lay, self.device, ctypes.byref(h))
+        self.dst_dims = None if dims is None else tuple(int(v) for v in dims)
         self._adopt(h)
 
     def _adopt(self, handle):
@@ -57,7 +78,7 @@ class SparseOperator:
         self.has_frac = False
 
     @classmethod
-    def from_csr(cls, n_src, n_dst, rowptr, col, val, device=None):
+    def from_csr(cls, n_src, n_dst, rowptr, col, val, device=None, dst_dims=None, layout="auto"):
         """Operator from a canonical CSR (what export_csr returned): no sort, no duplicate pass.
         A non-canonical CSR (unsorted or repeated columns, bad rowptr) is a ValueError."""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64).ravel()
@@ -70,9 +91,11 @@ class SparseOperator:
         self = cls.__new__(cls)
         self.device = int(current_device() if device is None else device)
         h = ctypes.c_void_p()
+        dims, rank, lay = _grid_args(dst_dims, layout)
+        self.dst_dims = None if dims is None else tuple(int(v) for v in dims)
         try:
-            _lib.call("smm_operator_create_csr", int(n_src), int(n_dst), _cptr(rowptr), _cptr(col), _cptr(val),
-                      self.device, ctypes.byref(h))
+            _lib.call("smm_operator_create_csr_grid", int(n_src), int(n_dst), _cptr(rowptr), _cptr(col),
+                      _cptr(val), _cptr(dims), rank, lay, self.device, ctypes.byref(h))
         except _lib.SmmError as e:
             if e.code == _lib.SMM_ERR_INVALID:
                 raise ValueError(str(e)) from None
@@ -86,6 +109,8 @@ class SparseOperator:
         rowptr, col, val = self.export_csr()
         payload = {"shape": np.array([self.n_src, self.n_dst], dtype=np.int64), "rowptr": rowptr, "col": col,
                    "val": val}
+        if getattr(self, "dst_dims", None):
+            payload["dst_dims"] = np.asarray(self.dst_dims, dtype=np.int32)
         for name in ("_dst_imask", "_dst_frac"):
             a = getattr(self, name, None)
             if a is not None:
@@ -96,7 +121,8 @@ class SparseOperator:
     def load(cls, path, device=None):
         z = np.load(path, allow_pickle=False)
         n_src, n_dst = (int(v) for v in z["shape"])
-        op = cls.from_csr(n_src, n_dst, z["rowptr"], z["col"], z["val"], device=device)
+        op = cls.from_csr(n_src, n_dst, z["rowptr"], z["col"], z["val"], device=device,
+                          dst_dims=z["dst_dims"] if "dst_dims" in z.files else None)
         if "dst_imask" in z.files or "dst_frac" in z.files:
             op.set_epilogue(z["dst_imask"] if "dst_imask" in z.files else None,
                             z["dst_frac"] if "dst_frac" in z.files else None)
@@ -135,7 +161,8 @@ class SparseOperator:
         _lib.call("smm_operator_plan_info", self.handle, ctypes.byref(kind), ctypes.byref(lds),
                   ctypes.byref(staged))
         return {"tile_plan": bool(kind.value & 1), "tile_preferred": bool(kind.value & 2),
-                "lds_bytes": lds.value, "staged_src_elems": staged.value, "rows_per_block": kind.value >> 8}
+                "dst_patches": bool(kind.value & 4), "lds_bytes": lds.value, "staged_src_elems": staged.value,
+                "rows_per_block": kind.value >> 8}
 
     def launch_info(self, n_batch, dtype=np.float64, flags=0):
         """Launch geometry `apply` would use for `n_batch` rows (nothing is launched)."""

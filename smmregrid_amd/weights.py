@@ -20,6 +20,13 @@ def _level_slice(var, mask_dim, i):
     return v
 
 
+def _dst_dims(weights):
+    """dst_grid_dims of the weights file (fastest dimension first, regrid.py:572-579), or None."""
+    if "dst_grid_dims" not in weights:
+        return None
+    return np.asarray(weights["dst_grid_dims"].values).astype(np.int32).ravel()
+
+
 def compute_weights_matrix(weights, device=None):
     """CDO weights -> one operator of shape (S, D)   (weights.py:25-44)."""
     weights = from_xarray(weights)
@@ -30,7 +37,8 @@ def compute_weights_matrix(weights, device=None):
         remap_matrix = remap_matrix[:, 0]
     n_src = weights.sizes["src_grid_size"]
     n_dst = weights.sizes["dst_grid_size"]
-    return SparseOperator(n_src, n_dst, src_address, dst_address, remap_matrix, device=device)
+    return SparseOperator(n_src, n_dst, src_address, dst_address, remap_matrix, device=device,
+                          dst_dims=_dst_dims(weights))
 
 
 def compute_weights_matrix3d(weights, mask_dim="lev", device=None):
@@ -39,14 +47,24 @@ def compute_weights_matrix3d(weights, mask_dim="lev", device=None):
     link_length = np.asarray(weights["link_length"].values).astype(np.int64)
     n_src = weights.sizes["src_grid_size"]
     n_dst = weights.sizes["dst_grid_size"]
-    sparse_weights = []
-    for i, nl in enumerate(link_length):
+    dims = _dst_dims(weights)
+    sparse_weights = [None] * len(link_length)
+    # The levels are applied in one grouped launch and must share one destination layout: the level
+    # with the most links decides (rows, or 4 x 64 patches of the 2-D target grid), the others follow.
+    order = [int(np.argmax(link_length))] if len(link_length) else []
+    order += [i for i in range(len(link_length)) if i not in order]
+    layout = "auto"
+    for i in order:
+        nl = link_length[i]
         src = _level_slice(weights["src_address"], mask_dim, i)[:nl]
         dst = _level_slice(weights["dst_address"], mask_dim, i)[:nl]
         rm = _level_slice(weights["remap_matrix"], mask_dim, i)[:nl]
         if rm.ndim == 2:
             rm = rm[:, 0]
-        sparse_weights.append(SparseOperator(n_src, n_dst, src, dst, rm, device=device))
+        op = SparseOperator(n_src, n_dst, src, dst, rm, device=device, dst_dims=dims, layout=layout)
+        if layout == "auto":
+            layout = "patches" if op.plan_info()["dst_patches"] else "rows"
+        sparse_weights[i] = op
     return sparse_weights
 
 
