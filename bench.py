@@ -130,7 +130,8 @@ class Problem2D:
         w = self.weights
         self.n_src, self.n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
         self.op = SparseOperator(self.n_src, self.n_dst, w["src_address"].values,
-                                 w["dst_address"].values, w["remap_matrix"].values, device=device)
+                                 w["dst_address"].values, w["remap_matrix"].values, device=device,
+                                 dst_dims=w["dst_grid_dims"].values)
         self.op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
         self.np_dt = np.float64 if self.x_dtype == "f64" else np.float32
         x_shape = {"bs": (self.n_batch, self.n_src), "sb": (self.n_src, self.n_batch),

@@ -141,12 +141,12 @@ int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
  *   SMM_LAYOUT_PATCHES 2-D grids: a 4-wave workgroup owns a patch of 4 grid rows x 64 grid columns and
  *                      stages ONE source tile for it, so the source rows between vertically adjacent
  *                      destination rows are fetched once per workgroup instead of once per wavefront
- *                      (conservative remaps with 17..48 links per row: ~10 % less HBM traffic)
- *   SMM_LAYOUT_AUTO    patches when the grid is 2-D, rows carry 17..48 links, padding the grid to whole
- *                      patches costs <= 12.5 % and the patch plan stages >= 4 % fewer lines
- * Results do not depend on the layout (bit-identical).  The members of a group must share one layout:
- * create the first level with SMM_LAYOUT_AUTO, read the choice with smm_operator_plan_info (bit 2)
- * and create the others with it.  dst_dims may be NULL (rank 0): same as the plain constructors.
+ *                      (conservative remaps with 17..48 links per row: ~11 % fewer staged lines).
+ *                      Opt-in: on MI355X the barriers that couple the four waves cost what the
+ *                      traffic saves, so it is not chosen automatically.
+ *   SMM_LAYOUT_AUTO    the library's choice: rows
+ * Results do not depend on the layout (bit-identical).  The members of a group must share one layout.
+ * dst_dims may be NULL (rank 0): same as the plain constructors.
  */
 enum { SMM_LAYOUT_AUTO = 0, SMM_LAYOUT_ROWS = 1, SMM_LAYOUT_PATCHES = 2 };
 int smm_operator_create_grid(int64_t n_src, int64_t n_dst, int64_t nnz,

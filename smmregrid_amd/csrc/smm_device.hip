@@ -643,9 +643,10 @@ int smm_fill_random(void* dst, int dtype, int64_t n, uint64_t seed, double mean,
 
 // Shared by the two constructors: `fill_csr` builds op->csr (false + err on invalid input).
 extern "C++" {
-// Decides the destination slot order of a new operator (host work only).  Patches need a 2-D
-// destination grid; in SMM_LAYOUT_AUTO they are taken for rows of 17..48 links when they pad the
-// grid by <= 12.5 % and their tile plan stages >= 4 % fewer lines than the row-order plan.
+// Destination slot order of a new operator (host work only).  Patches are opt-in: measured on MI355X
+// (config 3, `tools/exp/ab_layout.sh`) they stage 11 % fewer lines than 64-row blocks, but the two
+// barriers per batch row that couple the four waves of a patch cost as much as the traffic saves
+// (12.6 vs 12.5 ms), so SMM_LAYOUT_AUTO keeps rows.
 static int choose_layout(smm_operator* op, const int32_t* dst_dims, int dst_rank, int layout) {
   if (layout != SMM_LAYOUT_AUTO && layout != SMM_LAYOUT_ROWS && layout != SMM_LAYOUT_PATCHES)
     return fail(SMM_ERR_INVALID, "layout must be SMM_LAYOUT_AUTO, SMM_LAYOUT_ROWS or SMM_LAYOUT_PATCHES");
@@ -657,32 +658,11 @@ static int choose_layout(smm_operator* op, const int32_t* dst_dims, int dst_rank
     op->dst_ny = dst_dims[1];
     can = true;
   }
-  if (layout == SMM_LAYOUT_PATCHES && !can)
-    return fail(SMM_ERR_INVALID, "SMM_LAYOUT_PATCHES needs dst_dims of rank 2 whose product is n_dst");
-  if (!can || layout == SMM_LAYOUT_ROWS) return SMM_OK;
-  if (layout == SMM_LAYOUT_AUTO && !(csr.max_row_nnz > 16 && csr.max_row_nnz <= 48)) return SMM_OK;
-  smm::SlotMap map;
-  smm::build_patch_slots(op->dst_nx, op->dst_ny, kWavesPerBlock, map);
-  if (layout == SMM_LAYOUT_AUTO && map.n_slots * 8 > csr.n_dst * 9) return SMM_OK;   // > 12.5 % padding
-  smm::HostCsr pcsr;
-  smm::permute_csr(csr, map, pcsr);
-  if (layout == SMM_LAYOUT_AUTO) {
-    smm::HostSell si, sp;
-    smm::HostTilePlan hi, hp;
-    smm::build_sell(csr, si);
-    smm::build_tile_plan(csr, si, shape_rows(1), kChunkElems, kTileMaxChunks / kWavesPerBlock, hi);
-    smm::build_sell(pcsr, sp);
-    smm::build_tile_plan(pcsr, sp, shape_rows(0), kChunkElems, kTileMaxChunks, hp);
-    smm::tighten_tile_plan(pcsr, hp, kTileMaxChunks);
-    const int64_t np = (hp.max_block_chunks * 8 + kThreads - 1) / kThreads;   // 16-B pieces per thread (f64)
-    const bool good = hp.valid && np <= 16 &&
-                      hp.total_distinct * 10 >= hp.total_chunks * (int64_t)hp.chunk_elems &&
-                      (!hi.valid || hp.total_chunks * 100 <= hi.total_chunks * 96);
-    if (!good) return SMM_OK;
-  }
+  if (layout != SMM_LAYOUT_PATCHES) return SMM_OK;
+  if (!can) return fail(SMM_ERR_INVALID, "SMM_LAYOUT_PATCHES needs dst_dims of rank 2 whose product is n_dst");
+  smm::build_patch_slots(op->dst_nx, op->dst_ny, kWavesPerBlock, op->slots);
+  smm::permute_csr(csr, op->slots, op->pcsr);
   op->use_slots = true;
-  op->slots = std::move(map);
-  op->pcsr = std::move(pcsr);
   return SMM_OK;
 }
 

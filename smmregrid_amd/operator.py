@@ -23,6 +23,9 @@ _LAYOUTS = {"auto": _lib.LAYOUT_AUTO, "rows": _lib.LAYOUT_ROWS, "patches": _lib.
 def _grid_args(dst_dims, layout):
     if layout not in _LAYOUTS:
         raise ValueError(f"layout must be one of {sorted(_LAYOUTS)}")
+    import os
+    if layout == "auto" and os.environ.get("SMM_LAYOUT") in ("rows", "patches") and dst_dims is not None:
+        layout = os.environ["SMM_LAYOUT"]          # A/B runs of the two destination layouts (bench.py)
     if dst_dims is None:
         if layout == "patches":
             raise ValueError("layout='patches' needs dst_dims")

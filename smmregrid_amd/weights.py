@@ -27,7 +27,7 @@ def _dst_dims(weights):
     return np.asarray(weights["dst_grid_dims"].values).astype(np.int32).ravel()
 
 
-def compute_weights_matrix(weights, device=None):
+def compute_weights_matrix(weights, device=None, layout="auto"):
     """CDO weights -> one operator of shape (S, D)   (weights.py:25-44)."""
     weights = from_xarray(weights)
     src_address = weights["src_address"].values
@@ -38,33 +38,26 @@ def compute_weights_matrix(weights, device=None):
     n_src = weights.sizes["src_grid_size"]
     n_dst = weights.sizes["dst_grid_size"]
     return SparseOperator(n_src, n_dst, src_address, dst_address, remap_matrix, device=device,
-                          dst_dims=_dst_dims(weights))
+                          dst_dims=_dst_dims(weights), layout=layout)
 
 
-def compute_weights_matrix3d(weights, mask_dim="lev", device=None):
+def compute_weights_matrix3d(weights, mask_dim="lev", device=None, layout="auto"):
     """Per-level operators; links truncated to link_length[level]   (weights.py:7-23)."""
     weights = from_xarray(weights)
     link_length = np.asarray(weights["link_length"].values).astype(np.int64)
     n_src = weights.sizes["src_grid_size"]
     n_dst = weights.sizes["dst_grid_size"]
     dims = _dst_dims(weights)
-    sparse_weights = [None] * len(link_length)
-    # The levels are applied in one grouped launch and must share one destination layout: the level
-    # with the most links decides (rows, or 4 x 64 patches of the 2-D target grid), the others follow.
-    order = [int(np.argmax(link_length))] if len(link_length) else []
-    order += [i for i in range(len(link_length)) if i not in order]
-    layout = "auto"
-    for i in order:
-        nl = link_length[i]
+    sparse_weights = []
+    for i, nl in enumerate(link_length):
         src = _level_slice(weights["src_address"], mask_dim, i)[:nl]
         dst = _level_slice(weights["dst_address"], mask_dim, i)[:nl]
         rm = _level_slice(weights["remap_matrix"], mask_dim, i)[:nl]
         if rm.ndim == 2:
             rm = rm[:, 0]
-        op = SparseOperator(n_src, n_dst, src, dst, rm, device=device, dst_dims=dims, layout=layout)
-        if layout == "auto":
-            layout = "patches" if op.plan_info()["dst_patches"] else "rows"
-        sparse_weights[i] = op
+        # one grouped launch covers all levels: they share one destination layout
+        sparse_weights.append(SparseOperator(n_src, n_dst, src, dst, rm, device=device, dst_dims=dims,
+                                             layout=layout))
     return sparse_weights
 
 
