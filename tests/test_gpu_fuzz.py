@@ -49,7 +49,13 @@ def test_fuzz_2d(hip, seed):
     n_dst = int(rng.integers(1, 1500))
     kind = ["random", "ragged", "banded"][seed % 3]
     src, dst, w = make_links(rng, kind, n_src, n_dst)
-    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    # every third case lays the destination out in 4 x 64 patches of a 2-D grid (nx * ny == n_dst)
+    dims, layout = None, "auto"
+    if seed % 3 == 1:
+        nx = next(f for f in range(int(np.sqrt(n_dst)) + 1, 0, -1) if n_dst % f == 0)
+        dims, layout = [n_dst // nx, nx] if seed % 2 else [nx, n_dst // nx], "patches"
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0, dst_dims=dims, layout=layout)
+    assert op.plan_info()["dst_patches"] == (layout == "patches")
     csr = op.export_csr()
     ref_csr = oracle.coo_to_csr(n_src, n_dst, src, dst, w)
     assert np.array_equal(csr[0], ref_csr[0]) and np.array_equal(csr[1], ref_csr[1])
@@ -70,6 +76,13 @@ def test_fuzz_2d(hip, seed):
         assert_same(y, ref, exact=True)
     yh = op.apply_host(x, masked=masked, remap_area_min=amin, chunk_rows=int(rng.integers(0, 9)))
     assert_same(yh, ref, exact=True)
+    # the batch-fastest entry point (X transposed, full or packed to the used source cells)
+    xt = np.ascontiguousarray(x.T)
+    packed = bool(seed % 2)
+    if packed:
+        xt = np.ascontiguousarray(xt[op.used_sources()]) if op.n_used_src else np.zeros((0, n_batch), dtype)
+    ysb = op.apply_sb(to_device(xt), masked=masked, remap_area_min=amin, packed=packed).to_host()
+    assert_same(ysb, ref, exact=True)
     # mixed pinned / pageable buffers and the float32 narrowing store through the same pipeline
     from smmregrid_amd import pinned_empty
     xin = x
@@ -113,9 +126,13 @@ def test_fuzz_levels(hip, seed):
     ops, csrs = [], []
     imask = (rng.random((n_ops, n_dst)) > 0.3).astype(np.int32)
     frac = rng.random((n_ops, n_dst))
+    dims, layout = None, "auto"
+    if seed % 2:                                             # all levels in patch order
+        nx = next(f for f in range(int(np.sqrt(n_dst)) + 1, 0, -1) if n_dst % f == 0)
+        dims, layout = [n_dst // nx, nx], "patches"
     for i in range(n_ops):
         src, dst, w = make_links(rng, ["random", "ragged", "banded"][(seed + i) % 3], n_src, n_dst)
-        op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+        op = SparseOperator(n_src, n_dst, src, dst, w, device=0, dst_dims=dims, layout=layout)
         op.set_epilogue(imask[i], frac[i])
         ops.append(op)
         csrs.append(op.export_csr())
