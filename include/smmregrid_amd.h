@@ -61,6 +61,7 @@ enum {
   SMM_APPLY_MASKED = 1u << 0,   /* apply dst_imask (regrid.py:553-559); per level in a group */
   SMM_APPLY_NO_FILL = 1u << 1,  /* skip the 1e20 fill: the caller guarantees finite X (results are undefined otherwise) */
   SMM_APPLY_SB_PACKED = 1u << 2, /* smm_apply_sb: X holds only the used source cells (smm_operator_used_sources order) */
+  SMM_APPLY_HOST_NO_PACK = 1u << 3, /* smm_apply_host: always ship whole rows (no packing of the used source cells) */
   SMM_APPLY_KERNEL_SELL = 1u << 8, /* force the row-per-lane SELL-64 kernel                  */
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };
@@ -260,7 +261,11 @@ int smm_apply_sb(smm_operator_t op,
  * buffers, e.g. from smm_host_alloc), H2D, kernel, D2H -- on two streams, so
  * transfers of one chunk overlap the kernel of the other.  Synchronous: Y is
  * complete on return.  chunk_rows <= 0 picks ~256 MiB of X per chunk.
- * This path is PCIe-bound (about 100x below the device-resident rate).
+ * This path is PCIe-bound (about 100x below the device-resident rate).  When the operator uses at most
+ * half of its source cells (bilinear / nearest downsampling) and the batch has >= 32 rows, the staging
+ * copy packs only the used cells of a chunk, batch-fastest, and the chunk runs through the kernel of
+ * smm_apply_sb: a quarter of the PCIe bytes for config 2, the same bits (SMM_APPLY_HOST_NO_PACK or a
+ * forced kernel flag turns it off).
  */
 int smm_apply_host(smm_operator_t op,
                    const void* x_host, int x_dtype, int64_t ldx,

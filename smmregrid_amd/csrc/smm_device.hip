@@ -183,6 +183,7 @@ struct smm_operator {
   HostPipe pipe;
   // plain canonical CSR on the device for the batch-fastest kernel, uploaded on first use
   bool sb_ready = false;
+  std::vector<int32_t> h_used;        // ascending used source cells (host pack of the pipeline)
   int64_t* d_csr_rowptr = nullptr;
   int32_t* d_csr_col = nullptr;       // source cell
   int32_t* d_csr_colp = nullptr;      // rank of the source cell among the used cells (packed X)
@@ -335,6 +336,10 @@ int ensure_sb(smm_operator* op) {
   for (int64_t s = 0; s < c.n_src; ++s)
     if (rank[(size_t)s] == 0) rank[(size_t)s] = r++;
   for (int64_t i = 0; i < c.nnz; ++i) colp[(size_t)i] = rank[(size_t)c.col[(size_t)i]];
+  op->h_used.clear();
+  op->h_used.reserve((size_t)c.n_used_src);
+  for (int64_t s = 0; s < c.n_src; ++s)
+    if (rank[(size_t)s] >= 0) op->h_used.push_back((int32_t)s);
   int rc = SMM_OK;
   if ((rc = upload(&op->d_csr_rowptr, c.rowptr)) || (rc = upload(&op->d_csr_col, c.col)) ||
       (rc = upload(&op->d_csr_colp, colp)) || (rc = upload(&op->d_csr_val, c.val))) {
@@ -473,6 +478,47 @@ void host_copy(void* dst, const void* src, size_t bytes) {
 int64_t test_fail_chunk() {
   const char* e = getenv("SMM_TEST_FAIL_AT_CHUNK");
   return (e && *e) ? (int64_t)atoll(e) : -1;
+}
+
+// Pack of the host pipeline: out[u * rows + r] = x[r * ldx + used[u]] -- the used source cells of a
+// chunk of batch rows, batch-fastest, ready for smm_apply_sb (SMM_APPLY_SB_PACKED).  Threads split
+// the used cells; rows go in blocks of 16 so that a block's 16 source lines stay in L1 while the
+// neighbouring cells of the same lines are picked up.
+template <typename T>
+void pack_rows_t(T* __restrict__ out, const T* __restrict__ x, int64_t ldx, const int32_t* __restrict__ used,
+                 int64_t u0, int64_t u1, int64_t rows) {
+  constexpr int64_t RB = 16;
+  for (int64_t r0 = 0; r0 < rows; r0 += RB) {
+    const int64_t rn = std::min(RB, rows - r0);
+    for (int64_t u = u0; u < u1; ++u) {
+      const T* src = x + (size_t)r0 * ldx + used[u];
+      T* dst = out + (size_t)u * rows + r0;
+      for (int64_t r = 0; r < rn; ++r) dst[r] = src[(size_t)r * ldx];
+    }
+  }
+}
+
+void host_pack(void* out, const void* x, size_t xsz, int64_t ldx, const std::vector<int32_t>& used, int64_t rows) {
+  const int64_t U = (int64_t)used.size();
+  unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+  if ((size_t)U * rows * xsz < (4u << 20)) nt = 1;
+  auto work = [&](int64_t u0, int64_t u1) {
+    if (xsz == 8)
+      pack_rows_t((double*)out, (const double*)x, ldx, used.data(), u0, u1, rows);
+    else
+      pack_rows_t((float*)out, (const float*)x, ldx, used.data(), u0, u1, rows);
+  };
+  if (nt == 1) {
+    work(0, U);
+    return;
+  }
+  std::vector<std::thread> pool;
+  const int64_t per = (U + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const int64_t lo = std::min(U, (int64_t)t * per), hi = std::min(U, lo + per);
+    if (hi > lo) pool.emplace_back(work, lo, hi);
+  }
+  for (auto& th : pool) th.join();
 }
 
 bool is_pinned(const void* p) {
@@ -1025,6 +1071,20 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
   // source: +17 % fetched bytes when its rows are packed back to back)
   const size_t xrow_d = (((size_t)S * xsz + 127) / 128) * 128;
   const int64_t ldx_d = (int64_t)(xrow_d / xsz);
+  // Operators that use at most half of their source cells (bilinear / nearest downsampling: config 2
+  // uses a quarter) do not ship the whole field over PCIe: the staging copy packs the used cells of a
+  // chunk batch-fastest (host_pack) and the chunk runs through the batch-fastest kernel.  Same bits.
+  const int64_t U = op->csr.n_used_src;
+  const bool pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
+                    U > 0 && U * 2 <= S && n_batch >= 32;
+  if (pack) {
+    int prc = ensure_sb(op);
+    if (prc) return prc;
+    if (chunk_rows <= 0) {   // ~256 MiB of packed cells per chunk, whole 128-entry batch tiles
+      chunk_rows = (int64_t)((256u << 20) / std::max<size_t>((size_t)U * xsz, 1)) / 128 * 128;
+      chunk_rows = std::max<int64_t>(128, chunk_rows);
+    }
+  }
   if (chunk_rows <= 0) {
     chunk_rows = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(xrow_d, 1)));
     chunk_rows = std::min(chunk_rows, n_batch);
@@ -1038,12 +1098,13 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
   chunk_rows = std::min(chunk_rows, n_batch);
   const bool x_pinned = is_pinned(x_host), y_pinned = is_pinned(y_host);
   // a pinned source with the device pitch can be DMA'd row-block-wise without staging
-  const bool x_direct = x_pinned, y_direct = y_pinned;
+  const bool x_direct = x_pinned && !pack, y_direct = y_pinned;
 
   std::lock_guard<std::mutex> pipe_lock(op->pipe_mu);
   HostPipe& pipe = op->pipe;
-  SMM_HIP(pipe.ensure((size_t)chunk_rows * xrow_d, (size_t)chunk_rows * D * ysz,
-                      x_direct ? 0 : (size_t)chunk_rows * S * xsz,
+  const size_t x_chunk_d = pack ? (size_t)chunk_rows * U * xsz : (size_t)chunk_rows * xrow_d;
+  SMM_HIP(pipe.ensure(x_chunk_d, (size_t)chunk_rows * D * ysz,
+                      x_direct ? 0 : (pack ? x_chunk_d : (size_t)chunk_rows * S * xsz),
                       y_direct ? 0 : (size_t)chunk_rows * D * ysz));
 
   const int64_t n_chunks = (n_batch + chunk_rows - 1) / chunk_rows;
@@ -1076,7 +1137,10 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     }
     if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (SMM_TEST_FAIL_AT_CHUNK)");
     const char* xsrc = (const char*)x_host + (size_t)r0 * xrow;
-    if (!x_direct) {
+    if (pack) {
+      host_pack(pipe.hx[b], xsrc, xsz, ldx, op->h_used, rows);
+      SMM_HIP(hipMemcpyAsync(pipe.dx[b], pipe.hx[b], (size_t)U * rows * xsz, hipMemcpyHostToDevice, pipe.stream[b]));
+    } else if (!x_direct) {
       if (ldx == S) {
         host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
       } else {
@@ -1091,10 +1155,15 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     }
     const int pw = op->native_plan();
     const smm_operator::TilePlan& pl = op->plan[pw];
-    int rc = run_apply(op->d_desc, nullptr, nullptr, S, op->kcsr().n_dst, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
-                       pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
-                       ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
-                       pipe.stream[b]);
+    int rc = SMM_OK;
+    if (pack)
+      rc = smm_apply_sb(op, pipe.dx[b], x_dtype, rows, pipe.dy[b], y_dtype, D, rows, remap_area_min,
+                        (flags & (SMM_APPLY_MASKED | SMM_APPLY_NO_FILL)) | SMM_APPLY_SB_PACKED, pipe.stream[b]);
+    else
+      rc = run_apply(op->d_desc, nullptr, nullptr, S, op->kcsr().n_dst, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
+                     pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
+                     ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
+                     pipe.stream[b]);
     if (rc) return rc;
     if (!y_direct) {
       SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)rows * D * ysz, hipMemcpyDeviceToHost,

@@ -116,3 +116,35 @@ def test_sb_config2_geometry(hip):
     rows = [0, 7, 127, 128, 255, 256, 299]
     assert_same(y[rows], oracle.apply_c(op.export_csr(), x_bs[rows], False, None, w["dst_grid_frac"].values, 0.5),
                 exact=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_host_pipeline_packs_the_used_cells(hip, rng, dtype):
+    """smm_apply_host on an operator that uses a quarter of its source cells (bilinear 4:1): the staging
+    copy packs the used cells batch-fastest and the chunk runs through the batch-fastest kernel -- same
+    bits as the whole-row pipeline and as the oracle, for every chunking, pitch and buffer kind."""
+    from smmregrid_amd import pinned_empty
+    w = gridgen.bilinear_weights("r360x180", "r90x45")
+    op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                        w["dst_address"].values, w["remap_matrix"].values, device=0)
+    assert 2 * op.n_used_src <= op.n_src
+    imask = (rng.random(op.n_dst) > 0.2).astype(np.int32)
+    op.set_epilogue(imask, w["dst_grid_frac"].values)
+    B = 150
+    x = field(rng, B, op.n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.003)
+    ref = oracle.apply_c(op.export_csr(), x, True, imask, w["dst_grid_frac"].values, 0.5)
+    for chunk in (0, 7, 40, 128, 149):
+        y = op.apply_host(x, masked=True, remap_area_min=0.5, chunk_rows=chunk)
+        assert_same(y, ref, exact=True)
+    y = op.apply_host(x, masked=True, remap_area_min=0.5, flags=_lib.APPLY_HOST_NO_PACK)
+    assert_same(y, ref, exact=True)
+    wide = np.zeros((B, op.n_src + 5), dtype=dtype)              # ldx > S
+    wide[:, :op.n_src] = x
+    assert_same(op.apply_host(wide[:, :op.n_src], masked=True, remap_area_min=0.5, chunk_rows=33), ref, exact=True)
+    xp = pinned_empty(x.shape, dtype)
+    xp[...] = x
+    yp = pinned_empty((B, op.n_dst), np.float64)
+    op.apply_host(xp, out=yp, masked=True, remap_area_min=0.5)
+    assert_same(np.array(yp), ref, exact=True)
+    # fewer than 32 rows: whole rows as before
+    assert_same(op.apply_host(x[:20], masked=True, remap_area_min=0.5), ref[:20], exact=True)

@@ -3,7 +3,7 @@
 import os, sys, time, json
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from smmregrid_amd import SparseOperator, gridgen, pinned_empty
+from smmregrid_amd import SparseOperator, _lib, gridgen, pinned_empty
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 w = gridgen.bilinear_weights("r1440x721", "r360x180")
@@ -17,10 +17,11 @@ for kind in ("pageable", "pinned"):
     x = alloc((rows, S), np.float64)
     x[...] = 250 + 30 * rng.standard_normal((1, S))
     y = alloc((rows, D), np.float64)
-    op.apply_host(x, out=y, remap_area_min=0.5)           # warm-up (allocations, page faults)
-    t0 = time.perf_counter()
-    op.apply_host(x, out=y, remap_area_min=0.5)
-    dt = time.perf_counter() - t0
-    out[kind] = {"rows": rows, "seconds": dt, "cells_per_s": rows * D / dt,
-                 "host_GBs": (x.nbytes + y.nbytes) / dt / 1e9}
+    for mode, fl in (("packed", 0), ("whole_rows", _lib.APPLY_HOST_NO_PACK)):
+        op.apply_host(x, out=y, remap_area_min=0.5, flags=fl)           # warm-up (allocations, page faults)
+        t0 = time.perf_counter()
+        op.apply_host(x, out=y, remap_area_min=0.5, flags=fl)
+        dt = time.perf_counter() - t0
+        out[kind + "/" + mode] = {"rows": rows, "seconds": dt, "cells_per_s": rows * D / dt,
+                                  "host_GBs": (x.nbytes + y.nbytes) / dt / 1e9}
 print(json.dumps(out))
