@@ -17,7 +17,11 @@ for seed in range(n):
     if kind == "longband":
         n_src, n_dst = int(rng.integers(5000, 200000)), int(rng.integers(1, 900))
     src, dst, w = make_links(rng, kind, n_src, n_dst)
-    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    dims, layout = None, "auto"
+    if seed % 5 == 2:          # destination patches of a 2-D grid with nx * ny == n_dst
+        nx = next(f for f in range(int(np.sqrt(n_dst)) + 1, 0, -1) if n_dst % f == 0)
+        dims, layout = [n_dst // nx, nx], "patches"
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0, dst_dims=dims, layout=layout)
     csr = op.export_csr()
     imask = (rng.random(n_dst) > 0.3).astype(np.int32); frac = rng.random(n_dst)
     op.set_epilogue(imask, frac)
@@ -37,6 +41,16 @@ for seed in range(n):
             same = np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])
             if not same:
                 bad += 1; print("MISMATCH seed", seed, "flags", fl, "rep", rep, flush=True)
+    # batch-fastest entry point (full and packed X) and the host pipeline (packing when the operator qualifies)
+    xt = np.ascontiguousarray(x.T)
+    for packed in (False, True):
+        xx = np.ascontiguousarray(xt[op.used_sources()]) if packed else xt
+        y = op.apply_sb(to_device(xx), masked=masked, remap_area_min=amin, packed=packed).to_host()
+        if not (np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])):
+            bad += 1; print("MISMATCH seed", seed, "apply_sb packed", packed, flush=True)
+    y = op.apply_host(x, masked=masked, remap_area_min=amin, chunk_rows=int(rng.integers(0, 40)))
+    if not (np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])):
+        bad += 1; print("MISMATCH seed", seed, "apply_host", flush=True)
     op.close()
     if seed % 50 == 49: print(f"{seed+1} cases, {bad} mismatches, {time.time()-t0:.0f}s", flush=True)
 # level groups (grouped launch, both Y layouts, host pipeline): the fuzz test body on many more seeds
