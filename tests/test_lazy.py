@@ -103,3 +103,47 @@ def test_lazy_regridder_defers_the_launch(hip, rng):
     l3 = Regridder(weights=w3, device=0, lazy=True).regrid(f3)
     assert isinstance(l3.data, LazyArray) and not l3.data.computed and l3.shape == e3.shape
     assert_same(l3.values, e3.values, exact=True)
+
+
+@pytest.mark.gpu
+def test_dask_field_through_the_regridder_on_the_gpu(hip):
+    """Regridder(lazy=True) with a real dask array (the image's second interpreter has dask): the
+    result is a dask array with the kept chunking, nothing is launched before compute, and the computed
+    values are the eager ones (which the other tests tie to the oracle)."""
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import dask.array, scipy.sparse"],
+                                                capture_output=True).returncode:
+        pytest.skip("no interpreter with dask on this box")
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, dask.array as da
+from smmregrid_amd import CdoGenerate, DataArray, Regridder, gridgen
+from smmregrid_amd.lazy import is_dask
+g = gridgen.parse_grid("r96x48")
+rng = np.random.default_rng(4)
+x = (280.0 + 10.0 * rng.standard_normal((10, 48, 96))).astype(np.float32)
+x[3, 10:20, 30:40] = np.nan
+coords = {"time": np.arange(10), "lat": g.lat, "lon": g.lon}
+w = CdoGenerate("r96x48", "r36x18").weights(method="con")
+eager = Regridder(weights=w, device=0).regrid(DataArray(x, dims=("time", "lat", "lon"), coords=coords, name="tas"))
+dx = da.from_array(x, chunks=(4, 24, 96))
+lazy = Regridder(weights=w, device=0, lazy=True).regrid(DataArray(dx, dims=("time", "lat", "lon"), coords=coords,
+                                                                  name="tas"))
+assert is_dask(lazy.data) and lazy.shape == (10, 18, 36) and lazy.data.chunks == ((4, 4, 2), (18,), (36,))
+got = lazy.data.compute(scheduler="threads")          # blocks call smm_apply_host concurrently: they take turns
+ev = eager.values
+assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(ev))
+assert np.array_equal(got[~np.isnan(got)], ev[~np.isnan(ev)])
+assert np.array_equal(np.asarray(lazy.values), got) or np.array_equal(np.isnan(lazy.values), np.isnan(got))
+print("dask-gpu-ok")
+''' % ROOT
+    # that interpreter ships an older libstdc++ than the one the HIP library was linked against
+    env = dict(os.environ)
+    std = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(std):
+        env["LD_PRELOAD"] = std + (":" + env["LD_PRELOAD"] if env.get("LD_PRELOAD") else "")
+    out = subprocess.run([py, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    if "GLIBCXX" in out.stderr:
+        pytest.skip("the dask interpreter cannot load the HIP library (libstdc++ too old)")
+    assert out.returncode == 0 and "dask-gpu-ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
