@@ -74,6 +74,8 @@ WORKLOADS = {
     # row of the 1442x1021 grid then starts mid-line (S * 8 B = 80 mod 128)
     "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "pad"),
     "cfg3c": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
+    # config 3 with the field kept batch-fastest per level, X (L, S, T) (smm_group_apply_sb)
+    "cfg3sb": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "sb"),
     "cfg3s": ("con3d", (1442, 1021), "r360x180", (16, 8), "f64"),
 }
 
@@ -266,22 +268,30 @@ class ProblemLevels:
         slab[masks == 0] = np.nan
         self.slab, self.masks = slab, masks
         self.padded = len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "pad"
+        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "sb" else "bs"
         ldx = -(-self.n_src // 16) * 16 if self.padded else self.n_src
-        self.x = DeviceArray((self.n_t, n_lev, 1, ldx), np.float64)
-        first = np.zeros((1, n_lev, 1, ldx))
-        first[0, :, 0, :self.n_src] = slab
-        self.x.rows(0, 1).copy_from_host(first)
         from smmregrid_amd import _lib
         import ctypes
-        for t in range(1, self.n_t):
-            _lib.call("smm_memcpy_d2d", ctypes.c_void_p(self.x.rows(t, t + 1).ptr),
-                      ctypes.c_void_p(self.x.ptr), first.nbytes, None)
+        if self.layout == "sb":
+            # X (L, S, T): every time step carries the same slab, so a cell's T values are one constant
+            self.x = DeviceArray((n_lev, self.n_src, self.n_t), np.float64)
+            for lv in range(n_lev):
+                self.x.rows(lv, lv + 1).copy_from_host(np.repeat(slab[lv][:, None], self.n_t, axis=1)[None])
+        else:
+            self.x = DeviceArray((self.n_t, n_lev, 1, ldx), np.float64)
+            first = np.zeros((1, n_lev, 1, ldx))
+            first[0, :, 0, :self.n_src] = slab
+            self.x.rows(0, 1).copy_from_host(first)
+            for t in range(1, self.n_t):
+                _lib.call("smm_memcpy_d2d", ctypes.c_void_p(self.x.rows(t, t + 1).ptr),
+                          ctypes.c_void_p(self.x.ptr), first.nbytes, None)
         self.y_shape = (self.n_t, 1, n_lev, self.n_dst)
         self.np_dt = np.float64
         nnz = sum(op.nnz for op in self.ops)
         self.desc = (f"{name}: {nx}x{ny} tripolar-like -> {tgrid} conservative, {self.n_t} time steps x "
-                     f"{n_lev} masked levels per GPU, f64, remap_area_min 0.5, grouped launch, X (T, L, S) "
-                     + (f"with rows on 128-B lines (pitch {ldx})" if self.padded else "packed"))
+                     f"{n_lev} masked levels per GPU, f64, remap_area_min 0.5, grouped launch, "
+                     + ("X (L, S, T) batch-fastest per level" if self.layout == "sb" else
+                        "X (T, L, S) " + (f"with rows on 128-B lines (pitch {ldx})" if self.padded else "packed")))
         self.meta = {"S": self.n_src, "D": self.n_dst, "nnz_total": nnz, "levels": n_lev,
                      "max_row_nnz": max(op.max_row_nnz for op in self.ops),
                      "plan": self.ops[0].plan_info()}
@@ -296,16 +306,24 @@ class ProblemLevels:
         return self.n_t * self.n_lev * (self.n_src + self.n_dst) * 8 + sum(op.nnz for op in self.ops) * 12
 
     def line_bytes(self):
+        if self.layout == "sb":
+            return None
         staged = [op.plan_info()["staged_src_elems"] for op in self.ops]
         if not all(op.plan_info()["tile_plan"] for op in self.ops):
             return None
         return self.n_t * (sum(staged) + self.n_lev * self.n_dst) * 8 + sum(op.nnz for op in self.ops) * 12
 
     def run(self, y, flags):
+        if self.layout == "sb":
+            self.group.apply_sb(self.x, self.level_index, self.masked_levels, y=y.reshape(self.n_t, self.n_lev, self.n_dst),
+                                masked=True, remap_area_min=0.5, transpose=True, flags=flags)
+            return
         self.group.apply(self.x, self.level_index, self.masked_levels, y=y, masked=True,
                          remap_area_min=0.5, transpose=True, flags=flags)
 
     def run_rows(self, y, flags, r0, r1):
+        if self.layout == "sb":
+            raise SystemExit("the tiled gather needs time-major rows: use cfg3 / cfg3c with --gpus N")
         self.group.apply(self.x.rows(r0, r1), self.level_index, self.masked_levels, y=y.rows(r0, r1),
                          masked=True, remap_area_min=0.5, transpose=True, flags=flags)
 

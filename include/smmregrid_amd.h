@@ -293,6 +293,22 @@ int smm_group_apply(smm_group_t g,
                     double remap_area_min, unsigned flags, void* stream);
 
 /*
+ * Masked-level apply for a field kept batch-fastest per level: data level l is an (S, ldx >= n_batch)
+ * slab at x + l * xs_lev (the n_batch values of a source cell contiguous), its results go to
+ * y + l * ys_lev + b * ys_batch + d.  Y as regrid3d lays it out with transpose (B, L, D):
+ * ys_lev = D, ys_batch = L * D; without (L, B, D): ys_lev = B * D, ys_batch = D.  Same level_index /
+ * masked_levels semantics and the same bits as smm_group_apply; HBM traffic equals the algorithmic bytes.
+ * smm_group_prepare_sb uploads the members' CSRs ahead of time (else done by the first call).
+ */
+int smm_group_prepare_sb(smm_group_t g);
+int smm_group_apply_sb(smm_group_t g,
+                       const void* x, int x_dtype, int64_t xs_lev, int64_t ldx,
+                       void* y, int y_dtype, int64_t ys_lev, int64_t ys_batch,
+                       int64_t n_batch, int64_t n_lev,
+                       const int32_t* level_index, const uint8_t* masked_levels,
+                       double remap_area_min, unsigned flags, void* stream);
+
+/*
  * Host-buffer variant (the fields Regridder.regrid3d receives): X host C-contiguous
  * (n_outer, n_lev, n_inner, S); Y host (n_outer, n_inner, n_lev, D) when transpose != 0
  * (regrid.py:420-427) else (n_lev, n_outer, n_inner, D) (regrid.py:410).  Chunks of the outer

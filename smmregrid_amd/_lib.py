@@ -102,6 +102,8 @@ SIGNATURES = {
     "smm_apply_host": [_p, _p, _int, _i64, _p, _int, _i64, _i64, _dbl, _uint, _i64],
     "smm_group_apply": [_p, _p, _int, _i64, _i64, _i64, _p, _int, _i64, _i64, _i64,
                         _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
+    "smm_group_prepare_sb": [_p],
+    "smm_group_apply_sb": [_p, _p, _int, _i64, _i64, _p, _int, _i64, _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
     "smm_group_apply_host": [_p, _p, _int, _p, _int, _i64, _i64, _i64, _int, _p, _p, _dbl, _uint, _i64],
     "smm_comm_unique_id": [_p],
     "smm_comm_create": [_p, _int, _int, _pp],

@@ -196,14 +196,14 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
 // Batch-fastest layout (kernel C).  TD destination rows per tile: 16 doubles = one 128-B line of Y
 // per batch row; f32 output takes 32 rows for the same line.
 template <typename XT, typename YT>
-int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
+int launch_sb(const SbArgs& a, int64_t n_lev, bool fill, unsigned flags, hipStream_t s) {
   SbArgs args = a;
   constexpr int TD = sizeof(YT) == 8 ? 16 : 32;
   constexpr int BT = 128;
   const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
   args.n_dtiles = (a.n_dst + TD - 1) / TD;
   args.n_btiles = (a.n_batch + BT - 1) / BT;
-  const int64_t total = args.n_dtiles * args.n_btiles;
+  const int64_t total = args.n_dtiles * args.n_btiles * n_lev;
   if (total <= 0) return SMM_OK;
   if (total > 0x7fffffffLL) return smm::fail_msg(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
   args.n_blocks = total;

@@ -353,6 +353,28 @@ class OperatorGroup:
                   float(remap_area_min), fl, _stream_handle(stream))
         return y
 
+    def apply_sb(self, x, level_index, masked_levels=None, y=None, masked=False, remap_area_min=0.0,
+                 transpose=True, out_dtype=np.float64, flags=0, stream=None):
+        """Masked levels for a field kept batch-fastest per level: x is a DeviceArray (n_lev, S, B) --
+        per data level the B batch values of each source cell contiguous.  Returns (B, n_lev, D) when
+        transpose (regrid.py:420-427) else (n_lev, B, D); bit-identical to `apply` on the transposed field."""
+        if not isinstance(x, DeviceArray) or x.ndim != 3 or x.shape[1] != self.n_src:
+            raise ValueError(f"X must be a DeviceArray (n_lev, {self.n_src}, B)")
+        n_lev, S, B = x.shape
+        D = self.n_dst
+        lev, ml = self._level_args(level_index, masked_levels, n_lev)
+        shape = (B, n_lev, D) if transpose else (n_lev, B, D)
+        ys_lev, ys_b = (D, n_lev * D) if transpose else (B * D, D)
+        if y is None:
+            y = DeviceArray(shape, out_dtype)
+        elif y.shape != shape:
+            raise ValueError(f"Y must be {shape}, got {y.shape}")
+        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
+        _lib.call("smm_group_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), S * max(B, 1),
+                  max(B, 1), ctypes.c_void_p(y.ptr), dtype_code(y.dtype), ys_lev, ys_b, B, n_lev, _cptr(lev),
+                  _cptr(ml), float(remap_area_min), fl, _stream_handle(stream))
+        return y
+
     def apply_host(self, x, level_index, masked_levels=None, masked=False, remap_area_min=0.0,
                    transpose=True, out_dtype=np.float64, flags=0, chunk_outer=0):
         """Host (numpy) variant: x of shape (n_outer, n_lev, n_inner, S); chunks of the outer

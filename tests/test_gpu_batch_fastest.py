@@ -148,3 +148,36 @@ def test_host_pipeline_packs_the_used_cells(hip, rng, dtype):
     assert_same(np.array(yp), ref, exact=True)
     # fewer than 32 rows: whole rows as before
     assert_same(op.apply_host(x[:20], masked=True, remap_area_min=0.5), ref[:20], exact=True)
+
+
+@pytest.mark.parametrize("transpose", [True, False])
+def test_group_apply_sb_matches_the_oracle(hip, rng, transpose):
+    """Masked levels with the field kept batch-fastest per level, X (L, S, B): regrid.py:387-427 in one
+    launch of the batch-fastest kernel -- level sub-selection and repeats, per-level masks, odd batch sizes."""
+    from smmregrid_amd import OperatorGroup
+    S, D, n_ops = 900, 217, 4
+    ops, csrs = [], []
+    imask = (rng.random((n_ops, D)) > 0.3).astype(np.int32)
+    frac = rng.random((n_ops, D))
+    for i in range(n_ops):
+        src, dst, w = (random_links(rng, S, D, 1500 + 300 * i) if i % 2 else ragged_links(rng, S, D, max_len=25))
+        op = SparseOperator(S, D, src, dst, w, device=0)
+        op.set_epilogue(imask[i], frac[i])
+        ops.append(op)
+        csrs.append(op.export_csr())
+    grp = OperatorGroup(ops)
+    masked_levels = np.array([1, 0, 1, 1], np.uint8)
+    for level_index, B in [([0, 1, 2, 3], 130), ([2, 0, 2], 7), ([3], 1), ([1, 1, 0, 3, 2], 64)]:
+        L = len(level_index)
+        x = field(rng, B * L, S, nan_frac=0.03).reshape(B, L, 1, S)           # native layout for the oracle
+        ref = oracle.apply_levels(csrs, x, 1, np.asarray(level_index), masked_levels.astype(bool), imask, frac,
+                                  0.4, transpose)                            # (B, 1, L, D) / (L, B, 1, D)
+        x_sb = np.ascontiguousarray(np.transpose(x[:, :, 0, :], (1, 2, 0)))   # (L, S, B)
+        y = grp.apply_sb(to_device(x_sb), level_index, masked_levels, masked=True, remap_area_min=0.4,
+                         transpose=transpose).to_host()
+        assert_same(y.reshape(ref.shape), ref, exact=True)
+        native = grp.apply(to_device(x), level_index, masked_levels, masked=True, remap_area_min=0.4,
+                           transpose=transpose).to_host()
+        assert_same(y.reshape(native.shape), native, exact=True)
+    with pytest.raises(_lib.SmmError):                                        # packed is per operator
+        grp.apply_sb(to_device(np.zeros((1, S, 4))), [0], flags=_lib.APPLY_SB_PACKED)
