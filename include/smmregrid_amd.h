@@ -297,8 +297,8 @@ int smm_group_apply(smm_group_t g,
  * slab at x + l * xs_lev (the n_batch values of a source cell contiguous), its results go to
  * y + l * ys_lev + b * ys_batch + d.  Y as regrid3d lays it out with transpose (B, L, D):
  * ys_lev = D, ys_batch = L * D; without (L, B, D): ys_lev = B * D, ys_batch = D.  Same level_index /
- * masked_levels semantics and the same bits as smm_group_apply; HBM traffic equals the algorithmic bytes.
- * smm_group_prepare_sb uploads the members' CSRs ahead of time (else done by the first call).
+ * masked_levels semantics and the same bits as smm_group_apply (one kernel launch per data level, all
+ * on `stream`).  smm_group_prepare_sb uploads the members' CSRs ahead of time (else done by the first call).
  */
 int smm_group_prepare_sb(smm_group_t g);
 int smm_group_apply_sb(smm_group_t g,

@@ -65,26 +65,12 @@ struct ApplyArgs {
 };
 
 // arguments of the batch-fastest kernel (kernel C below)
-struct SbLevel {           // one member of a level group (canonical CSR + epilogue vectors, row order)
-  const int64_t* rowptr;
-  const int32_t* col;
-  const double* val;
-  const uint8_t* imask;
-  const double* frac;
-};
-
 struct SbArgs {
   const int64_t* rowptr;   // [n_dst + 1] canonical CSR
   const int32_t* col;      // [nnz] source cell, or its rank among the used cells (packed X)
   const double* val;       // [nnz]
   const uint8_t* imask;    // [n_dst] or null
   const double* frac;      // [n_dst] or null
-  // level groups (regrid.py:387-418 in one launch): levels != null, data level l uses member
-  // lev_map[l]; its field starts at x + l * xs_lev, its results at y + l * ys_lev
-  const SbLevel* levels;
-  const int32_t* lev_map;
-  const uint8_t* lev_masked;   // per member, null = all
-  int64_t xs_lev, ys_lev;
   const void* x;           // (n_rows_x, ldx): row = source cell, batch entry fastest
   void* y;                 // batch entry b of destination cell d at y + b * ldy + d
   int64_t ldx, ldy, n_batch, n_dst;
@@ -888,23 +874,8 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
       bid = (slot / C) * round + xcd * C + (slot % C);
     }
   }
-  // tile order: destination tile fastest, then batch tile, then level
-  const uint32_t q32 = bid / (uint32_t)a.n_dtiles;
-  const int64_t dt = bid - q32 * (uint32_t)a.n_dtiles;
-  const uint32_t lev = q32 / (uint32_t)a.n_btiles;
-  const int64_t bt = q32 - lev * (uint32_t)a.n_btiles;
-  if (a.levels) {   // wave-uniform: this level's operator and slabs
-    const int di = a.lev_map[lev];
-    const SbLevel L = a.levels[di];
-    a.rowptr = L.rowptr;
-    a.col = L.col;
-    a.val = L.val;
-    a.imask = L.imask;
-    a.frac = L.frac;
-    a.masked = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
-    a.x = (const XT*)a.x + (int64_t)lev * a.xs_lev;
-    a.y = (YT*)a.y + (int64_t)lev * a.ys_lev;
-  }
+  const uint32_t bt32 = bid / (uint32_t)a.n_dtiles;
+  const int64_t dt = bid - bt32 * (uint32_t)a.n_dtiles, bt = bt32;
   const int64_t d0 = dt * TD;
   const int rows = (int)(a.n_dst - d0 < TD ? a.n_dst - d0 : TD);
   const int64_t b0 = bt * BT;

@@ -196,29 +196,28 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
 // Batch-fastest layout (kernel C).  TD destination rows per tile: 16 doubles = one 128-B line of Y
 // per batch row; f32 output takes 32 rows for the same line.
 template <typename XT, typename YT>
-int launch_sb(const SbArgs& a, int64_t n_lev, bool fill, unsigned flags, hipStream_t s) {
+int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
   SbArgs args = a;
   constexpr int TD = sizeof(YT) == 8 ? 16 : 32;
   constexpr int BT = 128;
   const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
   args.n_dtiles = (a.n_dst + TD - 1) / TD;
   args.n_btiles = (a.n_batch + BT - 1) / BT;
-  const int64_t total = args.n_dtiles * args.n_btiles * n_lev;
+  const int64_t total = args.n_dtiles * args.n_btiles;
   if (total <= 0) return SMM_OK;
   if (total > 0x7fffffffLL) return smm::fail_msg(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
   args.n_blocks = total;
   args.xcd_remap = variant == 6 ? 0 : (variant == 7 ? 8 : (variant == 13 ? 128 : 32));
-  if (variant == 1) {        // tuning: 4 loads per batch instead of 8
-    if (fill)
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, 4, true>), dim3((unsigned)total), dim3(64), 0, s, args);
-    else
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, 4, false>), dim3((unsigned)total), dim3(64), 0, s, args);
-  } else {
-    if (fill)
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, 8, true>), dim3((unsigned)total), dim3(64), 0, s, args);
-    else
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, 8, false>), dim3((unsigned)total), dim3(64), 0, s, args);
-  }
+  auto go = [&](auto u_tag, auto fill_tag) {
+    hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, decltype(u_tag)::value, decltype(fill_tag)::value>),
+                       dim3((unsigned)total), dim3(64), 0, s, args);
+  };
+  auto with_fill = [&](auto u_tag) {
+    if (fill) go(u_tag, std::true_type());
+    else go(u_tag, std::false_type());
+  };
+  if (variant == 1) with_fill(std::integral_constant<int, 4>());   // tuning: 4 loads per batch instead of 8
+  else with_fill(std::integral_constant<int, 8>());
   SMM_LAUNCH_HIP(hipGetLastError());
   return SMM_OK;
 }

@@ -152,8 +152,8 @@ def test_host_pipeline_packs_the_used_cells(hip, rng, dtype):
 
 @pytest.mark.parametrize("transpose", [True, False])
 def test_group_apply_sb_matches_the_oracle(hip, rng, transpose):
-    """Masked levels with the field kept batch-fastest per level, X (L, S, B): regrid.py:387-427 in one
-    launch of the batch-fastest kernel -- level sub-selection and repeats, per-level masks, odd batch sizes."""
+    """Masked levels with the field kept batch-fastest per level, X (L, S, B): regrid.py:387-427 through the
+    batch-fastest kernel -- level sub-selection and repeats, per-level masks, odd batch sizes."""
     from smmregrid_amd import OperatorGroup
     S, D, n_ops = 900, 217, 4
     ops, csrs = [], []
