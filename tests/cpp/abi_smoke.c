@@ -1,6 +1,6 @@
 /* Plain-C consumer of the C ABI (include/smmregrid_amd.h): builds an operator from SCRIP
- * links, regrids a device-resident batch, the same batch through the host pipeline and a
- * two-level group, and checks them against a scalar loop.  Compiled with gcc (no HIP headers):
+ * links, regrids a device-resident batch, the same batch through the host pipeline, a two-level
+ * group, the batch-fastest entry and a patch-order operator, and checks them against a scalar loop.  Compiled with gcc (no HIP headers):
  *   gcc -std=c99 -I include tests/cpp/abi_smoke.c -o abi_smoke smmregrid_amd/libsmmregrid_hip.so -lm */
 #include <math.h>
 #include <stdio.h>
@@ -70,10 +70,28 @@ int main(void) {
   int32_t level_index[1] = {1};
   CHECK(smm_group_apply_host(grp, x, SMM_F64, yg, SMM_F64, B, 1, 1, 1, level_index, NULL, 0.0, 0, 0));
 
-  int bad = 0;
+  /* the batch-fastest entry: X transposed to (S, B), Y still (B, D); and an operator created with the
+   * shape of its target grid in patch order (30 x 20 = D) -- both must give the same bits */
+  static double xt[S * B], ysb[B * D], yp[B * D];
+  for (int b = 0; b < B; ++b)
+    for (int s = 0; s < S; ++s) xt[s * B + b] = x[b * S + s];
+  void* dxt = NULL;
+  CHECK(smm_malloc(&dxt, sizeof xt));
+  CHECK(smm_memcpy_h2d(dxt, xt, sizeof xt, NULL));
+  CHECK(smm_apply_sb(op, dxt, SMM_F64, B, dy, SMM_F64, D, B, 0.0, 0, NULL));
+  CHECK(smm_memcpy_d2h(ysb, dy, sizeof ysb, NULL));
+  const int32_t dims[2] = {30, 20};
+  smm_operator_t opp = NULL;
+  CHECK(smm_operator_create_grid(S, D, NNZ, src, dst, w, dims, 2, SMM_LAYOUT_PATCHES, 0, &opp));
+  int kind = 0;
+  CHECK(smm_operator_plan_info(opp, &kind, NULL, NULL));
+  CHECK(smm_apply(opp, dx, SMM_F64, S, dy, SMM_F64, D, B, 0.0, 0, NULL));
+  CHECK(smm_memcpy_d2h(yp, dy, sizeof yp, NULL));
+
+  int bad = (kind & 4) ? 0 : 1;
   for (int i = 0; i < B * D; ++i) {
-    const int same = (isnan(ref[i]) && isnan(y[i]) && isnan(yh[i]) && isnan(yg[i])) ||
-                     (ref[i] == y[i] && ref[i] == yh[i] && ref[i] == yg[i]);
+    const int same = (isnan(ref[i]) && isnan(y[i]) && isnan(yh[i]) && isnan(yg[i]) && isnan(ysb[i]) && isnan(yp[i])) ||
+                     (ref[i] == y[i] && ref[i] == yh[i] && ref[i] == yg[i] && ref[i] == ysb[i] && ref[i] == yp[i]);
     if (!same) ++bad;
   }
   /* error path: an address outside the grid is refused with a message */
@@ -84,6 +102,8 @@ int main(void) {
 
   CHECK(smm_group_destroy(grp));
   CHECK(smm_operator_destroy(op));
+  CHECK(smm_operator_destroy(opp));
+  CHECK(smm_free(dxt));
   CHECK(smm_free(dx));
   CHECK(smm_free(dy));
   printf("abi-smoke mismatches=%d last_error=\"%s\"\n", bad, smm_last_error());
