@@ -238,8 +238,36 @@ class CdoGenerate:
             op.close()
         return ds
 
+    def _areas_with_cdo(self, grid_arg, cdo_extra, cdo_options):
+        """cdogenerate.py:362-400: `cdo [options] -f nc4 gridarea [extra] <grid> <file>`."""
+        from .io import open_dataset
+        sgrid, tmp = self._prepare_grid(grid_arg)
+        try:
+            with tempfile.NamedTemporaryFile(suffix=".nc") as areas_file:
+                command = [self.cdo, *(cdo_options + ["-f", "nc4"]), "gridarea", *cdo_extra, sgrid, areas_file.name]
+                self.loggy.debug("Final CDO command: %s", command)
+                try:
+                    subprocess.check_output(command, stderr=subprocess.STDOUT, env=self.env)
+                except subprocess.CalledProcessError as err:
+                    print(err.output.decode(errors="replace"), file=sys.stderr)
+                    raise
+                areas = open_dataset(areas_file.name)
+            areas["cell_area"].attrs.update(units="m2", standard_name="area", long_name="area of grid cell")
+            return areas
+        finally:
+            if tmp and os.path.exists(tmp):
+                os.remove(tmp)
+
     def areas(self, target=False):
-        """Cell areas in m^2 (cdogenerate.py:345-400, `cdo gridarea`) for regular grids."""
+        """Cell areas in m^2 (cdogenerate.py:345-400): `cdo gridarea` when the binary exists (the source
+        grid with cdo_extra / cdo_options, the target grid without, as the reference does), else computed
+        here for regular and HEALPix grids."""
+        if target and self.target_grid is None:
+            raise TypeError('Target grid is not specified, cannot provide any area')
+        if self.have_cdo:
+            if target:
+                return self._areas_with_cdo(self._target_arg, [], [])
+            return self._areas_with_cdo(self._source_arg, self.cdo_extra, self.cdo_options)
         grid = self._grid_of(self.target_grid if target else self.source_grid)
         r = 6371000.0   # CDO's PlanetRadius default
         if grid.kind != "regular":
@@ -254,13 +282,15 @@ class CdoGenerate:
 
 
 def cdo_generate_weights(source_grid, target_grid, method="con", extrapolate=True,
-                         remap_norm="fracarea", vertical_dim=None, cdo_extra=None, cdo_options=None,
-                         cdo="cdo", nproc=1, loglevel='warning'):
-    """Deprecated wrapper kept for API parity (cdogenerate.py:403-418)."""
+                         remap_norm="fracarea", gridpath=None, icongridpath=None, cdo_extra=None,
+                         cdo_options=None, mask_dim=None, vertical_dim=None, cdo="cdo", nproc=1,
+                         loglevel='warning'):
+    """Deprecated wrapper kept for API parity (cdogenerate.py:403-423: same keywords, same order)."""
     import warnings
-    warnings.warn("cdo_generate_weights is deprecated, use CdoGenerate().weights()",
+    warnings.warn("cdo_generate_weights() is now deprecated, please use CdoGenerate().weights()",
                   DeprecationWarning)
-    return CdoGenerate(source_grid, target_grid, cdo_extra=cdo_extra, cdo_options=cdo_options,
-                       cdo=cdo, loglevel=loglevel).weights(method=method, extrapolate=extrapolate,
-                                                           remap_norm=remap_norm,
-                                                           mask_dim=vertical_dim, nproc=nproc)
+    generator = CdoGenerate(source_grid=source_grid, target_grid=target_grid, loglevel=loglevel,
+                            cdo_extra=cdo_extra, cdo_options=cdo_options, cdo=cdo,
+                            cdo_icon_grids=icongridpath, cdo_download_path=gridpath)
+    return generator.weights(method=method, extrapolate=extrapolate, remap_norm=remap_norm,
+                             mask_dim=mask_dim, vertical_dim=vertical_dim, nproc=nproc)

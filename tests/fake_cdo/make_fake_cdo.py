@@ -23,7 +23,15 @@ with open(os.environ["FAKE_CDO_LOG"], "a") as f:
     f.write(json.dumps({{"argv": argv, "REMAP_EXTRAPOLATE": os.environ.get("REMAP_EXTRAPOLATE"),
                         "CDO_REMAP_NORM": os.environ.get("CDO_REMAP_NORM"),
                         "CDO_DOWNLOAD_PATH": os.environ.get("CDO_DOWNLOAD_PATH")}}) + "\n")
-ops = [a for a in argv if not a.startswith("-") or a.startswith("-const") or a.startswith("-sellevidx")]
+if "gridarea" in argv:                       # cdo [options] -f nc4 gridarea [extra] <grid> <out>
+    out, source = argv[-1], argv[-2]
+    g = gridgen.parse_grid(source.split(",", 2)[2]) if source.startswith("-const,1,") else \
+        CdoGenerate._grid_of(next(v for v in io.open_dataset(source).data_vars.values()
+                                  if GridType(v.dims).horizontal_dims))
+    r = 6371000.0
+    area = (np.diff(np.sin(np.radians(g.lat_b)))[:, None] * np.radians(np.diff(g.lon_b))[None, :]) * r * r
+    io.write_netcdf3(Dataset({{"cell_area": (("lat", "lon"), area)}}, coords={{"lat": g.lat, "lon": g.lon}}), out)
+    sys.exit(0)
 gen = next(a for a in argv if a.startswith("gen"))
 method, target = gen[3:].split(",", 1)
 out, source = argv[-1], argv[-2]

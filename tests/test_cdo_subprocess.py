@@ -127,3 +127,18 @@ def test_regridder_uses_cdo_when_present(hip, fake_cdo, rng):
     imask = oracle.mask_apply_c(csr, w["src_grid_imask"].values)
     ref = oracle.apply_c(csr, x.reshape(3, -1), oracle.check_mask(imask), imask, w["dst_grid_frac"].values, 0.5)
     assert_same(out.values.reshape(3, -1), ref, exact=True)
+
+
+def test_areas_through_cdo_gridarea(fake_cdo):
+    """cdogenerate.py:345-400: source areas with cdo_extra / cdo_options, target areas without."""
+    gen = CdoGenerate("r32x16", "r16x8", cdo_options=["-P", "2"], cdo_extra=["-b", "F64"])
+    a = gen.areas()
+    (call,) = fake_cdo()
+    assert call["argv"][:4] == ["-P", "2", "-f", "nc4"] and call["argv"][4] == "gridarea"
+    assert call["argv"][5:7] == ["-b", "F64"] and call["argv"][7] == "-const,1,r32x16"
+    assert a["cell_area"].shape == (16, 32) and a["cell_area"].attrs["units"] == "m2"
+    np.testing.assert_allclose(a["cell_area"].values.sum(), 4 * np.pi * 6371000.0 ** 2, rtol=1e-12)
+    t = gen.areas(target=True)
+    assert fake_cdo()[1]["argv"][:3] == ["-f", "nc4", "gridarea"] and t["cell_area"].shape == (8, 16)
+    with pytest.raises(TypeError):
+        CdoGenerate("r32x16").areas(target=True)
