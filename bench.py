@@ -46,6 +46,10 @@ WORKLOADS = {
     # "sb" = X (S, B), "sbp" = X (U, B) holding only the used source cells
     "cfg2sb": ("bil", "r1440x721", "r360x180", 3600, "f64", "sb"),
     "cfg2sbp": ("bil", "r1440x721", "r360x180", 3600, "f64", "sbp"),
+    # config 2 with the exact-zero links dropped at operator creation (SMM_CREATE_PRUNE_ZEROS: the grids are
+    # aligned, 3 of the 4 bilinear links of every row weigh exactly 0) -- same results, a quarter of the links
+    "cfg2z": ("bil", "r1440x721", "r360x180", 3600, "f64", "bs+z"),
+    "cfg2zsb": ("bil", "r1440x721", "r360x180", 3600, "f64", "sb+z"),
     "cfg5sb": ("con", "r1440x721", "r720x360", 1024, "f64", "sb"),
     "conmidsb": ("con", "r1440x720", "r360x180", 1024, "f64", "sb"),
     "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
@@ -117,6 +121,8 @@ class Problem2D:
         from smmregrid_amd.device import DeviceArray
         method, sgrid, tgrid, n_batch, self.x_dtype = WORKLOADS[name][:5]
         self.layout = WORKLOADS[name][5] if len(WORKLOADS[name]) > 5 else "bs"
+        self.prune = self.layout.endswith("+z")
+        self.layout = self.layout.split("+")[0]
         self.n_batch = batch or n_batch
         if method == "conmask":
             nx, ny, frac = sgrid
@@ -133,7 +139,7 @@ class Problem2D:
         self.n_src, self.n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
         self.op = SparseOperator(self.n_src, self.n_dst, w["src_address"].values,
                                  w["dst_address"].values, w["remap_matrix"].values, device=device,
-                                 dst_dims=w["dst_grid_dims"].values)
+                                 dst_dims=w["dst_grid_dims"].values, prune_zeros=self.prune)
         self.op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
         self.np_dt = np.float64 if self.x_dtype == "f64" else np.float32
         x_shape = {"bs": (self.n_batch, self.n_src), "sb": (self.n_src, self.n_batch),
@@ -148,6 +154,14 @@ class Problem2D:
                      f"{self.x_dtype} in / f64 out, {lay[self.layout]}, Y (B, D), X and Y resident in HBM")
         self.meta = {"S": self.n_src, "D": self.n_dst, "nnz": self.op.nnz, "U": self.op.n_used_src,
                      "plan": self.op.plan_info()}
+        if self.prune:
+            links = w.sizes["num_links"]
+            u_file = int(np.unique(w["src_address"].values).size)
+            isz = np.dtype(self.np_dt).itemsize
+            self.meta.update(zero_links_pruned=int(links - self.op.nnz), links_as_given=int(links), U_as_given=u_file,
+                             algorithmic_bytes_as_given=int(self.n_batch * (u_file * isz + self.n_dst * 8)
+                                                            + links * 12 + (self.n_dst + 1) * 4))
+            self.desc += f", {links - self.op.nnz} exact-zero links of {links} dropped at creation"
 
     def cells(self):
         return float(self.n_dst) * self.n_batch

@@ -150,6 +150,13 @@ int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
  * dst_dims may be NULL (rank 0): same as the plain constructors.
  */
 enum { SMM_LAYOUT_AUTO = 0, SMM_LAYOUT_ROWS = 1, SMM_LAYOUT_PATCHES = 2 };
+/* Option bit OR-ed into `layout`: drop links whose (duplicate-summed) weight is exactly zero.  The
+ * reference multiplies them (`sparse.COO` keeps explicit zeros, weights.py:37-39); with the 1e20 fill
+ * every gathered value is finite, so such a link adds +-0.0 to a sum that starts at +0.0 and the
+ * results are bit-identical without it.  Bilinear weights between aligned grids are mostly zeros
+ * (r1440x721 -> r360x180: 3 links of 4).  smm_operator_info / export_csr then describe the pruned
+ * matrix.  Off by default: the operator holds exactly the links it was given. */
+enum { SMM_CREATE_PRUNE_ZEROS = 1 << 8 };
 int smm_operator_create_grid(int64_t n_src, int64_t n_dst, int64_t nnz,
                              const int32_t* src_addr_1based, const int32_t* dst_addr_1based,
                              const double* w, const int32_t* dst_dims, int dst_rank, int layout,

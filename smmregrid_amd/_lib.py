@@ -25,6 +25,7 @@ APPLY_NO_FILL = 1 << 1
 APPLY_SB_PACKED = 1 << 2
 APPLY_HOST_NO_PACK = 1 << 3
 LAYOUT_AUTO, LAYOUT_ROWS, LAYOUT_PATCHES = 0, 1, 2
+CREATE_PRUNE_ZEROS = 1 << 8
 APPLY_KERNEL_SELL = 1 << 8
 APPLY_KERNEL_TILE = 1 << 9
 

@@ -158,6 +158,34 @@ bool adopt_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_
   return true;
 }
 
+int64_t prune_zero_links(HostCsr& csr) {
+  int64_t kept = 0, max_row = 0;
+  std::vector<int64_t> rowptr((size_t)csr.n_dst + 1, 0);
+  for (int64_t d = 0; d < csr.n_dst; ++d) {
+    const int64_t row_start = kept;
+    for (int64_t i = csr.rowptr[(size_t)d]; i < csr.rowptr[(size_t)d + 1]; ++i) {
+      if (csr.val[(size_t)i] == 0.0) continue;   // +0.0 and -0.0
+      csr.col[(size_t)kept] = csr.col[(size_t)i];
+      csr.val[(size_t)kept] = csr.val[(size_t)i];
+      ++kept;
+    }
+    rowptr[(size_t)d + 1] = kept;
+    max_row = std::max(max_row, kept - row_start);
+  }
+  const int64_t dropped = csr.nnz - kept;
+  csr.rowptr.swap(rowptr);
+  csr.col.resize((size_t)kept);
+  csr.val.resize((size_t)kept);
+  csr.nnz = kept;
+  csr.max_row_nnz = max_row;
+  std::vector<uint8_t> used((size_t)csr.n_src, 0);
+  for (int32_t c : csr.col) used[(size_t)c] = 1;
+  int64_t u = 0;
+  for (uint8_t b : used) u += b;
+  csr.n_used_src = u;
+  return dropped;
+}
+
 void build_patch_slots(int64_t nx, int64_t ny, int patch_rows, SlotMap& out) {
   out = SlotMap();
   const int64_t ncb = (nx + 63) / 64, nrb = (ny + patch_rows - 1) / patch_rows;

@@ -155,6 +155,7 @@ struct smm_operator {
   uint8_t* d_imask_rows = nullptr;   // row-order copies for the batch-fastest kernel (patch order only)
   double* d_frac_rows = nullptr;
   int64_t dst_nx = 0, dst_ny = 0;    // destination grid dims when given at create time
+  int64_t pruned_links = 0;          // exact-zero links dropped at create time (SMM_CREATE_PRUNE_ZEROS)
   const smm::HostCsr& kcsr() const { return use_slots ? pcsr : csr; }   // what the kernels see
   int64_t n_slices = 0, n_slots = 0;
   int64_t* d_slice_off = nullptr;
@@ -694,6 +695,8 @@ extern "C++" {
 // barriers per batch row that couple the four waves of a patch cost as much as the traffic saves
 // (12.6 vs 12.5 ms), so SMM_LAYOUT_AUTO keeps rows.
 static int choose_layout(smm_operator* op, const int32_t* dst_dims, int dst_rank, int layout) {
+  if (layout & ~(0xFF | SMM_CREATE_PRUNE_ZEROS)) return fail(SMM_ERR_INVALID, "unknown create option bits");
+  layout &= 0xFF;
   if (layout != SMM_LAYOUT_AUTO && layout != SMM_LAYOUT_ROWS && layout != SMM_LAYOUT_PATCHES)
     return fail(SMM_ERR_INVALID, "layout must be SMM_LAYOUT_AUTO, SMM_LAYOUT_ROWS or SMM_LAYOUT_PATCHES");
   const smm::HostCsr& csr = op->csr;
@@ -739,6 +742,7 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr, const in
       delete op;
       return fail(SMM_ERR_INVALID, err);
     }
+    if (layout & SMM_CREATE_PRUNE_ZEROS) op->pruned_links = smm::prune_zero_links(op->csr);
     int lrc = choose_layout(op, dst_dims, dst_rank, layout);
     if (lrc) {
       delete op;

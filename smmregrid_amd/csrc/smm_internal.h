@@ -58,6 +58,12 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
 // monotone from 0, columns strictly ascending inside a row and < n_src) instead of sorting.
 bool adopt_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
                const double* val, HostCsr& out, std::string& err);
+// Drops links whose (duplicate-summed) weight is exactly +-0.0; returns how many went.  With the 1e20
+// fill every gathered value is finite, so such a link contributes +-0.0 to a sum that starts at +0.0:
+// the results are bit-identical with or without it (not so under SMM_APPLY_NO_FILL with non-finite X,
+// whose contract excludes them).  Bilinear weights between aligned grids are full of them: r1440x721 ->
+// r360x180 keeps 1 link of 4.
+int64_t prune_zero_links(HostCsr& csr);
 void build_sell(const HostCsr& csr, HostSell& out);
 
 // Source-tile plan for the LDS-staged kernel.  Destination rows are grouped in

@@ -49,11 +49,13 @@ class SparseOperator:
     """(S x D) weights matrix in HBM, built from SCRIP links (weights.py:25-44)."""
 
     def __init__(self, n_src, n_dst, src_address, dst_address, remap_matrix, device=None, dst_dims=None,
-                 layout="auto"):
+                 layout="auto", prune_zeros=False):
         """dst_dims: shape of the destination grid as the weights file gives it (`dst_grid_dims`,
         fastest dimension first); with it the library may lay the device structures out in 4 x 64
         patches of a 2-D target grid (`layout`: "auto" | "rows" | "patches", smm_operator_create_grid).
-        Results do not depend on the layout; the members of an OperatorGroup must share one."""
+        Results do not depend on the layout; the members of an OperatorGroup must share one.
+        prune_zeros: drop links whose weight is exactly zero (bilinear weights between aligned grids are
+        mostly zeros); results stay bit-identical because every gathered value is finite after the fill."""
         src = np.ascontiguousarray(src_address, dtype=np.int32).ravel()
         dst = np.ascontiguousarray(dst_address, dtype=np.int32).ravel()
         w = np.asarray(remap_matrix, dtype=np.float64)
@@ -67,6 +69,8 @@ class SparseOperator:
         self.device = int(device)
         h = ctypes.c_void_p()
         dims, rank, lay = _grid_args(dst_dims, layout)
+        if prune_zeros:
+            lay |= _lib.CREATE_PRUNE_ZEROS
         _lib.call("smm_operator_create_grid", int(n_src), int(n_dst), int(src.size), _cptr(src),
                   _cptr(dst), _cptr(w), _cptr(dims), rank, lay, self.device, ctypes.byref(h))
         self.dst_dims = None if dims is None else tuple(int(v) for v in dims)

@@ -55,7 +55,7 @@ class Regridder(object):
                  method='con', remap_area_min=DEFAULT_AREA_MIN, transpose=True, mask_dim=None,
                  vertical_dim=None, horizontal_dims=None, cdo_extra=None, cdo_options=None,
                  check_nan=False, cdo='cdo', loglevel='WARNING', device=None, out_dtype=np.float64,
-                 lazy=False):
+                 lazy=False, prune_zero_weights=False):
         if (source_grid is None or target_grid is None) and (weights is None):
             raise ValueError("Either weights or source_grid/target_grid must be supplied")
 
@@ -70,6 +70,9 @@ class Regridder(object):
         self.transpose = transpose
         self.device = device
         self.lazy = bool(lazy)
+        # opt-in: links of weight exactly 0 (3 of 4 bilinear links between aligned grids) are dropped when
+        # the operators are built; results are bit-identical (SMM_CREATE_PRUNE_ZEROS)
+        self.prune_zero_weights = bool(prune_zero_weights)
         # the reference always yields float64 (result_type(x, f64)); float32 is an opt-in narrowing store
         self.out_dtype = np.dtype(out_dtype)
         if self.out_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
@@ -119,10 +122,11 @@ class Regridder(object):
         epilogue vectors are placed next to the operators in HBM."""
         w = gridtype.weights
         if gridtype.mask_dim:
-            gridtype.weights_matrix = compute_weights_matrix3d(w, gridtype.mask_dim,
-                                                               device=self.device)
+            gridtype.weights_matrix = compute_weights_matrix3d(w, gridtype.mask_dim, device=self.device,
+                                                               prune_zeros=self.prune_zero_weights)
         else:
-            gridtype.weights_matrix = compute_weights_matrix(w, device=self.device)
+            gridtype.weights_matrix = compute_weights_matrix(w, device=self.device,
+                                                             prune_zeros=self.prune_zero_weights)
 
         if "dst_grid_masked" in w.variables:
             gridtype.masked = np.asarray(w["dst_grid_masked"].values)

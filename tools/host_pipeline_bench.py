@@ -5,10 +5,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from smmregrid_amd import SparseOperator, _lib, gridgen, pinned_empty
 
-rows = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+rows = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
 w = gridgen.bilinear_weights("r1440x721", "r360x180")
 S, D = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
-op = SparseOperator(S, D, w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values, device=0)
+prune = "--prune" in sys.argv      # drop the exact-zero links (half of them between these aligned grids)
+op = SparseOperator(S, D, w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values, device=0,
+                    prune_zeros=prune)
 op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
 rng = np.random.default_rng(0)
 out = {}
@@ -24,4 +26,6 @@ for kind in ("pageable", "pinned"):
         dt = time.perf_counter() - t0
         out[kind + "/" + mode] = {"rows": rows, "seconds": dt, "cells_per_s": rows * D / dt,
                                   "host_GBs": (x.nbytes + y.nbytes) / dt / 1e9}
+out["prune_zeros"] = prune
+out["used_source_cells"] = op.n_used_src
 print(json.dumps(out))
