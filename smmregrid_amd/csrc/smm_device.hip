@@ -485,29 +485,42 @@ int64_t test_fail_chunk() {
 // chunk of batch rows, batch-fastest, ready for smm_apply_sb (SMM_APPLY_SB_PACKED).  Threads split
 // the used cells; rows go in blocks of 16 so that a block's 16 source lines stay in L1 while the
 // neighbouring cells of the same lines are picked up.
+// Batch entry r of the chunk is the source row at x + (r / n_inner) * stride_o + (r % n_inner) * stride_i
+// (elements): plain row blocks have n_inner = rows' worth of stride_i = ldx; one level of a
+// (outer, level, inner, S) field has stride_o = n_lev * n_inner * S, stride_i = S.
 template <typename T>
-void pack_rows_t(T* __restrict__ out, const T* __restrict__ x, int64_t ldx, const int32_t* __restrict__ used,
-                 int64_t u0, int64_t u1, int64_t rows) {
+void pack_rows_t(T* __restrict__ out, const T* __restrict__ x, int64_t n_inner, int64_t stride_o, int64_t stride_i,
+                 const int32_t* __restrict__ used, int64_t u0, int64_t u1, int64_t rows) {
   constexpr int64_t RB = 16;
   for (int64_t r0 = 0; r0 < rows; r0 += RB) {
     const int64_t rn = std::min(RB, rows - r0);
+    const T* row[RB];
+    for (int64_t r = 0; r < rn; ++r) row[r] = x + (size_t)((r0 + r) / n_inner) * stride_o + (size_t)((r0 + r) % n_inner) * stride_i;
     for (int64_t u = u0; u < u1; ++u) {
-      const T* src = x + (size_t)r0 * ldx + used[u];
+      const int32_t c = used[u];
       T* dst = out + (size_t)u * rows + r0;
-      for (int64_t r = 0; r < rn; ++r) dst[r] = src[(size_t)r * ldx];
+      for (int64_t r = 0; r < rn; ++r) dst[r] = row[r][c];
     }
   }
 }
 
+void host_pack(void* out, const void* x, size_t xsz, int64_t n_inner, int64_t stride_o, int64_t stride_i,
+               const std::vector<int32_t>& used, int64_t rows);
+
 void host_pack(void* out, const void* x, size_t xsz, int64_t ldx, const std::vector<int32_t>& used, int64_t rows) {
+  host_pack(out, x, xsz, std::max<int64_t>(rows, 1), 0, ldx, used, rows);
+}
+
+void host_pack(void* out, const void* x, size_t xsz, int64_t n_inner, int64_t stride_o, int64_t stride_i,
+               const std::vector<int32_t>& used, int64_t rows) {
   const int64_t U = (int64_t)used.size();
   unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
   if ((size_t)U * rows * xsz < (4u << 20)) nt = 1;
   auto work = [&](int64_t u0, int64_t u1) {
     if (xsz == 8)
-      pack_rows_t((double*)out, (const double*)x, ldx, used.data(), u0, u1, rows);
+      pack_rows_t((double*)out, (const double*)x, n_inner, stride_o, stride_i, used.data(), u0, u1, rows);
     else
-      pack_rows_t((float*)out, (const float*)x, ldx, used.data(), u0, u1, rows);
+      pack_rows_t((float*)out, (const float*)x, n_inner, stride_o, stride_i, used.data(), u0, u1, rows);
   };
   if (nt == 1) {
     work(0, U);
@@ -1507,6 +1520,34 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
   const int64_t rows_per_outer = n_lev * n_inner;
   const size_t x_outer_d = (size_t)rows_per_outer * xrow_d;   // device bytes per outer index
   const size_t y_outer = (size_t)rows_per_outer * D * ysz;    // Y bytes per outer index
+  // Packing variant (see smm_apply_host): when the selected levels use at most half of their source
+  // cells in total -- masked ocean levels thin out with depth -- each level's used cells of a chunk are
+  // packed batch-fastest, one (U_l, batch) block per data level, and every level runs through the
+  // batch-fastest kernel on its block.
+  if (n_lev > 0 && !level_index) return fail(SMM_ERR_INVALID, "null level_index");
+  int64_t used_total = 0;
+  for (int64_t l = 0; l < n_lev; ++l) {
+    if (level_index[l] < 0 || level_index[l] >= (int32_t)g->ops.size())
+      return fail(SMM_ERR_INVALID, "level_index[" + std::to_string(l) + "] outside the group");
+    used_total += g->ops[(size_t)level_index[l]]->csr.n_used_src;
+  }
+  // A chunk carries every selected level, so it needs >= 32 batch entries per level to feed the
+  // batch-fastest kernel and the pack loops; when 32 entries of all levels do not fit 1 GiB of staging
+  // (config 3: 39 M used cells per time step) the whole-row pipeline stays (measured there: packing with
+  // one time step per chunk ran 4x slower than whole rows).
+  const int64_t min_outer = (32 + n_inner - 1) / n_inner;
+  bool pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
+              used_total > 0 && used_total * 2 <= n_lev * S && n_outer >= min_outer &&
+              (size_t)used_total * n_inner * min_outer * xsz <= ((size_t)1 << 30) &&
+              (chunk_outer <= 0 || chunk_outer >= min_outer || chunk_outer >= n_outer);
+  if (pack) {
+    int prc = smm_group_prepare_sb(g);
+    if (prc) return prc;
+    if (chunk_outer <= 0) {   // ~256 MiB of packed cells per chunk, at least 32 batch entries per level
+      chunk_outer = (int64_t)((256u << 20) / std::max<size_t>((size_t)used_total * n_inner * xsz, 1));
+      chunk_outer = std::max<int64_t>(min_outer, chunk_outer);
+    }
+  }
   if (chunk_outer <= 0) {
     chunk_outer = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(x_outer_d, 1)));
     chunk_outer = std::min(chunk_outer, n_outer);
@@ -1516,12 +1557,13 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
       chunk_outer = std::max<int64_t>(1, std::min<int64_t>(chunk_outer, (int64_t)(free_b / 4 / (x_outer_d + y_outer + 1))));
   }
   chunk_outer = std::min(chunk_outer, n_outer);
-  const bool x_direct = is_pinned(x_host), y_direct = is_pinned(y_host);
+  const bool x_direct = is_pinned(x_host) && !pack, y_direct = is_pinned(y_host);
 
   std::lock_guard<std::mutex> pipe_lock(g->pipe_mu);
   HostPipe& pipe = g->pipe;
-  SMM_HIP(pipe.ensure((size_t)chunk_outer * x_outer_d, (size_t)chunk_outer * y_outer,
-                      x_direct ? 0 : (size_t)chunk_outer * rows_per_outer * S * xsz,
+  const size_t x_chunk_d = pack ? (size_t)chunk_outer * n_inner * used_total * xsz : (size_t)chunk_outer * x_outer_d;
+  SMM_HIP(pipe.ensure(x_chunk_d, (size_t)chunk_outer * y_outer,
+                      x_direct ? 0 : (pack ? x_chunk_d : (size_t)chunk_outer * rows_per_outer * S * xsz),
                       y_direct ? 0 : (size_t)chunk_outer * y_outer));
 
   const int64_t n_chunks = (n_outer + chunk_outer - 1) / chunk_outer;
@@ -1554,22 +1596,46 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
     }
     if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (SMM_TEST_FAIL_AT_CHUNK)");
     const char* xsrc = (const char*)x_host + (size_t)o0 * rows_per_outer * S * xsz;
-    const void* h2d_src = xsrc;
-    if (!x_direct) {
-      host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
-      h2d_src = pipe.hx[b];
-    }
-    SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, h2d_src, (size_t)S * xsz, (size_t)S * xsz, (size_t)rows,
-                             hipMemcpyHostToDevice, pipe.stream[b]));
     int64_t ys_o, ys_l, ys_i;
     if (transpose) {
       ys_o = n_inner * n_lev * D, ys_l = D, ys_i = n_lev * D;
     } else {
       ys_o = n_inner * D, ys_l = no * n_inner * D, ys_i = D;
     }
-    int rc = smm_group_apply(g, pipe.dx[b], x_dtype, rows_per_outer * ldx_d, n_inner * ldx_d, ldx_d,
-                             pipe.dy[b], y_dtype, ys_o, ys_l, ys_i, no, n_lev, n_inner, level_index,
-                             masked_levels, remap_area_min, flags, pipe.stream[b]);
+    int rc = SMM_OK;
+    if (pack) {
+      const int64_t bc = no * n_inner;   // batch entries per level in this chunk: b = (o - o0) * n_inner + i
+      size_t off = 0;                    // bytes
+      for (int64_t l = 0; l < n_lev; ++l) {
+        smm_operator* op = g->ops[(size_t)level_index[l]];
+        host_pack((char*)pipe.hx[b] + off, xsrc + (size_t)l * n_inner * S * xsz, xsz, n_inner, rows_per_outer * S, S,
+                  op->h_used, bc);
+        off += (size_t)op->csr.n_used_src * bc * xsz;
+      }
+      SMM_HIP(hipMemcpyAsync(pipe.dx[b], pipe.hx[b], off, hipMemcpyHostToDevice, pipe.stream[b]));
+      off = 0;
+      for (int64_t l = 0; l < n_lev && !rc; ++l) {
+        const int w = level_index[l];
+        smm_operator* op = g->ops[(size_t)w];
+        unsigned fl = (flags & SMM_APPLY_NO_FILL) | SMM_APPLY_SB_PACKED;
+        if ((flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w])) fl |= SMM_APPLY_MASKED;
+        // Y of the chunk: entry (b, l, d) at b * ys_i' + l * ys_l + d, with b running over (o, i)
+        rc = smm_apply_sb(op, (char*)pipe.dx[b] + off, x_dtype, bc, (char*)pipe.dy[b] + (size_t)l * ys_l * ysz, y_dtype,
+                          transpose ? n_lev * D : D, bc, remap_area_min, fl, pipe.stream[b]);
+        off += (size_t)op->csr.n_used_src * bc * xsz;
+      }
+    } else {
+      const void* h2d_src = xsrc;
+      if (!x_direct) {
+        host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
+        h2d_src = pipe.hx[b];
+      }
+      SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, h2d_src, (size_t)S * xsz, (size_t)S * xsz, (size_t)rows,
+                               hipMemcpyHostToDevice, pipe.stream[b]));
+      rc = smm_group_apply(g, pipe.dx[b], x_dtype, rows_per_outer * ldx_d, n_inner * ldx_d, ldx_d,
+                           pipe.dy[b], y_dtype, ys_o, ys_l, ys_i, no, n_lev, n_inner, level_index,
+                           masked_levels, remap_area_min, flags, pipe.stream[b]);
+    }
     if (rc) return rc;
     if (!y_direct) {
       SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)no * y_outer, hipMemcpyDeviceToHost,

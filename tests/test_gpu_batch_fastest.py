@@ -181,3 +181,37 @@ def test_group_apply_sb_matches_the_oracle(hip, rng, transpose):
         assert_same(y.reshape(native.shape), native, exact=True)
     with pytest.raises(_lib.SmmError):                                        # packed is per operator
         grp.apply_sb(to_device(np.zeros((1, S, 4))), [0], flags=_lib.APPLY_SB_PACKED)
+
+
+@pytest.mark.parametrize("transpose", [True, False])
+def test_group_host_pipeline_packs_per_level(hip, rng, transpose):
+    """smm_group_apply_host when the selected levels use at most half of their source cells (ocean levels
+    thinning out with depth): each level's used cells of a chunk are packed batch-fastest and the level
+    runs through the batch-fastest kernel -- same bits as the whole-row pipeline and the oracle."""
+    from smmregrid_amd import OperatorGroup
+    S, D, n_ops = 4000, 230, 4
+    ops, csrs = [], []
+    imask = (rng.random((n_ops, D)) > 0.3).astype(np.int32)
+    frac = rng.random((n_ops, D))
+    for i in range(n_ops):
+        src, dst, w = random_links(rng, S, D, 300 + 250 * i)             # U_i well below S / 2
+        op = SparseOperator(S, D, src, dst, w, device=0)
+        op.set_epilogue(imask[i], frac[i])
+        ops.append(op)
+        csrs.append(op.export_csr())
+    assert sum(op.n_used_src for op in ops) * 2 <= n_ops * S
+    grp = OperatorGroup(ops)
+    masked_levels = np.array([1, 0, 1, 1], np.uint8)
+    for level_index, n_outer, n_inner, dtype in [([0, 1, 2, 3], 40, 1, np.float64), ([2, 0, 2], 9, 5, np.float32),
+                                                  ([3], 33, 1, np.float64)]:
+        L = len(level_index)
+        x = field(rng, n_outer * L * n_inner, S, dtype=dtype, nan_frac=0.03).reshape(n_outer, L, n_inner, S)
+        ref = oracle.apply_levels(csrs, x, 1, np.asarray(level_index), masked_levels.astype(bool), imask, frac, 0.4,
+                                  transpose)
+        for chunk in (0, 1, 4, 7, 33):          # small explicit chunks take the whole-row pipeline
+            y = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.4, transpose=transpose,
+                               chunk_outer=chunk)
+            assert_same(y, ref, exact=True)
+        y = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.4, transpose=transpose,
+                           flags=_lib.APPLY_HOST_NO_PACK)
+        assert_same(y, ref, exact=True)
