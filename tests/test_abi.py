@@ -76,3 +76,29 @@ def test_missing_rccl_is_unsupported_not_a_crash():
     rc, rc2, msg = out.stdout.strip().split(" ", 2)
     assert int(rc) == _lib.SMM_ERR_UNSUPPORTED and int(rc2) == _lib.SMM_ERR_UNSUPPORTED
     assert "cannot load librccl" in msg and "nonexistent" in msg
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: no module of the product package, and no native source of the
+    library, may import, link or call anything under oracle/ (only tests/, smoke() and bench.py's
+    cpu_baseline leg do)."""
+    import ast
+    pkg = os.path.join(ROOT, "smmregrid_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for name in files:
+            path = os.path.join(dirpath, name)
+            if name.endswith(".py"):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        mods = [node.module or ""]
+                    assert not any(m == "oracle" or m.startswith("oracle.") for m in mods), path
+            elif name.endswith((".hip", ".cpp", ".hpp", ".h")) or name == "Makefile":
+                text = open(path).read()     # comments may name the oracle; includes and link lines may not
+                assert not re.search(r'#\s*include[^\n]*oracle|liboracle|-loracle|oracle\.(c|so)\b', text), path
+    lib = ctypes.CDLL(_lib.LIB_PATH) if os.path.exists(_lib.LIB_PATH) else None
+    if lib is not None:
+        assert not hasattr(lib, "oracle_apply")
