@@ -4,6 +4,7 @@
 // stdout: the canonical CSR and invariants of the SELL / tile-plan structures.
 #include <cinttypes>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -129,6 +130,66 @@ int main() {
       }
     }
     printf("ADOPTBAD %lld\n", abad);
+  }
+  // destination patches: slot order of a 2-D grid (the largest nx <= sqrt(n_dst) dividing n_dst), the
+  // permuted CSR keeps every row's links, padding slots are empty, SELL / tile plan build on it
+  {
+    long long sbad = 0;
+    int64_t nx = 1;
+    for (int64_t f = 1; f * f <= csr.n_dst; ++f)
+      if (csr.n_dst % f == 0) nx = f;
+    const int64_t ny = csr.n_dst / nx;
+    smm::SlotMap map;
+    smm::build_patch_slots(nx, ny, 4, map);
+    if (map.identity || map.n_slots % 256 != 0 || (int64_t)map.row_of_slot.size() != map.n_slots) ++sbad;
+    std::vector<int> seen((size_t)csr.n_dst, 0);
+    smm::HostCsr pc;
+    smm::permute_csr(csr, map, pc);
+    if (pc.n_dst != map.n_slots || pc.nnz != csr.nnz || pc.rowptr.back() != csr.nnz) ++sbad;
+    for (int64_t sl = 0; sl < map.n_slots; ++sl) {
+      const int32_t r = map.row_of_slot[(size_t)sl];
+      const int64_t a = pc.rowptr[(size_t)sl], b = pc.rowptr[(size_t)sl + 1];
+      if (r < 0) {
+        if (a != b) ++sbad;
+        continue;
+      }
+      if (r >= csr.n_dst || seen[(size_t)r]++) { ++sbad; continue; }
+      const int64_t a0 = csr.rowptr[(size_t)r], b0 = csr.rowptr[(size_t)r + 1];
+      if (b - a != b0 - a0) { ++sbad; continue; }
+      for (int64_t k = 0; k < b - a; ++k)
+        if (pc.col[(size_t)(a + k)] != csr.col[(size_t)(a0 + k)] || pc.val[(size_t)(a + k)] != csr.val[(size_t)(a0 + k)]) ++sbad;
+    }
+    for (int64_t d = 0; d < csr.n_dst; ++d)
+      if (seen[(size_t)d] != 1) ++sbad;
+    smm::HostSell ps;
+    smm::build_sell(pc, ps);
+    smm::HostTilePlan pp;
+    smm::build_tile_plan(pc, ps, 256, 16, 512, pp);
+    smm::tighten_tile_plan(pc, pp, 512);
+    if (ps.n_slices * 64 != map.n_slots) ++sbad;
+    printf("SLOTBAD %lld\n", sbad);
+  }
+  // exact-zero links dropped: what is left is the same matrix without its zeros
+  {
+    long long pbad = 0;
+    smm::HostCsr pr = csr;
+    const int64_t dropped = smm::prune_zero_links(pr);
+    int64_t zeros = 0;
+    for (double v : csr.val) zeros += v == 0.0;
+    if (dropped != zeros || pr.nnz != csr.nnz - zeros || (int64_t)pr.col.size() != pr.nnz || pr.rowptr.back() != pr.nnz) ++pbad;
+    int64_t max_row = 0;
+    for (int64_t d = 0; d < csr.n_dst; ++d) {
+      int64_t k2 = pr.rowptr[(size_t)d];
+      for (int64_t k = csr.rowptr[(size_t)d]; k < csr.rowptr[(size_t)d + 1]; ++k) {
+        if (csr.val[(size_t)k] == 0.0) continue;
+        if (k2 >= pr.rowptr[(size_t)d + 1] || pr.col[(size_t)k2] != csr.col[(size_t)k] || pr.val[(size_t)k2] != csr.val[(size_t)k]) ++pbad;
+        ++k2;
+      }
+      if (k2 != pr.rowptr[(size_t)d + 1]) ++pbad;
+      max_row = std::max<int64_t>(max_row, pr.rowptr[(size_t)d + 1] - pr.rowptr[(size_t)d]);
+    }
+    if (max_row != pr.max_row_nnz) ++pbad;
+    printf("PRUNEBAD %lld %lld\n", pbad, (long long)dropped);
   }
   printf("SELLBAD %lld\n", bad);
   return 0;
