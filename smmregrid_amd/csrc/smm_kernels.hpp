@@ -78,6 +78,7 @@ struct SbArgs {
   double area_min;
   int masked;
   int xcd_remap;
+  int b_fastest;           // > 0: width (destination tiles) of the strips the tiles are ordered in
 };
 
 namespace {
@@ -874,8 +875,22 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
       bid = (slot / C) * round + xcd * C + (slot % C);
     }
   }
-  const uint32_t bt32 = bid / (uint32_t)a.n_dtiles;
-  const int64_t dt = bid - bt32 * (uint32_t)a.n_dtiles, bt = bt32;
+  int64_t dt, bt;
+  if (a.b_fastest > 0) {
+    // strips of `b_fastest` destination tiles: inside a strip the destination tile runs fastest, then the
+    // batch tile -- consecutive workgroups (one XCD run) read consecutive 1-KiB pieces of the same source
+    // rows (b) and write neighbouring 128-B lines of the same Y rows (d)
+    const uint32_t sub = (uint32_t)a.b_fastest, per = (uint32_t)a.n_btiles * sub;
+    const uint32_t sd = bid / per, rem = bid - sd * per;
+    const uint32_t left = (uint32_t)a.n_dtiles - sd * sub, sub_here = left < sub ? left : sub;
+    const uint32_t b32 = rem / sub_here;
+    bt = b32;
+    dt = (int64_t)sd * sub + (rem - b32 * sub_here);
+  } else {
+    const uint32_t bt32 = bid / (uint32_t)a.n_dtiles;
+    dt = bid - bt32 * (uint32_t)a.n_dtiles;
+    bt = bt32;
+  }
   const int64_t d0 = dt * TD;
   const int rows = (int)(a.n_dst - d0 < TD ? a.n_dst - d0 : TD);
   const int64_t b0 = bt * BT;

@@ -208,6 +208,10 @@ int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
   if (total > 0x7fffffffLL) return smm::fail_msg(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
   args.n_blocks = total;
   args.xcd_remap = variant == 6 ? 0 : (variant == 7 ? 8 : (variant == 13 ? 128 : 32));
+  // Tile order: strips of 2 destination tiles, inside a strip destination tile fastest, then batch tile
+  // (config 2: 1.76 -> 1.65 ms against destination-tile-fastest order over the whole grid; strips of 1, 4,
+  // 8, 16 tiles within 3 % of it).  Tuning variants: 3 = whole-grid order, 4 / 5 = strips of 1 / 8.
+  args.b_fastest = variant == 3 ? 0 : (variant == 4 ? 1 : (variant == 5 ? 8 : 2));
   auto go = [&](auto u_tag, auto fill_tag) {
     hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, decltype(u_tag)::value, decltype(fill_tag)::value>),
                        dim3((unsigned)total), dim3(64), 0, s, args);
