@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SMM_ABI_VERSION 2
+#define SMM_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -66,7 +66,7 @@ enum {
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };
 /* tuning knobs for benchmarks (0 = library default; results are identical for every value):
- * kernel variant in bits 16..19 -- tile kernel: 2..5 cache policy of X loads / Y stores,
+ * kernel variant in bits 16..19 -- tile kernel: 3 / 4 non-temporal / cached X loads,
  * 6 dispatcher block order instead of runs of 32 consecutive blocks per XCD (7 / 13: runs of
  * 8 / 128), 12 single-row steps on small tiles; SELL kernel: 1 / 2 = 8 / 2 batch rows per thread -- and the batch rows walked per
  * workgroup of the tile kernel in bits 20..27 */
@@ -93,6 +93,12 @@ int smm_host_free(void* hptr);
 int smm_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int smm_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int smm_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+/* pitched copies: `height` rows of `width` BYTES, row r at base + r * pitch (pitches in bytes) -- fields
+ * whose device rows start on 128-B lines, columns of a batch-fastest field */
+int smm_memcpy2d_h2d(void* dst_dev, size_t dpitch, const void* src_host, size_t spitch, size_t width,
+                     size_t height, void* stream);
+int smm_memcpy2d_d2h(void* dst_host, size_t dpitch, const void* src_dev, size_t spitch, size_t width,
+                     size_t height, void* stream);
 int smm_memset(void* dst_dev, int value, size_t bytes, void* stream);
 int smm_stream_create(void** stream);
 int smm_stream_destroy(void* stream);
@@ -136,34 +142,18 @@ int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
                             const int32_t* col, const double* val, int device,
                             smm_operator_t* out);
 /*
- * The same two constructors with the shape of the destination grid (SCRIP `dst_grid_dims`, fastest
- * dimension first, `regrid.py:572-579`) and the destination layout of the device structures:
- *   SMM_LAYOUT_ROWS    consecutive destination cells per wavefront (what the plain constructors build)
- *   SMM_LAYOUT_PATCHES 2-D grids: a 4-wave workgroup owns a patch of 4 grid rows x 64 grid columns and
- *                      stages ONE source tile for it, so the source rows between vertically adjacent
- *                      destination rows are fetched once per workgroup instead of once per wavefront
- *                      (conservative remaps with 17..48 links per row: ~11 % fewer staged lines).
- *                      Opt-in: on MI355X the barriers that couple the four waves cost what the
- *                      traffic saves, so it is not chosen automatically.
- *   SMM_LAYOUT_AUTO    the library's choice: rows
- * Results do not depend on the layout (bit-identical).  The members of a group must share one layout.
- * dst_dims may be NULL (rank 0): same as the plain constructors.
+ * smm_operator_create with options.
+ *   SMM_CREATE_PRUNE_ZEROS  drop links whose (duplicate-summed) weight is exactly zero.  The reference
+ *     multiplies them (`sparse.COO` keeps explicit zeros, weights.py:37-39); with the 1e20 fill every
+ *     gathered value is finite, so such a link adds +-0.0 to a sum that starts at +0.0 and the results
+ *     are bit-identical without it.  Bilinear weights between aligned grids are mostly zeros
+ *     (r1440x721 -> r360x180: 2 links of 4).  smm_operator_info / export_csr then describe the pruned
+ *     matrix.  Off by default: the operator holds exactly the links it was given.
  */
-enum { SMM_LAYOUT_AUTO = 0, SMM_LAYOUT_ROWS = 1, SMM_LAYOUT_PATCHES = 2 };
-/* Option bit OR-ed into `layout`: drop links whose (duplicate-summed) weight is exactly zero.  The
- * reference multiplies them (`sparse.COO` keeps explicit zeros, weights.py:37-39); with the 1e20 fill
- * every gathered value is finite, so such a link adds +-0.0 to a sum that starts at +0.0 and the
- * results are bit-identical without it.  Bilinear weights between aligned grids are mostly zeros
- * (r1440x721 -> r360x180: 3 links of 4).  smm_operator_info / export_csr then describe the pruned
- * matrix.  Off by default: the operator holds exactly the links it was given. */
-enum { SMM_CREATE_PRUNE_ZEROS = 1 << 8 };
-int smm_operator_create_grid(int64_t n_src, int64_t n_dst, int64_t nnz,
-                             const int32_t* src_addr_1based, const int32_t* dst_addr_1based,
-                             const double* w, const int32_t* dst_dims, int dst_rank, int layout,
-                             int device, smm_operator_t* out);
-int smm_operator_create_csr_grid(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
-                                 const int32_t* col, const double* val, const int32_t* dst_dims,
-                                 int dst_rank, int layout, int device, smm_operator_t* out);
+enum { SMM_CREATE_PRUNE_ZEROS = 1u << 0 };
+int smm_operator_create_opt(int64_t n_src, int64_t n_dst, int64_t nnz,
+                            const int32_t* src_addr_1based, const int32_t* dst_addr_1based,
+                            const double* w, unsigned options, int device, smm_operator_t* out);
 int smm_operator_destroy(smm_operator_t op);
 
 /* sizes after duplicate-summing; n_used_src = distinct source cells with >= 1 link (U) */
@@ -194,8 +184,7 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask,
 int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask);
 
 /* kernel selection the library made for this operator -- kernel_kind bit 0: an LDS tile plan
- * exists, bit 1: it is the default kernel (else SELL row-per-lane), bit 2: destination patches
- * (SMM_LAYOUT_PATCHES), bits 8..: destination rows
+ * exists, bit 1: it is the default kernel (else SELL row-per-lane), bits 8..: destination rows
  * per block of the plan (256, 64, or 32 / 16 / 8 for rows with very wide footprints) */
 int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
                            int64_t* staged_src_elems);
@@ -326,6 +315,11 @@ int smm_group_apply_host(smm_group_t g,
                          int64_t n_outer, int64_t n_lev, int64_t n_inner, int transpose,
                          const int32_t* level_index, const uint8_t* masked_levels,
                          double remap_area_min, unsigned flags, int64_t chunk_outer);
+
+/* Test hook of the two host pipelines' error path: chunk number `chunk` (0-based) of every following
+ * smm_apply_host / smm_group_apply_host call fails with SMM_ERR_HIP before its copies are queued;
+ * chunk < 0 (the initial state) switches it off.  Process-wide; for tests only. */
+int smm_debug_fail_at_chunk(int64_t chunk);
 
 /* ------------------------------------------------- multi-GPU exchange (RCCL over xGMI) */
 

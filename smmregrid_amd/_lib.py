@@ -24,8 +24,7 @@ APPLY_MASKED = 1 << 0
 APPLY_NO_FILL = 1 << 1
 APPLY_SB_PACKED = 1 << 2
 APPLY_HOST_NO_PACK = 1 << 3
-LAYOUT_AUTO, LAYOUT_ROWS, LAYOUT_PATCHES = 0, 1, 2
-CREATE_PRUNE_ZEROS = 1 << 8
+CREATE_PRUNE_ZEROS = 1 << 0
 APPLY_KERNEL_SELL = 1 << 8
 APPLY_KERNEL_TILE = 1 << 9
 
@@ -64,6 +63,8 @@ SIGNATURES = {
     "smm_memcpy_h2d": [_p, _p, _size, _p],
     "smm_memcpy_d2h": [_p, _p, _size, _p],
     "smm_memcpy_d2d": [_p, _p, _size, _p],
+    "smm_memcpy2d_h2d": [_p, _size, _p, _size, _size, _size, _p],
+    "smm_memcpy2d_d2h": [_p, _size, _p, _size, _size, _size, _p],
     "smm_memset": [_p, _int, _size, _p],
     "smm_stream_create": [_pp],
     "smm_stream_destroy": [_p],
@@ -78,8 +79,7 @@ SIGNATURES = {
     "smm_fill_random": [_p, _int, _i64, ctypes.c_uint64, _dbl, _dbl, _p],
     "smm_operator_create": [_i64, _i64, _i64, _p, _p, _p, _int, _pp],
     "smm_operator_create_csr": [_i64, _i64, _p, _p, _p, _int, _pp],
-    "smm_operator_create_grid": [_i64, _i64, _i64, _p, _p, _p, _p, _int, _int, _int, _pp],
-    "smm_operator_create_csr_grid": [_i64, _i64, _p, _p, _p, _p, _int, _int, _int, _pp],
+    "smm_operator_create_opt": [_i64, _i64, _i64, _p, _p, _p, _uint, _int, _pp],
     "smm_operator_destroy": [_p],
     "smm_operator_info": [_p] + [ctypes.POINTER(_i64)] * 5,
     "smm_operator_export_csr": [_p, _p, _p, _p],
@@ -106,6 +106,7 @@ SIGNATURES = {
     "smm_group_prepare_sb": [_p],
     "smm_group_apply_sb": [_p, _p, _int, _i64, _i64, _p, _int, _i64, _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
     "smm_group_apply_host": [_p, _p, _int, _p, _int, _i64, _i64, _i64, _int, _p, _p, _dbl, _uint, _i64],
+    "smm_debug_fail_at_chunk": [_i64],
     "smm_comm_unique_id": [_p],
     "smm_comm_create": [_p, _int, _int, _pp],
     "smm_comm_destroy": [_p],

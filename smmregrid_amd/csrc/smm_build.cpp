@@ -186,43 +186,47 @@ int64_t prune_zero_links(HostCsr& csr) {
   return dropped;
 }
 
-void build_patch_slots(int64_t nx, int64_t ny, int patch_rows, SlotMap& out) {
-  out = SlotMap();
-  const int64_t ncb = (nx + 63) / 64, nrb = (ny + patch_rows - 1) / patch_rows;
-  out.identity = false;
-  out.n_slots = nrb * ncb * patch_rows * 64;
-  out.row_of_slot.assign((size_t)out.n_slots, -1);
-  int64_t s = 0;
-  for (int64_t jb = 0; jb < nrb; ++jb)
-    for (int64_t ib = 0; ib < ncb; ++ib)
-      for (int w = 0; w < patch_rows; ++w)
-        for (int lane = 0; lane < 64; ++lane, ++s) {
-          const int64_t j = jb * patch_rows + w, i = ib * 64 + lane;
-          if (j < ny && i < nx) out.row_of_slot[(size_t)s] = (int32_t)(j * nx + i);
-        }
-}
-
-void permute_csr(const HostCsr& csr, const SlotMap& slots, HostCsr& out) {
-  out = HostCsr();
-  out.n_src = csr.n_src;
-  out.n_dst = slots.n_slots;
-  out.nnz = csr.nnz;
-  out.n_used_src = csr.n_used_src;
-  out.max_row_nnz = csr.max_row_nnz;
-  out.rowptr.assign((size_t)slots.n_slots + 1, 0);
-  out.col.resize((size_t)csr.nnz);
-  out.val.resize((size_t)csr.nnz);
-  int64_t p = 0;
-  for (int64_t s = 0; s < slots.n_slots; ++s) {
-    const int32_t r = slots.row_of_slot[(size_t)s];
-    if (r >= 0) {
-      const int64_t a = csr.rowptr[(size_t)r], b = csr.rowptr[(size_t)r + 1];
-      std::copy(csr.col.begin() + a, csr.col.begin() + b, out.col.begin() + p);
-      std::copy(csr.val.begin() + a, csr.val.begin() + b, out.val.begin() + p);
-      p += b - a;
-    }
-    out.rowptr[(size_t)s + 1] = p;
+HostChunk host_chunk_units(int64_t n_units, size_t x_unit, size_t y_unit, size_t xp_unit,
+                           int64_t min_pack_units, int64_t pack_align, int64_t requested,
+                           size_t free_bytes) {
+  constexpr size_t kTarget = (size_t)256 << 20;   // ~256 MiB of X + Y per chunk
+  constexpr size_t kPackCap = (size_t)1 << 30;    // the shortest packed chunk may not exceed 1 GiB
+  HostChunk c;
+  n_units = std::max<int64_t>(n_units, 1);
+  min_pack_units = std::max<int64_t>(min_pack_units, 1);
+  const size_t unit_w = std::max<size_t>(x_unit + y_unit, 1), unit_p = std::max<size_t>(xp_unit + y_unit, 1);
+  c.pack = xp_unit > 0 && n_units >= min_pack_units;
+  if (requested > 0) {   // the caller's chunk size is kept; too short a chunk does not pack
+    if (requested < min_pack_units && requested < n_units) c.pack = false;
+    c.units = std::min(requested, n_units);
+    return c;
   }
+  if (c.pack) {
+    int64_t u = (int64_t)(kTarget / unit_p);
+    if (u < min_pack_units) {
+      // too few batch entries per chunk for the pack loops and the batch-fastest kernel: take the
+      // minimum if that stays within the cap, else ship whole rows
+      if ((size_t)min_pack_units * unit_p <= kPackCap) u = min_pack_units;
+      else c.pack = false;
+    }
+    if (c.pack && pack_align > 1 && 2 * u >= pack_align)   // whole batch tiles of the kernel
+      u = std::max<int64_t>(pack_align, u / pack_align * pack_align);
+    c.units = u;
+  }
+  if (!c.pack) c.units = std::max<int64_t>(1, (int64_t)(kTarget / unit_w));
+  c.units = std::min(c.units, n_units);
+  // the four device buffers of a chunk (2 x X, 2 x Y) may take a quarter of the free memory at most
+  auto clamp = [&](size_t unit) {
+    if (free_bytes > 0 && 2 * (size_t)c.units * unit > ((size_t)2 << 30))
+      c.units = std::max<int64_t>(1, std::min<int64_t>(c.units, (int64_t)(free_bytes / 4 / (unit + 1))));
+  };
+  clamp(c.pack ? unit_p : unit_w);
+  if (c.pack && c.units < min_pack_units && c.units < n_units) {   // cannot pack in that little memory
+    c.pack = false;
+    c.units = std::min<int64_t>(n_units, std::max<int64_t>(1, (int64_t)(kTarget / unit_w)));
+    clamp(unit_w);
+  }
+  return c;
 }
 
 void build_sell(const HostCsr& csr, HostSell& out) {

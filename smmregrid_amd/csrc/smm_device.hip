@@ -144,19 +144,8 @@ constexpr int shape_rows(int which) { return which == 0 ? 256 : (64 >> (which - 
 
 struct smm_operator {
   int device = -1;
-  smm::HostCsr csr;          // canonical: row = destination cell (export, info, batch-fastest kernel)
-  // Destination slot order of the SELL / tile-plan structures below (smm_internal.h SlotMap): rows, or
-  // 4 x 64 patches of a 2-D destination grid.  With patches `pcsr` is the CSR in slot order and every
-  // per-row device array below (rowlen, imask, frac) is indexed by slot.
-  bool use_slots = false;
-  smm::SlotMap slots;
-  smm::HostCsr pcsr;
-  int32_t* d_row_of = nullptr;
-  uint8_t* d_imask_rows = nullptr;   // row-order copies for the batch-fastest kernel (patch order only)
-  double* d_frac_rows = nullptr;
-  int64_t dst_nx = 0, dst_ny = 0;    // destination grid dims when given at create time
-  int64_t pruned_links = 0;          // exact-zero links dropped at create time (SMM_CREATE_PRUNE_ZEROS)
-  const smm::HostCsr& kcsr() const { return use_slots ? pcsr : csr; }   // what the kernels see
+  smm::HostCsr csr;          // canonical: row = destination cell
+  int64_t pruned_links = 0;  // exact-zero links dropped at create time (SMM_CREATE_PRUNE_ZEROS)
   int64_t n_slices = 0, n_slots = 0;
   int64_t* d_slice_off = nullptr;
   int32_t* d_col = nullptr;
@@ -205,7 +194,6 @@ struct smm_operator {
     L.chunk_src = plan[which].d_chunk_src;
     L.lcol = plan[which].d_lcol;
     L.blk_direct = plan[which].d_blk_direct;
-    L.row_of = d_row_of;
     return L;
   }
 };
@@ -281,9 +269,6 @@ void release(smm_operator* op) {
     (void)hipFree(pl.d_blk_direct);
   }
   (void)hipFree(op->d_desc);
-  (void)hipFree(op->d_row_of);
-  (void)hipFree(op->d_imask_rows);
-  (void)hipFree(op->d_frac_rows);
   (void)hipFree(op->d_csr_rowptr);
   (void)hipFree(op->d_csr_col);
   (void)hipFree(op->d_csr_colp);
@@ -300,8 +285,8 @@ int ensure_plan(smm_operator* op, int which) {
   // LDS / staging-register budget: 64 KiB per 4-wave block, 16 KiB per single-wave block (whatever
   // part of the slice's rows it owns)
   const int64_t budget = which == 0 ? kTileMaxChunks : kTileMaxChunks / kWavesPerBlock;
-  smm::build_tile_plan(op->kcsr(), op->sell_shape, shape_rows(which), kChunkElems, budget, hp);
-  smm::tighten_tile_plan(op->kcsr(), hp, budget);
+  smm::build_tile_plan(op->csr, op->sell_shape, shape_rows(which), kChunkElems, budget, hp);
+  smm::tighten_tile_plan(op->csr, hp, budget);
   pl.built = true;
   if (!hp.valid) return SMM_OK;
   int rc = SMM_OK;
@@ -475,11 +460,10 @@ void host_copy(void* dst, const void* src, size_t bytes) {
   for (auto& th : pool) th.join();
 }
 
-// test hook for the pipelines' error path: SMM_TEST_FAIL_AT_CHUNK=<c> makes chunk c fail
-int64_t test_fail_chunk() {
-  const char* e = getenv("SMM_TEST_FAIL_AT_CHUNK");
-  return (e && *e) ? (int64_t)atoll(e) : -1;
-}
+// test hook for the pipelines' error path (smm_debug_fail_at_chunk): chunk c of the next host-pipeline
+// calls fails; -1 (the default) = off.  Set explicitly by the tests, never read from the environment.
+std::atomic<int64_t> g_fail_at_chunk{-1};
+int64_t test_fail_chunk() { return g_fail_at_chunk.load(std::memory_order_relaxed); }
 
 // Pack of the host pipeline: out[u * rows + r] = x[r * ldx + used[u]] -- the used source cells of a
 // chunk of batch rows, batch-fastest, ready for smm_apply_sb (SMM_APPLY_SB_PACKED).  Threads split
@@ -629,6 +613,30 @@ int smm_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
   SMM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return SMM_OK;
 }
+int smm_memcpy2d_h2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                     void* stream) {
+  if (width == 0 || height == 0) return SMM_OK;
+  if (dpitch < width || spitch < width) return fail(SMM_ERR_INVALID, "pitch smaller than the row width");
+  if (stream)
+    SMM_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, (hipStream_t)stream));
+  else
+    SMM_HIP(hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice));
+  return SMM_OK;
+}
+int smm_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                     void* stream) {
+  if (width == 0 || height == 0) return SMM_OK;
+  if (dpitch < width || spitch < width) return fail(SMM_ERR_INVALID, "pitch smaller than the row width");
+  if (stream)
+    SMM_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  else
+    SMM_HIP(hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost));
+  return SMM_OK;
+}
+int smm_debug_fail_at_chunk(int64_t chunk) {
+  g_fail_at_chunk.store(chunk < 0 ? -1 : chunk, std::memory_order_relaxed);
+  return SMM_OK;
+}
 int smm_memset(void* dst, int value, size_t bytes, void* stream) {
   if (bytes == 0) return SMM_OK;
   SMM_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
@@ -703,36 +711,11 @@ int smm_fill_random(void* dst, int dtype, int64_t n, uint64_t seed, double mean,
 
 // Shared by the two constructors: `fill_csr` builds op->csr (false + err on invalid input).
 extern "C++" {
-// Destination slot order of a new operator (host work only).  Patches are opt-in: measured on MI355X
-// (config 3, `tools/exp/ab_layout.sh`) they stage 11 % fewer lines than 64-row blocks, but the two
-// barriers per batch row that couple the four waves of a patch cost as much as the traffic saves
-// (12.6 vs 12.5 ms), so SMM_LAYOUT_AUTO keeps rows.
-static int choose_layout(smm_operator* op, const int32_t* dst_dims, int dst_rank, int layout) {
-  if (layout & ~(0xFF | SMM_CREATE_PRUNE_ZEROS)) return fail(SMM_ERR_INVALID, "unknown create option bits");
-  layout &= 0xFF;
-  if (layout != SMM_LAYOUT_AUTO && layout != SMM_LAYOUT_ROWS && layout != SMM_LAYOUT_PATCHES)
-    return fail(SMM_ERR_INVALID, "layout must be SMM_LAYOUT_AUTO, SMM_LAYOUT_ROWS or SMM_LAYOUT_PATCHES");
-  const smm::HostCsr& csr = op->csr;
-  bool can = false;
-  if (dst_dims && dst_rank == 2 && dst_dims[0] > 0 && dst_dims[1] > 0 &&
-      (int64_t)dst_dims[0] * dst_dims[1] == csr.n_dst) {
-    op->dst_nx = dst_dims[0];   // SCRIP dst_grid_dims: fastest first
-    op->dst_ny = dst_dims[1];
-    can = true;
-  }
-  if (layout != SMM_LAYOUT_PATCHES) return SMM_OK;
-  if (!can) return fail(SMM_ERR_INVALID, "SMM_LAYOUT_PATCHES needs dst_dims of rank 2 whose product is n_dst");
-  smm::build_patch_slots(op->dst_nx, op->dst_ny, kWavesPerBlock, op->slots);
-  smm::permute_csr(csr, op->slots, op->pcsr);
-  op->use_slots = true;
-  return SMM_OK;
-}
-
 template <typename F>
-static int create_operator(int device, smm_operator_t* out, F fill_csr, const int32_t* dst_dims = nullptr,
-                           int dst_rank = 0, int layout = SMM_LAYOUT_AUTO) {
+static int create_operator(int device, smm_operator_t* out, F fill_csr, unsigned options = 0u) {
   if (!out) return fail(SMM_ERR_INVALID, "null out handle");
   *out = nullptr;
+  if (options & ~(unsigned)SMM_CREATE_PRUNE_ZEROS) return fail(SMM_ERR_INVALID, "unknown create option bits");
   int ndev = 0;
   {
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -755,13 +738,8 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr, const in
       delete op;
       return fail(SMM_ERR_INVALID, err);
     }
-    if (layout & SMM_CREATE_PRUNE_ZEROS) op->pruned_links = smm::prune_zero_links(op->csr);
-    int lrc = choose_layout(op, dst_dims, dst_rank, layout);
-    if (lrc) {
-      delete op;
-      return lrc;
-    }
-    const smm::HostCsr& kc = op->kcsr();
+    if (options & SMM_CREATE_PRUNE_ZEROS) op->pruned_links = smm::prune_zero_links(op->csr);
+    const smm::HostCsr& kc = op->csr;
     smm::HostSell sell;
     smm::build_sell(kc, sell);
 
@@ -784,23 +762,10 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr, const in
     op->sell_shape.rowlen = std::move(sell.rowlen);
     // own block shape: 256 rows for rows of <= 16 links; else one slice, or the largest part of a
     // slice whose footprint fits the LDS budget and is used well enough (plan valid and preferred)
-    if (op->use_slots && (rc = upload(&op->d_row_of, op->slots.row_of_slot))) {
-      release(op);
-      return rc;
-    }
-    // destination patches: a 4-wave workgroup owns a 4 x 64 patch (shape 0) also for rows of 17..48 links
-    op->native = (kc.max_row_nnz > 16 && !(op->use_slots && kc.max_row_nnz <= 48)) ? 1 : 0;
+    op->native = kc.max_row_nnz > 16 ? 1 : 0;
     if ((rc = ensure_plan(op, op->native))) {
       release(op);
       return rc;
-    }
-    if (op->native == 0 && kc.max_row_nnz > 16 &&
-        !(op->plan[0].valid && op->plan[0].max_chunks * 8 <= 16 * kThreads)) {
-      op->native = 1;   // forced patches whose 4-wave tile does not fit: single-wave blocks on the slot order
-      if ((rc = ensure_plan(op, op->native))) {
-        release(op);
-        return rc;
-      }
     }
     if (op->native == 1) {
       // rows beyond 48 links: start at the shape whose lane groups can keep the whole row in
@@ -851,12 +816,12 @@ int smm_operator_create(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t
   });
 }
 
-int smm_operator_create_grid(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src_addr_1based,
-                             const int32_t* dst_addr_1based, const double* w, const int32_t* dst_dims,
-                             int dst_rank, int layout, int device, smm_operator_t* out) {
+int smm_operator_create_opt(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src_addr_1based,
+                            const int32_t* dst_addr_1based, const double* w, unsigned options, int device,
+                            smm_operator_t* out) {
   return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
     return smm::build_csr(n_src, n_dst, nnz, src_addr_1based, dst_addr_1based, w, csr, err);
-  }, dst_dims, dst_rank, layout);
+  }, options);
 }
 
 int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
@@ -864,14 +829,6 @@ int smm_operator_create_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr,
   return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
     return smm::adopt_csr(n_src, n_dst, rowptr, col, val, csr, err);
   });
-}
-
-int smm_operator_create_csr_grid(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_t* col,
-                                 const double* val, const int32_t* dst_dims, int dst_rank, int layout,
-                                 int device, smm_operator_t* out) {
-  return create_operator(device, out, [&](smm::HostCsr& csr, std::string& err) {
-    return smm::adopt_csr(n_src, n_dst, rowptr, col, val, csr, err);
-  }, dst_dims, dst_rank, layout);
 }
 
 int smm_operator_destroy(smm_operator_t op) {
@@ -912,27 +869,16 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   const size_t n = (size_t)op->csr.n_dst;
   // upload the new vectors first: on failure the operator keeps its old state untouched
-  uint8_t *new_imask = nullptr, *new_imask_rows = nullptr;
-  double *new_frac = nullptr, *new_frac_rows = nullptr;
+  uint8_t* new_imask = nullptr;
+  double* new_frac = nullptr;
   auto drop_new = [&]() {
     (void)hipFree(new_imask);
-    (void)hipFree(new_imask_rows);
     (void)hipFree(new_frac);
-    (void)hipFree(new_frac_rows);
   };
-  const std::vector<int32_t>& row_of = op->slots.row_of_slot;   // patch order: kernels index by slot
   if (dst_imask) {
     std::vector<uint8_t> m(n);
     for (size_t i = 0; i < n; ++i) m[i] = dst_imask[i] != 0;  // .astype(bool), regrid.py:557
-    int rc = SMM_OK;
-    if (op->use_slots) {
-      std::vector<uint8_t> ms(row_of.size(), 1);
-      for (size_t k = 0; k < row_of.size(); ++k)
-        if (row_of[k] >= 0) ms[k] = m[(size_t)row_of[k]];
-      if (!(rc = upload(&new_imask, ms))) rc = upload(&new_imask_rows, m);
-    } else {
-      rc = upload(&new_imask, m);
-    }
+    int rc = upload(&new_imask, m);
     if (rc) {
       drop_new();
       return rc;
@@ -940,15 +886,7 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
   }
   if (dst_frac) {
     std::vector<double> f(dst_frac, dst_frac + n);
-    int rc = SMM_OK;
-    if (op->use_slots) {
-      std::vector<double> fs(row_of.size(), 1.0);
-      for (size_t k = 0; k < row_of.size(); ++k)
-        if (row_of[k] >= 0) fs[k] = f[(size_t)row_of[k]];
-      if (!(rc = upload(&new_frac, fs))) rc = upload(&new_frac_rows, f);
-    } else {
-      rc = upload(&new_frac, f);
-    }
+    int rc = upload(&new_frac, f);
     if (rc) {
       drop_new();
       return rc;
@@ -967,10 +905,6 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
   }
   (void)hipFree(old_imask);
   (void)hipFree(old_frac);
-  (void)hipFree(op->d_imask_rows);
-  (void)hipFree(op->d_frac_rows);
-  op->d_imask_rows = new_imask_rows;
-  op->d_frac_rows = new_frac_rows;
   return SMM_OK;
 }
 
@@ -979,8 +913,7 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   const smm_operator::TilePlan& pl = op->plan[op->native_plan()];
   if (kernel_kind)
-    *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0) | (op->use_slots ? 4 : 0) |
-                   (shape_rows(op->native_plan()) << 8);
+    *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0) | (shape_rows(op->native_plan()) << 8);
   if (lds_bytes) *lds_bytes = pl.valid ? pl.max_chunks * kChunkElems * 8 : 0;
   if (staged_src_elems) *staged_src_elems = pl.valid ? pl.total_chunks * kChunkElems : 0;
   return SMM_OK;
@@ -999,7 +932,7 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   const int pw = op->native_plan();
   const smm_operator::TilePlan& pl = op->plan[pw];
-  return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->kcsr().n_dst, pw, pl.valid,
+  return run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid,
                    pl.preferred, (pl.reuse ? 1 : 0), pl.max_chunks, op->csr.max_row_nnz, x, x_dtype, ldx, 0, 0, y, y_dtype, ldy,
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
@@ -1048,8 +981,8 @@ int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, voi
   a.rowptr = op->d_csr_rowptr;
   a.col = (flags & SMM_APPLY_SB_PACKED) ? op->d_csr_colp : op->d_csr_col;
   a.val = op->d_csr_val;
-  a.imask = op->use_slots ? op->d_imask_rows : op->d_imask;   // kernel C indexes by destination cell
-  a.frac = op->use_slots ? op->d_frac_rows : op->d_frac;
+  a.imask = op->d_imask;
+  a.frac = op->d_frac;
   a.x = x;
   a.y = y;
   a.ldx = ldx;
@@ -1092,27 +1025,23 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
   // uses a quarter) do not ship the whole field over PCIe: the staging copy packs the used cells of a
   // chunk batch-fastest (host_pack) and the chunk runs through the batch-fastest kernel.  Same bits.
   const int64_t U = op->csr.n_used_src;
-  const bool pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
-                    U > 0 && U * 2 <= S && n_batch >= 32;
+  const bool may_pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
+                        U > 0 && U * 2 <= S;
+  // Chunk size from the X AND Y bytes of a row (an operator with few used cells and a large target
+  // is bound by its Y staging), clamped to a quarter of the free device memory: smm_internal.h
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    free_b = 0;
+  }
+  const smm::HostChunk hc = smm::host_chunk_units(n_batch, xrow_d, (size_t)D * ysz, may_pack ? (size_t)U * xsz : 0,
+                                                  32, 128, chunk_rows, free_b);
+  const bool pack = hc.pack;
+  chunk_rows = hc.units;
   if (pack) {
     int prc = ensure_sb(op);
     if (prc) return prc;
-    if (chunk_rows <= 0) {   // ~256 MiB of packed cells per chunk, whole 128-entry batch tiles
-      chunk_rows = (int64_t)((256u << 20) / std::max<size_t>((size_t)U * xsz, 1)) / 128 * 128;
-      chunk_rows = std::max<int64_t>(128, chunk_rows);
-    }
   }
-  if (chunk_rows <= 0) {
-    chunk_rows = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(xrow_d, 1)));
-    chunk_rows = std::min(chunk_rows, n_batch);
-    const size_t need = 2 * (size_t)chunk_rows * (xrow_d + (size_t)D * ysz);
-    size_t free_b = 0, total_b = 0;
-    if (need > ((size_t)2 << 30) && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      const int64_t fit = (int64_t)(free_b / 4 / (xrow_d + (size_t)D * ysz + 1));
-      chunk_rows = std::max<int64_t>(1, std::min(chunk_rows, fit));
-    }
-  }
-  chunk_rows = std::min(chunk_rows, n_batch);
   const bool x_pinned = is_pinned(x_host), y_pinned = is_pinned(y_host);
   // a pinned source with the device pitch can be DMA'd row-block-wise without staging
   const bool x_direct = x_pinned && !pack, y_direct = y_pinned;
@@ -1152,7 +1081,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
       int rc = drain(c - 2);  // buffer b is free again once chunk c-2 has been delivered
       if (rc) return rc;
     }
-    if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (SMM_TEST_FAIL_AT_CHUNK)");
+    if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (smm_debug_fail_at_chunk)");
     const char* xsrc = (const char*)x_host + (size_t)r0 * xrow;
     if (pack) {
       host_pack(pipe.hx[b], xsrc, xsz, ldx, op->h_used, rows);
@@ -1177,7 +1106,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
       rc = smm_apply_sb(op, pipe.dx[b], x_dtype, rows, pipe.dy[b], y_dtype, D, rows, remap_area_min,
                         (flags & (SMM_APPLY_MASKED | SMM_APPLY_NO_FILL)) | SMM_APPLY_SB_PACKED, pipe.stream[b]);
     else
-      rc = run_apply(op->d_desc, nullptr, nullptr, S, op->kcsr().n_dst, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
+      rc = run_apply(op->d_desc, nullptr, nullptr, S, op->csr.n_dst, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
                      pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
                      ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
                      pipe.stream[b]);
@@ -1229,7 +1158,7 @@ int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t
     cleanup();
     return fail(SMM_ERR_HIP, "hipMemcpy failed in smm_operator_mask_apply");
   }
-  rc = run_apply(op->d_desc, nullptr, nullptr, S, op->kcsr().n_dst, 0, false, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
+  rc = run_apply(op->d_desc, nullptr, nullptr, S, op->csr.n_dst, 0, false, false, false, 0, op->csr.max_row_nnz, dx, SMM_F64,
                  std::max<int64_t>(S, 1), 0, 0, dy, SMM_F64, D, 0, 0, 1, 1, 1, 0.0,
                  SMM_APPLY_NO_FILL, nullptr);
   if (rc == SMM_OK) {
@@ -1256,10 +1185,6 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
     if (ops[i]->device != ops[0]->device || ops[i]->csr.n_src != ops[0]->csr.n_src ||
         ops[i]->csr.n_dst != ops[0]->csr.n_dst)
       return fail(SMM_ERR_INVALID, "group members must share device and grid sizes");
-    // one launch covers all levels: one destination slot order for all members
-    if (ops[i]->use_slots != ops[0]->use_slots || ops[i]->kcsr().n_dst != ops[0]->kcsr().n_dst)
-      return fail(SMM_ERR_INVALID, "group members must share the destination layout: create them with the same "
-                                   "SMM_LAYOUT_* (smm_operator_create_grid)");
   }
   smm_group* g = new (std::nothrow) smm_group();
   if (!g) return fail(SMM_ERR_ALLOC, "out of host memory");
@@ -1402,11 +1327,32 @@ int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer,
   int rc = group_level_cfg(g, n_lev, level_index, masked_levels, remap_area_min, flags, &d_map, &d_masked);
   if (rc || n_lev == 0) return rc;
   const smm_operator* op0 = g->ops[0];
-  return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->kcsr().n_dst, g->tile_which,
+  return run_apply(g->d_descs, d_map, d_masked, op0->csr.n_src, op0->csr.n_dst, g->tile_which,
                    g->tile_valid, g->tile_preferred, (g->tile_reuse ? 1 : 0), g->tile_max_chunks, g->max_row_nnz, x, x_dtype, xs_outer, xs_lev, xs_inner, y,
                    y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, remap_area_min,
                    flags, (hipStream_t)stream);
 }
+
+extern "C++" {
+// What smm_apply_sb would reject for one of the selected levels, checked for all of them up front.
+static int check_sb_levels(smm_group_t g, int64_t n_lev, const int32_t* level_index, const uint8_t* masked_levels,
+                           double remap_area_min, unsigned flags) {
+  if (!(remap_area_min >= 0.0 && remap_area_min <= 1.0))
+    return fail(SMM_ERR_INVALID, "remap_area_min must be within [0, 1]");  // regrid.py:124-125
+  const int n_ops = (int)g->ops.size();
+  for (int64_t l = 0; l < n_lev; ++l) {
+    const int32_t w = level_index[l];
+    if (w < 0 || w >= n_ops)
+      return fail(SMM_ERR_INVALID, "level_index[" + std::to_string(l) + "]=" + std::to_string(w) + " outside the group");
+    const smm_operator* op = g->ops[(size_t)w];
+    const bool m = (flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w]);
+    if (m && !op->d_imask) return fail(SMM_ERR_INVALID, "masked apply requested but a level has no dst_imask");
+    if (remap_area_min > 0.0 && !op->d_frac)
+      return fail(SMM_ERR_INVALID, "remap_area_min > 0 requested but a level has no dst_frac");
+  }
+  return SMM_OK;
+}
+}  // extern "C++"
 
 int smm_group_prepare_sb(smm_group_t g) {
   if (!g) return fail(SMM_ERR_INVALID, "null group");
@@ -1442,6 +1388,16 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
   if (n_lev == 0 || n_batch == 0 || g->ops[0]->csr.n_dst == 0) return SMM_OK;
   if (!x || !y) return fail(SMM_ERR_INVALID, "null field pointer");
   const size_t xsz = x_dtype == SMM_F64 ? 8 : 4, ysz = y_dtype == SMM_F64 ? 8 : 4;
+  // the whole call is validated before the first launch (as smm_group_apply does): a later level's
+  // missing dst_imask / dst_frac or a bad stride must not surface after earlier levels wrote part of Y
+  if (ldx < n_batch) return fail(SMM_ERR_INVALID, "ldx smaller than the batch");
+  if (ys_batch < g->ops[0]->csr.n_dst)
+    return fail(SMM_ERR_INVALID, "ys_batch smaller than the destination grid");
+  if ((uintptr_t)x % xsz || (uintptr_t)y % ysz) return fail(SMM_ERR_INVALID, "field pointer is not element aligned");
+  {
+    int vrc = check_sb_levels(g, n_lev, level_index, masked_levels, remap_area_min, flags);
+    if (vrc) return vrc;
+  }
   for (int64_t l = 0; l < n_lev; ++l) {
     const int w = level_index[l];
     unsigned fl = flags & ~(unsigned)SMM_APPLY_MASKED;
@@ -1474,7 +1430,7 @@ int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, un
   const int pw = op->native_plan();
   const smm_operator::TilePlan& pl = op->plan[pw];
   LaunchInfo li;
-  int rc = run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->kcsr().n_dst, pw, pl.valid, pl.preferred,
+  int rc = run_apply(op->d_desc, nullptr, nullptr, op->csr.n_src, op->csr.n_dst, pw, pl.valid, pl.preferred,
                      (pl.reuse ? 1 : 0), pl.max_chunks, op->csr.max_row_nnz, nullptr, x_dtype, op->csr.n_src, 0, 0,
                      nullptr, SMM_F64, op->csr.n_dst, 0, 0, n_batch, 1, 1, 0.0, flags, nullptr, &li);
   if (rc) return rc;
@@ -1488,7 +1444,7 @@ int smm_group_launch_info(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   const smm_operator* op0 = g->ops[0];
   LaunchInfo li;
-  int rc = run_apply(g->d_descs, nullptr, nullptr, op0->csr.n_src, op0->kcsr().n_dst, g->tile_which, g->tile_valid,
+  int rc = run_apply(g->d_descs, nullptr, nullptr, op0->csr.n_src, op0->csr.n_dst, g->tile_which, g->tile_valid,
                      g->tile_preferred, (g->tile_reuse ? 1 : 0), g->tile_max_chunks, g->max_row_nnz, nullptr,
                      x_dtype, 0, 0, 0, nullptr, SMM_F64, 0, 0, 0, n_outer, n_lev, n_inner, 0.0, flags, nullptr, &li);
   if (rc) return rc;
@@ -1536,27 +1492,27 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
   // (config 3: 39 M used cells per time step) the whole-row pipeline stays (measured there: packing with
   // one time step per chunk ran 4x slower than whole rows).
   const int64_t min_outer = (32 + n_inner - 1) / n_inner;
-  bool pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
-              used_total > 0 && used_total * 2 <= n_lev * S && n_outer >= min_outer &&
-              (size_t)used_total * n_inner * min_outer * xsz <= ((size_t)1 << 30) &&
-              (chunk_outer <= 0 || chunk_outer >= min_outer || chunk_outer >= n_outer);
+  const bool may_pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
+                        used_total > 0 && used_total * 2 <= n_lev * S;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    free_b = 0;
+  }
+  // X and Y bytes per outer index size the chunk (smm_internal.h host_chunk_units, as in smm_apply_host)
+  const smm::HostChunk hc = smm::host_chunk_units(n_outer, x_outer_d, y_outer,
+                                                  may_pack ? (size_t)used_total * n_inner * xsz : 0, min_outer, 1,
+                                                  chunk_outer, free_b);
+  const bool pack = hc.pack;
+  chunk_outer = hc.units;
   if (pack) {
+    // every selected level is checked before the first launch (as smm_group_apply does): a level that
+    // lacks dst_imask / dst_frac must not surface after earlier levels have written part of Y
+    int vrc = check_sb_levels(g, n_lev, level_index, masked_levels, remap_area_min, flags);
+    if (vrc) return vrc;
     int prc = smm_group_prepare_sb(g);
     if (prc) return prc;
-    if (chunk_outer <= 0) {   // ~256 MiB of packed cells per chunk, at least 32 batch entries per level
-      chunk_outer = (int64_t)((256u << 20) / std::max<size_t>((size_t)used_total * n_inner * xsz, 1));
-      chunk_outer = std::max<int64_t>(min_outer, chunk_outer);
-    }
   }
-  if (chunk_outer <= 0) {
-    chunk_outer = std::max<int64_t>(1, (int64_t)((256u << 20) / std::max<size_t>(x_outer_d, 1)));
-    chunk_outer = std::min(chunk_outer, n_outer);
-    size_t free_b = 0, total_b = 0;
-    if (2 * (size_t)chunk_outer * (x_outer_d + y_outer) > ((size_t)2 << 30) &&
-        hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      chunk_outer = std::max<int64_t>(1, std::min<int64_t>(chunk_outer, (int64_t)(free_b / 4 / (x_outer_d + y_outer + 1))));
-  }
-  chunk_outer = std::min(chunk_outer, n_outer);
   const bool x_direct = is_pinned(x_host) && !pack, y_direct = is_pinned(y_host);
 
   std::lock_guard<std::mutex> pipe_lock(g->pipe_mu);
@@ -1594,7 +1550,7 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
       int rc = drain(c - 2);
       if (rc) return rc;
     }
-    if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (SMM_TEST_FAIL_AT_CHUNK)");
+    if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (smm_debug_fail_at_chunk)");
     const char* xsrc = (const char*)x_host + (size_t)o0 * rows_per_outer * S * xsz;
     int64_t ys_o, ys_l, ys_i;
     if (transpose) {

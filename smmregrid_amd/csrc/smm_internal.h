@@ -35,22 +35,6 @@ struct HostSell {
   std::vector<double> val;          // n_slots (padding: 0.0)
 };
 
-// Destination slot order.  The device structures (SELL slices, tile-plan blocks) are built over
-// "slots": by default slot == destination row; for a 2-D destination grid whose rows are heavy the
-// slots follow PATCHES of `patch_rows` grid rows x 64 grid columns, one grid row of a patch per SELL
-// slice (= wavefront), so that the `patch_rows` waves of a workgroup share ONE staged source tile
-// whose halo -- the source rows between vertically adjacent destination rows -- is fetched once
-// instead of once per wave.  Patches at the grid's right / upper edge are padded with empty slots
-// (row_of_slot == -1).
-struct SlotMap {
-  bool identity = true;
-  int64_t n_slots = 0;
-  std::vector<int32_t> row_of_slot;   // [n_slots] destination row, or -1
-};
-void build_patch_slots(int64_t nx, int64_t ny, int patch_rows, SlotMap& out);
-// CSR whose row s is row row_of_slot[s] of `csr` (empty for padding slots); n_dst = n_slots.
-void permute_csr(const HostCsr& csr, const SlotMap& slots, HostCsr& out);
-
 // Returns false and fills err on invalid input.
 bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
                const int32_t* dst1, const double* w, HostCsr& out, std::string& err);
@@ -98,5 +82,24 @@ struct HostTilePlan {
 int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_budget);
 void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_block,
                      int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan);
+
+// Chunk sizing of the host-buffer pipelines (smm_apply_host / smm_group_apply_host).  A chunk's X
+// AND Y staging are each allocated twice on the device and twice as pinned host memory, so a chunk
+// is sized from the bytes one batch unit (a row; an outer index of a level group) needs on both
+// sides -- an operator with few used source cells and a large target (U << D) is bound by its Y.
+struct HostChunk {
+  int64_t units = 0;   // batch rows (or outer indices) per chunk, >= 1
+  bool pack = false;   // the packing variant is in force for this call
+};
+// x_unit / y_unit: device bytes per unit of the whole-row form; xp_unit: packed X bytes per unit
+// (0 = packing not applicable).  min_pack_units: fewest units per chunk that still feed the pack loops
+// and the batch-fastest kernel (32 batch entries); pack_align: packed chunks are whole multiples of
+// this when they are at least that long (the kernel's 128-entry batch tile).  requested > 0 = the
+// caller's chunk size (kept; packing is dropped if it is below min_pack_units and does not cover
+// the batch).  free_bytes = free device memory (0 = unknown): a chunk never asks for more than a
+// quarter of it across its four device buffers.
+HostChunk host_chunk_units(int64_t n_units, size_t x_unit, size_t y_unit, size_t xp_unit,
+                           int64_t min_pack_units, int64_t pack_align, int64_t requested,
+                           size_t free_bytes);
 
 }  // namespace smm

@@ -37,9 +37,6 @@ struct LevelDesc {
   const int32_t* chunk_src;      // source chunk index per staged chunk
   const int32_t* lcol;           // SELL slots (LDS element index)
   const uint8_t* blk_direct;     // [n_blocks] 1 = block not staged, links gathered from X directly
-  // Destination slot order (null = identity): the arrays above are indexed by SLOT; row_of[slot] is the
-  // destination cell the slot's result is stored to, -1 for a padding slot (smm_internal.h SlotMap).
-  const int32_t* row_of;
 };
 
 struct ApplyArgs {
@@ -212,16 +209,13 @@ __global__ __launch_bounds__(kThreads) void smm_apply_sell_kernel(ApplyArgs a, b
   }
 
   if (d < a.n_dst) {
-    const int64_t dy = L.row_of ? (int64_t)L.row_of[d] : d;   // slot -> destination cell (-1: padding slot)
     const bool use_mask = a.masked && (a.lev_masked ? a.lev_masked[di] != 0 : true);
     bool dead = false;
     if (use_mask && L.imask) dead = (L.imask[d] == 0);
     if (a.area_min > 0.0 && L.frac) dead = dead || (L.frac[d] < a.area_min);
-    if (dy >= 0) {
 #pragma unroll
-      for (int t = 0; t < BT; ++t) {
-        if (j0 + t < a.n_j) yr[t][dy] = (YT)epilogue(acc[t], dead);
-      }
+    for (int t = 0; t < BT; ++t) {
+      if (j0 + t < a.n_j) yr[t][d] = (YT)epilogue(acc[t], dead);
     }
   }
 }
@@ -260,12 +254,9 @@ constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPer
 // registers; per batch row the G = 1 << sub_shift lane groups run one after the other, each starting
 // from the sum its predecessor handed over (a shuffle), so every row is still accumulated link by
 // link in ascending source order -- bit-identical -- while no link is re-read from L2.
-// WPB_ = 4 with MAXK 32 / 48: heavy rows in 4-wave workgroups -- the four waves of a 4 x 64 destination
-// patch (slot order, LevelDesc::row_of) share one staged tile, so the source rows between vertically
-// adjacent destination rows are fetched once per workgroup instead of once per wave.
-template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SPLIT = false, int WPB_ = 0>
-__global__ __launch_bounds__((WPB_ ? WPB_ : tile_waves(MAXK)) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
-  constexpr int WPB = WPB_ ? WPB_ : tile_waves(MAXK);
+template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SPLIT = false>
+__global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
+  constexpr int WPB = tile_waves(MAXK);
   constexpr int T = WPB * 64;
   // Where the 1e20 fill happens: rows of more than 16 links test the staging pieces on their way into
   // LDS (a 48-link row would test 48 gathered values per batch row, its ~15 pieces hold 30); short
@@ -306,11 +297,10 @@ __global__ __launch_bounds__((WPB_ ? WPB_ : tile_waves(MAXK)) * 64, 2) void smm_
   // lane of the slice whose row this lane works on
   const int rowlane = SPLIT ? (sub << (6 - a.sub_shift)) + (lane & ((64 >> a.sub_shift) - 1)) : lane;
   const bool in_blk = SPLIT || WPB != 1 || grp == sub;
-  const int64_t d = slice * 64 + rowlane;      // slot
-  // the destination cell the slot's result goes to (identity unless the operator uses patch order)
-  const int64_t dy = (L.row_of && d < a.n_dst) ? (int64_t)L.row_of[d] : d;
+  const int64_t d = slice * 64 + rowlane;      // destination cell
+  const int64_t dy = d;
   // SPLIT: the last lane group ends up with the rows' sums and stores them
-  const bool row_live = in_blk && d < a.n_dst && dy >= 0 && (!SPLIT || grp == n_grp - 1);
+  const bool row_live = in_blk && d < a.n_dst && (!SPLIT || grp == n_grp - 1);
   const bool slice_live = slice * 64 < a.n_dst;
 
   // MAXK > 0: the row's links live in registers across batch rows (LDS byte offsets are
@@ -425,8 +415,8 @@ __global__ __launch_bounds__((WPB_ ? WPB_ : tile_waves(MAXK)) * 64, 2) void smm_
     if (slice_live) {
       // this path is row-per-lane; in a SPLIT kernel the lanes of group `sub` take their own rows
       const int64_t dd = SPLIT ? slice * 64 + lane : d;
-      const int64_t ddy = SPLIT ? ((L.row_of && dd < a.n_dst) ? (int64_t)L.row_of[dd] : dd) : dy;
-      const bool dlive = SPLIT ? (grp == sub && dd < a.n_dst && ddy >= 0) : row_live;
+      const int64_t ddy = SPLIT ? dd : dy;
+      const bool dlive = SPLIT ? (grp == sub && dd < a.n_dst) : row_live;
       int dlen = len, dmax = wmax;
       bool ddead = dead;
       if (SPLIT) {

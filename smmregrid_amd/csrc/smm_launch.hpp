@@ -135,12 +135,6 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
     if constexpr (MAXK == 32 || MAXK == 48) {
-      if (!tile_which) {   // heavy rows in 4-wave workgroups (destination patches): one shared tile per 256 slots
-        hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, false, 4>),
-                           dim3((unsigned)total), dim3(kWavesPerBlock * 64), lds, s, args, fill);
-        SMM_LAUNCH_HIP(hipGetLastError());
-        return SMM_OK;
-      }
       if (split) {
         hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, true>),
                            dim3((unsigned)total), dim3(64), lds, s, args, fill);
@@ -154,13 +148,13 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
     }
     return go3(k_tag, np_tag, nt_tag, std::integral_constant<int, 1>());
   };
-  auto with_k = [&](auto fn) -> int {  // plan shape 0 <-> 4 waves (MAXK <= 16, or 32 / 48 on destination patches), shape 1.. <-> 1 wave
+  auto with_k = [&](auto fn) -> int {  // plan shape 0 <-> 4 waves (rows of <= 16 links), shape 1.. <-> 1 wave
     if (!tile_which) {
+      if (max_row_nnz > 16)
+        return smm::fail_msg(SMM_ERR_UNSUPPORTED, "4-wave tile blocks serve rows of at most 16 links");
       if (max_row_nnz <= 4) return fn(std::integral_constant<int, 4>());
       if (max_row_nnz <= 8) return fn(std::integral_constant<int, 8>());
-      if (max_row_nnz <= 16) return fn(std::integral_constant<int, 16>());
-      if (max_row_nnz <= 32) return fn(std::integral_constant<int, 32>());
-      return fn(std::integral_constant<int, 48>());   // shape 0 is only planned for rows of <= 48 links
+      return fn(std::integral_constant<int, 16>());
     }
     if (variant == 14) return fn(std::integral_constant<int, 0>());  // tuning: stream the links
     if (split) return per_grp <= 32 ? fn(std::integral_constant<int, 32>()) : fn(std::integral_constant<int, 48>());
@@ -170,22 +164,17 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   };
   if (np_needed > 16)
     return smm::fail_msg(SMM_ERR_UNSUPPORTED, "tile plan exceeds the staging register budget");
-  // variant 0: X loads non-temporal only if no staged line is shared between blocks
-  // (tile_reuse false), Y stores always non-temporal; 2: none; 3: both; 4: stores; 5: loads
+  // Y stores are always non-temporal; X loads are non-temporal only if no staged line is shared between
+  // blocks (tile_reuse false).  Tuning variants 3 / 4 force non-temporal / cached X loads.  (Cached Y
+  // stores -- the former variants 2 and 5 -- measured flat or worse everywhere and are no longer built.)
   const bool tile_reuse = tile_flags & 1;
   int nt = tile_reuse ? 2 : 3;
-  if (variant == 2) nt = 0;
   if (variant == 3) nt = 3;
   if (variant == 4) nt = 2;
-  if (variant == 5) nt = 1;
   return with_k([&](auto k_tag) -> int {
     auto with_nt = [&](auto np_tag) -> int {
-      switch (nt) {
-        case 0: return go2(k_tag, np_tag, std::integral_constant<int, 0>());
-        case 1: return go2(k_tag, np_tag, std::integral_constant<int, 1>());
-        case 2: return go2(k_tag, np_tag, std::integral_constant<int, 2>());
-        default: return go2(k_tag, np_tag, std::integral_constant<int, 3>());
-      }
+      if (nt == 2) return go2(k_tag, np_tag, std::integral_constant<int, 2>());
+      return go2(k_tag, np_tag, std::integral_constant<int, 3>());
     };
     if (np_needed <= 4) return with_nt(std::integral_constant<int, 4>());
     if (np_needed <= 8) return with_nt(std::integral_constant<int, 8>());

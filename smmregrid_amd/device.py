@@ -134,6 +134,13 @@ class DeviceArray:
     def ndim(self):
         return len(self.shape)
 
+    @property
+    def __cuda_array_interface__(self):
+        """Zero-copy hand-over to array libraries that speak the protocol (``torch.as_tensor``,
+        cupy, numba): the buffer stays owned by this DeviceArray."""
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr), False),
+                "version": 2, "strides": None}
+
     def reshape(self, *shape):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])

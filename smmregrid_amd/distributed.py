@@ -5,11 +5,23 @@ read-only weights (regrid.py:529-541, :550), so ranks take contiguous blocks of
 the row axis, each rank holds its own copy of the operator, and there is no
 collective on the data path except the optional gather of the output shards.
 
-One process per GPU, launched with ``torch.distributed.run``; the process group
-is plumbing only (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" in
-CPU tests).  The compute itself is injected as ``apply_fn`` so that CPU tests
-can drive the sharding logic with the oracle while the product path passes the
-HIP operator.
+One process per GPU.  This module is sharding arithmetic plus the gather
+schedules over an INJECTED communicator object; it imports neither torch nor
+the HIP library.  The product communicator is `smmregrid_amd.comm.Comm` (RCCL
+over xGMI behind the C ABI: shards are `DeviceArray`s and never leave HBM
+before the collective); tests inject a gloo adapter (`tests/gloo_comm.py`) and
+the CPU oracle as the per-rank compute.
+
+Communicator interface (duck-typed):
+
+    comm.rank, comm.world
+    comm.alloc(shape, dtype)               -> array of the communicator's kind
+    comm.alloc_slot(shard, rows)           -> receive buffer for `rows` rows of every rank
+    comm.rows(arr, r0, r1)                 -> view of rows [r0, r1)
+    comm.to_host(arr)                      -> numpy array
+    comm.gather(shard, root, out=None)     -> (world, *shard.shape) array on root, None elsewhere
+    comm.allgather(shard, out=None)        -> (world, *shard.shape) array
+    comm.gather_rows(shard, r0, r1, slot, root) -> work, with work.wait() -> per-rank views (root) / None
 """
 import numpy as np
 
@@ -29,49 +41,42 @@ def shard_sizes(n_rows, world_size):
             for r in range(world_size)]
 
 
-def regrid_sharded(x_rows, apply_fn, n_dst, group=None, gather="root", root=0):
-    """Regrid a host array of batch rows (B, S) with the rows split over the ranks of
-    `group`.  Every rank passes the same full `x_rows` (or at least its own block
-    of it) and gets back
+def regrid_sharded(x_rows, apply_fn, n_dst, comm, gather="root", root=0, dtype=np.float64):
+    """Regrid batch rows (B, S) with the rows split over the ranks of `comm`.  Every rank
+    passes the same full `x_rows` (or at least its own block of it) and gets back
 
-      gather="root": the assembled (B, n_dst) array on `root`, None elsewhere;
+      gather="root": the assembled (B, n_dst) numpy array on `root`, None elsewhere;
       gather="all" : the assembled array on every rank;
-      gather="none": its own (rows, n_dst) shard.
+      gather="none": its own (rows, n_dst) shard, as the communicator's array kind.
 
-    `apply_fn(rows_2d) -> (rows, n_dst) float64 ndarray` is the per-rank compute.
+    `apply_fn(rows_2d, out)` is the per-rank compute: it regrids `rows_2d` (this rank's block of
+    `x_rows`) INTO `out`, a (rows, n_dst) view of a buffer of the communicator's kind -- for the
+    product communicator a `DeviceArray`, so the shard is produced in HBM, travels device to
+    device, and only the assembled result is copied to the host (once, on the receiving ranks).
     """
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    if gather not in ("root", "all", "none"):
+        raise ValueError("gather must be 'root', 'all' or 'none'")
+    world, rank = comm.world, comm.rank
     n_rows = x_rows.shape[0]
     lo, hi = shard_bounds(n_rows, world, rank)
-    mine = np.ascontiguousarray(apply_fn(x_rows[lo:hi]), dtype=np.float64).reshape(hi - lo, n_dst)
-    if gather == "none":
-        return mine
-
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    per = -(-n_rows // world)
-    pad = torch.zeros((per, n_dst), dtype=torch.float64, device=dev)   # equal-sized shards for the collective
+    per = -(-n_rows // world)                     # equal-sized shards for the collective
+    pad = comm.alloc((max(per, 1), n_dst), dtype)
     if hi > lo:
-        pad[:hi - lo] = torch.from_numpy(mine).to(dev)
+        apply_fn(x_rows[lo:hi], comm.rows(pad, 0, hi - lo))
+    if gather == "none":
+        return comm.rows(pad, 0, hi - lo)
     if gather == "all":
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-    elif gather == "root":
-        parts = [torch.empty_like(pad) for _ in range(world)] if rank == root else None
-        dist.gather(pad, parts, dst=root, group=group)
+        parts = comm.allgather(pad)
+    else:
+        parts = comm.gather(pad, root)
         if rank != root:
             return None
-    else:
-        raise ValueError("gather must be 'root', 'all' or 'none'")
-    out = np.empty((n_rows, n_dst), dtype=np.float64)
-    for r, part in enumerate(parts):
+    host = comm.to_host(parts).reshape(world, max(per, 1), n_dst)
+    out = np.empty((n_rows, n_dst), dtype=dtype)
+    for r in range(world):
         a, b = shard_bounds(n_rows, world, r)
         if b > a:
-            out[a:b] = part[:b - a].cpu().numpy()
+            out[a:b] = host[r, :b - a]
     return out
 
 
@@ -88,39 +93,35 @@ def tile_bounds(n_rows, tiles):
 class TiledRingGather:
     """Gather of every rank's Y shard to `root`, tiled and overlapped with the compute.
 
-    The shard (a torch tensor, rows first) is cut into row tiles; `gather_tile(k)` starts the
-    asynchronous gather of tile k -- on the GPU box it travels over RCCL/xGMI while the kernel of
-    tile k + 1 runs.  The root receives into a RING of `slots` tile buffers per rank, not into one
-    buffer of the full size: the gathered Y of all ranks never has to fit on one GPU (BASELINE
-    config 5: 211 GB).  A ring slot is reused only after the gather that last filled it has
-    completed AND the consumer has drained it (`on_tile(k, parts)` is called on the root with the
-    per-rank views of tile k exactly once, in tile order).
-
-    Works with any torch.distributed backend (nccl == RCCL on the GPU box, gloo in CPU tests).
+    The shard (rows first, the communicator's array kind) is cut into row tiles; `gather_tile(k)`
+    starts the asynchronous gather of tile k -- on the GPU box it travels over RCCL/xGMI on the
+    communication stream while the kernel of tile k + 1 runs.  The root receives into a RING of
+    `slots` tile buffers, not into one buffer of the full size: the gathered Y of all ranks never
+    has to fit on one GPU (BASELINE config 5: 211 GB).  A ring slot is reused only after the gather
+    that last filled it has completed AND the consumer has drained it (`on_tile(k, parts)` is
+    called on the root with the per-rank views of tile k exactly once, in tile order).
     """
 
-    def __init__(self, dist, torch, shard, root=0, tiles=8, slots=2, group=None, on_tile=None):
-        self.dist, self.torch, self.group = dist, torch, group
-        self.shard, self.root, self.slots = shard, int(root), int(slots)
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+    def __init__(self, comm, shard, root=0, tiles=8, slots=2, on_tile=None):
+        self.comm, self.shard, self.root, self.slots = comm, shard, int(root), int(slots)
+        self.rank, self.world = comm.rank, comm.world
         self.tiles = tile_bounds(shard.shape[0], tiles)
         self.on_tile = on_tile
-        per = max((r1 - r0 for r0, r1 in self.tiles), default=0)
+        self.rows_per_slot = max((r1 - r0 for r0, r1 in self.tiles), default=0)
         self.ring = None
         if self.rank == self.root:
-            self.ring = [[torch.empty((per,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
-                          for _ in range(self.world)] for _ in range(self.slots)]
+            self.ring = [comm.alloc_slot(shard, self.rows_per_slot) for _ in range(self.slots)]
+        self.row_bytes = int(np.prod(shard.shape[1:], dtype=np.int64)) * np.dtype(shard_dtype(shard)).itemsize
         self.pending = []          # (tile index, work handle), oldest first
         self.gathered_bytes = 0    # bytes received by the root from OTHER ranks (with_gather accounting)
         self.delivered = 0         # tiles handed to on_tile
 
     def _retire(self):
         k, work = self.pending.pop(0)
-        work.wait()
+        parts = work.wait()
         if self.rank == self.root:
             r0, r1 = self.tiles[k]
-            parts = [buf[:r1 - r0] for buf in self.ring[k % self.slots]]
-            self.gathered_bytes += (self.world - 1) * parts[0].numel() * parts[0].element_size()
+            self.gathered_bytes += (self.world - 1) * (r1 - r0) * self.row_bytes
             if self.on_tile is not None:
                 self.on_tile(k, parts)
         self.delivered += 1
@@ -130,10 +131,19 @@ class TiledRingGather:
         r0, r1 = self.tiles[k]
         while len(self.pending) >= self.slots:      # the slot about to be reused must be drained
             self._retire()
-        recv = [buf[:r1 - r0] for buf in self.ring[k % self.slots]] if self.rank == self.root else None
-        work = self.dist.gather(self.shard[r0:r1], recv, dst=self.root, group=self.group, async_op=True)
-        self.pending.append((k, work))
+        slot = self.ring[k % self.slots] if self.rank == self.root else None
+        self.pending.append((k, self.comm.gather_rows(self.shard, r0, r1, slot, self.root)))
 
     def finish(self):
         while self.pending:
             self._retire()
+
+
+def shard_dtype(shard):
+    """numpy dtype of an array of any communicator's kind (DeviceArray / numpy: .dtype; torch
+    tensors carry a torch dtype whose itemsize is what the byte accounting needs)."""
+    dt = shard.dtype
+    try:
+        return np.dtype(dt)
+    except TypeError:
+        return np.dtype(f"V{shard.element_size()}")

@@ -17,23 +17,6 @@ def _cptr(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
 
-_LAYOUTS = {"auto": _lib.LAYOUT_AUTO, "rows": _lib.LAYOUT_ROWS, "patches": _lib.LAYOUT_PATCHES}
-
-
-def _grid_args(dst_dims, layout):
-    if layout not in _LAYOUTS:
-        raise ValueError(f"layout must be one of {sorted(_LAYOUTS)}")
-    import os
-    if layout == "auto" and os.environ.get("SMM_LAYOUT") in ("rows", "patches") and dst_dims is not None:
-        layout = os.environ["SMM_LAYOUT"]          # A/B runs of the two destination layouts (bench.py)
-    if dst_dims is None:
-        if layout == "patches":
-            raise ValueError("layout='patches' needs dst_dims")
-        return None, 0, _LAYOUTS[layout]
-    dims = np.ascontiguousarray(dst_dims, dtype=np.int32).ravel()
-    return dims, int(dims.size), _LAYOUTS[layout]
-
-
 def _launch_info(fn, handle, dt, sizes, flags):
     ints = [ctypes.c_int(0) for _ in range(5)]
     nb, lds = ctypes.c_int64(0), ctypes.c_int64(0)
@@ -49,11 +32,9 @@ class SparseOperator:
     """(S x D) weights matrix in HBM, built from SCRIP links (weights.py:25-44)."""
 
     def __init__(self, n_src, n_dst, src_address, dst_address, remap_matrix, device=None, dst_dims=None,
-                 layout="auto", prune_zeros=False):
+                 prune_zeros=False):
         """dst_dims: shape of the destination grid as the weights file gives it (`dst_grid_dims`,
-        fastest dimension first); with it the library may lay the device structures out in 4 x 64
-        patches of a 2-D target grid (`layout`: "auto" | "rows" | "patches", smm_operator_create_grid).
-        Results do not depend on the layout; the members of an OperatorGroup must share one.
+        fastest dimension first); kept as metadata (save / load).
         prune_zeros: drop links whose weight is exactly zero (bilinear weights between aligned grids are
         mostly zeros); results stay bit-identical because every gathered value is finite after the fill."""
         src = np.ascontiguousarray(src_address, dtype=np.int32).ravel()
@@ -68,12 +49,9 @@ class SparseOperator:
             device = current_device()
         self.device = int(device)
         h = ctypes.c_void_p()
-        dims, rank, lay = _grid_args(dst_dims, layout)
-        if prune_zeros:
-            lay |= _lib.CREATE_PRUNE_ZEROS
-        _lib.call("smm_operator_create_grid", int(n_src), int(n_dst), int(src.size), _cptr(src),
-                  _cptr(dst), _cptr(w), _cptr(dims), rank, lay, self.device, ctypes.byref(h))
-        self.dst_dims = None if dims is None else tuple(int(v) for v in dims)
+        _lib.call("smm_operator_create_opt", int(n_src), int(n_dst), int(src.size), _cptr(src),
+                  _cptr(dst), _cptr(w), _lib.CREATE_PRUNE_ZEROS if prune_zeros else 0, self.device, ctypes.byref(h))
+        self.dst_dims = None if dst_dims is None else tuple(int(v) for v in np.asarray(dst_dims).ravel())
         self._adopt(h)
 
     def _adopt(self, handle):
@@ -85,7 +63,7 @@ class SparseOperator:
         self.has_frac = False
 
     @classmethod
-    def from_csr(cls, n_src, n_dst, rowptr, col, val, device=None, dst_dims=None, layout="auto"):
+    def from_csr(cls, n_src, n_dst, rowptr, col, val, device=None, dst_dims=None):
         """Operator from a canonical CSR (what export_csr returned): no sort, no duplicate pass.
         A non-canonical CSR (unsorted or repeated columns, bad rowptr) is a ValueError."""
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64).ravel()
@@ -98,11 +76,10 @@ class SparseOperator:
         self = cls.__new__(cls)
         self.device = int(current_device() if device is None else device)
         h = ctypes.c_void_p()
-        dims, rank, lay = _grid_args(dst_dims, layout)
-        self.dst_dims = None if dims is None else tuple(int(v) for v in dims)
+        self.dst_dims = None if dst_dims is None else tuple(int(v) for v in np.asarray(dst_dims).ravel())
         try:
-            _lib.call("smm_operator_create_csr_grid", int(n_src), int(n_dst), _cptr(rowptr), _cptr(col),
-                      _cptr(val), _cptr(dims), rank, lay, self.device, ctypes.byref(h))
+            _lib.call("smm_operator_create_csr", int(n_src), int(n_dst), _cptr(rowptr), _cptr(col),
+                      _cptr(val), self.device, ctypes.byref(h))
         except _lib.SmmError as e:
             if e.code == _lib.SMM_ERR_INVALID:
                 raise ValueError(str(e)) from None
@@ -168,7 +145,7 @@ class SparseOperator:
         _lib.call("smm_operator_plan_info", self.handle, ctypes.byref(kind), ctypes.byref(lds),
                   ctypes.byref(staged))
         return {"tile_plan": bool(kind.value & 1), "tile_preferred": bool(kind.value & 2),
-                "dst_patches": bool(kind.value & 4), "lds_bytes": lds.value, "staged_src_elems": staged.value,
+                "lds_bytes": lds.value, "staged_src_elems": staged.value,
                 "rows_per_block": kind.value >> 8}
 
     def launch_info(self, n_batch, dtype=np.float64, flags=0):

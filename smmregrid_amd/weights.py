@@ -27,7 +27,7 @@ def _dst_dims(weights):
     return np.asarray(weights["dst_grid_dims"].values).astype(np.int32).ravel()
 
 
-def compute_weights_matrix(weights, device=None, layout="auto", prune_zeros=False):
+def compute_weights_matrix(weights, device=None, prune_zeros=False):
     """CDO weights -> one operator of shape (S, D)   (weights.py:25-44)."""
     weights = from_xarray(weights)
     src_address = weights["src_address"].values
@@ -38,10 +38,10 @@ def compute_weights_matrix(weights, device=None, layout="auto", prune_zeros=Fals
     n_src = weights.sizes["src_grid_size"]
     n_dst = weights.sizes["dst_grid_size"]
     return SparseOperator(n_src, n_dst, src_address, dst_address, remap_matrix, device=device,
-                          dst_dims=_dst_dims(weights), layout=layout, prune_zeros=prune_zeros)
+                          dst_dims=_dst_dims(weights), prune_zeros=prune_zeros)
 
 
-def compute_weights_matrix3d(weights, mask_dim="lev", device=None, layout="auto", prune_zeros=False):
+def compute_weights_matrix3d(weights, mask_dim="lev", device=None, prune_zeros=False):
     """Per-level operators; links truncated to link_length[level]   (weights.py:7-23)."""
     weights = from_xarray(weights)
     link_length = np.asarray(weights["link_length"].values).astype(np.int64)
@@ -55,9 +55,8 @@ def compute_weights_matrix3d(weights, mask_dim="lev", device=None, layout="auto"
         rm = _level_slice(weights["remap_matrix"], mask_dim, i)[:nl]
         if rm.ndim == 2:
             rm = rm[:, 0]
-        # one grouped launch covers all levels: they share one destination layout
         sparse_weights.append(SparseOperator(n_src, n_dst, src, dst, rm, device=device, dst_dims=dims,
-                                             layout=layout, prune_zeros=prune_zeros))
+                                             prune_zeros=prune_zeros))
     return sparse_weights
 
 

@@ -1,6 +1,6 @@
 /* Plain-C consumer of the C ABI (include/smmregrid_amd.h): builds an operator from SCRIP
  * links, regrids a device-resident batch, the same batch through the host pipeline, a two-level
- * group, the batch-fastest entry and a patch-order operator, and checks them against a scalar loop.  Compiled with gcc (no HIP headers):
+ * group, the batch-fastest entry and a zero-pruned operator fed through a pitched upload, and checks them against a scalar loop.  Compiled with gcc (no HIP headers):
  *   gcc -std=c99 -I include tests/cpp/abi_smoke.c -o abi_smoke smmregrid_amd/libsmmregrid_hip.so -lm */
 #include <math.h>
 #include <stdio.h>
@@ -70,8 +70,8 @@ int main(void) {
   int32_t level_index[1] = {1};
   CHECK(smm_group_apply_host(grp, x, SMM_F64, yg, SMM_F64, B, 1, 1, 1, level_index, NULL, 0.0, 0, 0));
 
-  /* the batch-fastest entry: X transposed to (S, B), Y still (B, D); and an operator created with the
-   * shape of its target grid in patch order (30 x 20 = D) -- both must give the same bits */
+  /* the batch-fastest entry: X transposed to (S, B), Y still (B, D); and an operator created with
+   * SMM_CREATE_PRUNE_ZEROS fed through a pitched upload (rows on 128-B lines) -- both must give the same bits */
   static double xt[S * B], ysb[B * D], yp[B * D];
   for (int b = 0; b < B; ++b)
     for (int s = 0; s < S; ++s) xt[s * B + b] = x[b * S + s];
@@ -80,15 +80,19 @@ int main(void) {
   CHECK(smm_memcpy_h2d(dxt, xt, sizeof xt, NULL));
   CHECK(smm_apply_sb(op, dxt, SMM_F64, B, dy, SMM_F64, D, B, 0.0, 0, NULL));
   CHECK(smm_memcpy_d2h(ysb, dy, sizeof ysb, NULL));
-  const int32_t dims[2] = {30, 20};
   smm_operator_t opp = NULL;
-  CHECK(smm_operator_create_grid(S, D, NNZ, src, dst, w, dims, 2, SMM_LAYOUT_PATCHES, 0, &opp));
+  CHECK(smm_operator_create_opt(S, D, NNZ, src, dst, w, SMM_CREATE_PRUNE_ZEROS, 0, &opp));
   int kind = 0;
   CHECK(smm_operator_plan_info(opp, &kind, NULL, NULL));
-  CHECK(smm_apply(opp, dx, SMM_F64, S, dy, SMM_F64, D, B, 0.0, 0, NULL));
-  CHECK(smm_memcpy_d2h(yp, dy, sizeof yp, NULL));
+  const size_t pitch = ((size_t)S * 8 + 127) / 128 * 128;      /* device rows on 128-B lines */
+  void* dxp = NULL;
+  CHECK(smm_malloc(&dxp, pitch * B));
+  CHECK(smm_memcpy2d_h2d(dxp, pitch, x, (size_t)S * 8, (size_t)S * 8, B, NULL));
+  CHECK(smm_apply(opp, dxp, SMM_F64, (int64_t)(pitch / 8), dy, SMM_F64, D, B, 0.0, 0, NULL));
+  CHECK(smm_memcpy2d_d2h(yp, (size_t)D * 8, dy, (size_t)D * 8, (size_t)D * 8, B, NULL));
+  CHECK(smm_free(dxp));
 
-  int bad = (kind & 4) ? 0 : 1;
+  int bad = 0;
   for (int i = 0; i < B * D; ++i) {
     const int same = (isnan(ref[i]) && isnan(y[i]) && isnan(yh[i]) && isnan(yg[i]) && isnan(ysb[i]) && isnan(yp[i])) ||
                      (ref[i] == y[i] && ref[i] == yh[i] && ref[i] == yg[i] && ref[i] == ysb[i] && ref[i] == yp[i]);

@@ -131,43 +131,35 @@ int main() {
     }
     printf("ADOPTBAD %lld\n", abad);
   }
-  // destination patches: slot order of a 2-D grid (the largest nx <= sqrt(n_dst) dividing n_dst), the
-  // permuted CSR keeps every row's links, padding slots are empty, SELL / tile plan build on it
+  // chunk sizing of the host pipelines (smm_apply_host / smm_group_apply_host): Y counts too
   {
-    long long sbad = 0;
-    int64_t nx = 1;
-    for (int64_t f = 1; f * f <= csr.n_dst; ++f)
-      if (csr.n_dst % f == 0) nx = f;
-    const int64_t ny = csr.n_dst / nx;
-    smm::SlotMap map;
-    smm::build_patch_slots(nx, ny, 4, map);
-    if (map.identity || map.n_slots % 256 != 0 || (int64_t)map.row_of_slot.size() != map.n_slots) ++sbad;
-    std::vector<int> seen((size_t)csr.n_dst, 0);
-    smm::HostCsr pc;
-    smm::permute_csr(csr, map, pc);
-    if (pc.n_dst != map.n_slots || pc.nnz != csr.nnz || pc.rowptr.back() != csr.nnz) ++sbad;
-    for (int64_t sl = 0; sl < map.n_slots; ++sl) {
-      const int32_t r = map.row_of_slot[(size_t)sl];
-      const int64_t a = pc.rowptr[(size_t)sl], b = pc.rowptr[(size_t)sl + 1];
-      if (r < 0) {
-        if (a != b) ++sbad;
-        continue;
-      }
-      if (r >= csr.n_dst || seen[(size_t)r]++) { ++sbad; continue; }
-      const int64_t a0 = csr.rowptr[(size_t)r], b0 = csr.rowptr[(size_t)r + 1];
-      if (b - a != b0 - a0) { ++sbad; continue; }
-      for (int64_t k = 0; k < b - a; ++k)
-        if (pc.col[(size_t)(a + k)] != csr.col[(size_t)(a0 + k)] || pc.val[(size_t)(a + k)] != csr.val[(size_t)(a0 + k)]) ++sbad;
-    }
-    for (int64_t d = 0; d < csr.n_dst; ++d)
-      if (seen[(size_t)d] != 1) ++sbad;
-    smm::HostSell ps;
-    smm::build_sell(pc, ps);
-    smm::HostTilePlan pp;
-    smm::build_tile_plan(pc, ps, 256, 16, 512, pp);
-    smm::tighten_tile_plan(pc, pp, 512);
-    if (ps.n_slices * 64 != map.n_slots) ++sbad;
-    printf("SLOTBAD %lld\n", sbad);
+    long long cbad = 0;
+    const size_t GiB = (size_t)1 << 30, MiB = (size_t)1 << 20;
+    // config 2: 3600 rows, S = 1 038 240 f64 rows on 128-B lines, D = 64 800, U = 259 200
+    smm::HostChunk c = smm::host_chunk_units(3600, 8305920, 518400, 2073600, 32, 128, 0, 200 * GiB);
+    if (!c.pack || c.units % 128 != 0 || c.units < 128 || (size_t)c.units * (2073600 + 518400) > 512 * MiB) ++cbad;
+    // U << D: 64 used source cells feeding a 12.6-M-cell target (a regional subset onto HEALPix): the
+    // chunk is bound by its Y bytes, not by the packed X
+    c = smm::host_chunk_units(4096, 40000 * 8, (size_t)12582912 * 8, 64 * 8, 32, 128, 0, 200 * GiB);
+    if (c.units < 1 || (size_t)c.units * ((size_t)12582912 * 8 + 64 * 8) > GiB) ++cbad;
+    if (c.pack && c.units < 32) ++cbad;
+    // the same with little free memory: four buffers stay within a quarter of it
+    c = smm::host_chunk_units(4096, 40000 * 8, (size_t)12582912 * 8, 64 * 8, 32, 128, 0, 4 * GiB);
+    if (c.units < 1 || 4 * (size_t)c.units * ((c.pack ? 64 * 8 : 40000 * 8) + (size_t)12582912 * 8) > 4 * GiB + 4 * ((size_t)12582912 * 8)) ++cbad;
+    if (c.pack && c.units < 32) ++cbad;
+    // short batches never pack; a requested chunk size is kept
+    c = smm::host_chunk_units(16, 8000, 800, 2000, 32, 128, 0, 0);
+    if (c.pack || c.units != 16) ++cbad;
+    c = smm::host_chunk_units(1000, 8000, 800, 2000, 32, 128, 100, 0);
+    if (!c.pack || c.units != 100) ++cbad;
+    c = smm::host_chunk_units(1000, 8000, 800, 2000, 32, 128, 7, 0);
+    if (c.pack || c.units != 7) ++cbad;
+    c = smm::host_chunk_units(1000, 8000, 800, 0, 32, 128, 0, 0);
+    if (c.pack || c.units != 1000) ++cbad;
+    // a level group whose 32 batch entries of all levels exceed 1 GiB of staging keeps whole rows
+    c = smm::host_chunk_units(120, (size_t)75 * 11778304, (size_t)75 * 518400, (size_t)39000000 * 8, 32, 1, 0, 200 * GiB);
+    if (c.pack || c.units < 1) ++cbad;
+    printf("CHUNKBAD %lld\n", cbad);
   }
   // exact-zero links dropped: what is left is the same matrix without its zeros
   {

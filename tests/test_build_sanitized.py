@@ -83,7 +83,7 @@ def test_builder_under_sanitizers(harness, rng, case):
         t4 = [t for t in tight if t[1] == "4"][0]
         assert int(t4[2]) == 64 and int(t4[3]) <= 34 and 1000 <= int(t4[4]) <= 1024   # budget 512 -> 64, one block direct
     assert "ADOPTBAD 0" in lines            # smm_operator_create_csr's validator (adopt_csr)
-    assert "SLOTBAD 0" in lines             # destination patches: slot map + permuted CSR + plans on it
+    assert "CHUNKBAD 0" in lines            # host pipelines size their chunks from X AND Y bytes (U << D)
     prune = [ln.split() for ln in lines if ln.startswith("PRUNEBAD")][0]
     assert prune[1] == "0" and int(prune[2]) == int((val == 0.0).sum())     # exact-zero links dropped, rest intact
 

@@ -169,28 +169,57 @@ def test_weights_npz_roundtrip_and_path_init(hip, rng, tmp_path):
     assert_same(b, a, exact=True)
 
 
-def test_sharded_regrid_single_rank_gloo(hip, rng):
-    """The N>1 host path with the HIP operator as per-rank compute (world of 1 here;
-    world_size 2 is covered on CPU in tests/test_distributed_cpu.py)."""
-    import torch.distributed as dist
-    from smmregrid_amd import SparseOperator
-    from smmregrid_amd.distributed import regrid_sharded
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("gloo", rank=0, world_size=1)
-    try:
-        w = gridgen.bilinear_weights("r96x48", "r36x18")
-        op = SparseOperator(96 * 48, 36 * 18, w["src_address"].values, w["dst_address"].values,
-                            w["remap_matrix"].values, device=0)
-        x = 250.0 + rng.standard_normal((9, 96 * 48))
-
-        def apply_fn(rows):
-            return op.apply(to_device(rows)).to_host()
-
-        out = regrid_sharded(x, apply_fn, 36 * 18, gather="root")
-        assert_same(out, oracle.apply_c(op.export_csr(), x), exact=True)
-    finally:
-        dist.destroy_process_group()
+def test_sharded_regrid_single_rank_native_comm(hip):
+    """The N>1 product path -- smmregrid_amd.distributed over the RCCL communicator of the C ABI, the
+    HIP operator as per-rank compute, shards produced in HBM and gathered device to device -- with a
+    world of one rank (one GPU here; world_size 2 is covered on CPU in tests/test_distributed_cpu.py
+    with a gloo adapter).  Also the tiled ring gather on real RCCL: every tile delivered once, in
+    order, bit-equal to the shard.  Fresh process: RCCL is bound at run time and torch (imported by
+    other tests of this session) bundles its own build."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np
+from oracle import oracle
+from smmregrid_amd import SparseOperator, gridgen, to_device
+from smmregrid_amd.comm import Comm
+from smmregrid_amd.device import DeviceArray, set_device, synchronize
+from smmregrid_amd.distributed import TiledRingGather, regrid_sharded
+set_device(0)
+comm = Comm(0, 1)
+rng = np.random.default_rng(20260723)
+w = gridgen.bilinear_weights("r96x48", "r36x18")
+op = SparseOperator(96 * 48, 36 * 18, w["src_address"].values, w["dst_address"].values,
+                    w["remap_matrix"].values, device=0)
+x = 250.0 + rng.standard_normal((9, 96 * 48))
+kinds = []
+def apply_fn(rows, out):
+    kinds.append(type(out).__name__)
+    op.apply(to_device(rows), y=out)
+ref = oracle.apply_c(op.export_csr(), x)
+for gather in ("root", "all"):
+    out = regrid_sharded(x, apply_fn, 36 * 18, comm, gather=gather)
+    assert np.array_equal(out, ref), gather
+mine = regrid_sharded(x, apply_fn, 36 * 18, comm, gather="none")
+assert isinstance(mine, DeviceArray) and np.array_equal(mine.to_host(), ref)
+assert kinds == ["DeviceArray"] * 3            # the shard is produced in HBM
+y = op.apply(to_device(x))
+seen = []
+def on_tile(k, parts):
+    r0, r1 = ring.tiles[k]
+    assert len(parts) == 1 and np.array_equal(parts[0].to_host(), ref[r0:r1])
+    seen.append(k)
+ring = TiledRingGather(comm, y, root=0, tiles=4, slots=2, on_tile=on_tile)
+for step in range(2):
+    for k in range(len(ring.tiles)):
+        ring.gather_tile(k)
+    ring.finish()
+assert seen == list(range(len(ring.tiles))) * 2 and ring.gathered_bytes == 0
+synchronize(); comm.close(); print("sharded-native-ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "sharded-native-ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_check_nan_auto_mask_dim(hip, rng):

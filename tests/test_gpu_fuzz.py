@@ -49,13 +49,7 @@ def test_fuzz_2d(hip, seed):
     n_dst = int(rng.integers(1, 1500))
     kind = ["random", "ragged", "banded"][seed % 3]
     src, dst, w = make_links(rng, kind, n_src, n_dst)
-    # every third case lays the destination out in 4 x 64 patches of a 2-D grid (nx * ny == n_dst)
-    dims, layout = None, "auto"
-    if seed % 3 == 1:
-        nx = next(f for f in range(int(np.sqrt(n_dst)) + 1, 0, -1) if n_dst % f == 0)
-        dims, layout = [n_dst // nx, nx] if seed % 2 else [nx, n_dst // nx], "patches"
-    op = SparseOperator(n_src, n_dst, src, dst, w, device=0, dst_dims=dims, layout=layout)
-    assert op.plan_info()["dst_patches"] == (layout == "patches")
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
     csr = op.export_csr()
     ref_csr = oracle.coo_to_csr(n_src, n_dst, src, dst, w)
     assert np.array_equal(csr[0], ref_csr[0]) and np.array_equal(csr[1], ref_csr[1])
@@ -126,13 +120,9 @@ def test_fuzz_levels(hip, seed):
     ops, csrs = [], []
     imask = (rng.random((n_ops, n_dst)) > 0.3).astype(np.int32)
     frac = rng.random((n_ops, n_dst))
-    dims, layout = None, "auto"
-    if seed % 2:                                             # all levels in patch order
-        nx = next(f for f in range(int(np.sqrt(n_dst)) + 1, 0, -1) if n_dst % f == 0)
-        dims, layout = [n_dst // nx, nx], "patches"
     for i in range(n_ops):
         src, dst, w = make_links(rng, ["random", "ragged", "banded"][(seed + i) % 3], n_src, n_dst)
-        op = SparseOperator(n_src, n_dst, src, dst, w, device=0, dst_dims=dims, layout=layout)
+        op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
         op.set_epilogue(imask[i], frac[i])
         ops.append(op)
         csrs.append(op.export_csr())

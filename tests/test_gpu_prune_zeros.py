@@ -47,14 +47,13 @@ def test_pruning_random_links_with_explicit_and_summed_zeros(hip, rng):
     dst = np.concatenate([dst, [5, 5]]).astype(np.int32)
     w = np.concatenate([w, [0.25, -0.25]])
     full = SparseOperator(n_src, n_dst, src, dst, w, device=0)
-    pruned = SparseOperator(n_src, n_dst, src, dst, w, device=0, prune_zeros=True, dst_dims=[20, 20],
-                            layout="patches")
+    pruned = SparseOperator(n_src, n_dst, src, dst, w, device=0, prune_zeros=True, dst_dims=[20, 20])
     assert pruned.nnz < full.nnz and (pruned.export_csr()[2] != 0.0).all()
     x = field(rng, 33, n_src, nan_frac=0.05, inf_frac=0.01)
     assert_same(pruned.apply(to_device(x)).to_host(), oracle.apply_c(full.export_csr(), x), exact=True)
     with pytest.raises(_lib.SmmError):                          # unknown option bits are refused
         h = __import__("ctypes").c_void_p()
-        _lib.call("smm_operator_create_grid", n_src, n_dst, 0, None, None, None, None, 0, 1 << 12, 0,
+        _lib.call("smm_operator_create_opt", n_src, n_dst, 0, None, None, None, 1 << 12, 0,
                   __import__("ctypes").byref(h))
 
 

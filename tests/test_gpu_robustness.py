@@ -152,13 +152,13 @@ def test_host_pipeline_error_drains_in_flight_copies(hip, rng, pinned):
         out = pinned_empty((B, D), np.float64)
         out[...] = -1.0
     fail_at = 3
-    os.environ["SMM_TEST_FAIL_AT_CHUNK"] = str(fail_at)
+    _lib.call("smm_debug_fail_at_chunk", fail_at)      # explicit test hook, not an environment variable
     try:
         with pytest.raises(_lib.SmmError) as e:
             op.apply_host(xin, out=out, chunk_rows=chunk)
         assert "injected failure" in str(e.value)
     finally:
-        del os.environ["SMM_TEST_FAIL_AT_CHUNK"]
+        _lib.call("smm_debug_fail_at_chunk", -1)
     # direct DMA (pinned): chunks 0..c-1 were enqueued and must all have landed before the return;
     # staged copies are delivered by drain(), which had handled chunks 0..c-2 when chunk c failed
     done = fail_at * chunk if pinned else (fail_at - 1) * chunk

@@ -17,11 +17,7 @@ for seed in range(n):
     if kind == "longband":
         n_src, n_dst = int(rng.integers(5000, 200000)), int(rng.integers(1, 900))
     src, dst, w = make_links(rng, kind, n_src, n_dst)
-    dims, layout = None, "auto"
-    if seed % 5 == 2:          # destination patches of a 2-D grid with nx * ny == n_dst
-        nx = next(f for f in range(int(np.sqrt(n_dst)) + 1, 0, -1) if n_dst % f == 0)
-        dims, layout = [n_dst // nx, nx], "patches"
-    op = SparseOperator(n_src, n_dst, src, dst, w, device=0, dst_dims=dims, layout=layout)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0, prune_zeros=(seed % 5 == 2))
     csr = op.export_csr()
     imask = (rng.random(n_dst) > 0.3).astype(np.int32); frac = rng.random(n_dst)
     op.set_epilogue(imask, frac)
