@@ -13,22 +13,34 @@ cfg2sb / cfg2sbp (config 2 with the field kept batch-fastest, X (S, B) or packed
 cfg4 / cfg5 (one GPU's share of BASELINE configs 4 / 5: with --gpus 8 these are the
 fixed-total-batch lines of BASELINE.json).
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-regrids its own full-size shard of the time axis (weak scaling; batch rows are
-independent) and the Y shards stay resident on their GPUs: `value`
-is that job (no data-path collective).  A second timed loop in the same run adds
-the RCCL gather of the Y shards to rank 0 after every step and is reported as
-`with_gather` beside it (xGMI-link bound; --gather none skips it).
+For N > 1 there is one rank per GPU: either the caller started them (torch.distributed.run /
+any launcher that exports RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT), or -- when
+`--gpus N` is given and WORLD_SIZE is not set -- this process starts N rank processes itself,
+before touching any GPU, relays rank 0's JSON line and exits non-zero if any rank does.  Every rank
+regrids its own full-size shard of the time axis (weak scaling; batch rows are independent,
+SURVEY 8e) and the Y shards stay resident on their GPUs: `value` is that job (no data-path
+collective; barriers and the max over ranks go through a host-side TCP rendezvous).  A second timed
+loop in the same run adds the RCCL gather of the Y shards to rank 0 after every step and is
+reported as `with_gather` beside it (xGMI-link bound; --gather none skips it).  The plumbing of that
+gather is the library's own RCCL communicator (--comm native, default: no torch in the process) or
+torch.distributed (--comm torch).  `n_gpus` is the number of ranks that really joined.
 
 Rank 0 prints ONE JSON line: the driver's contract plus `roofline` (HBM bound;
-algorithmic bytes of SURVEY 8d over the live HIP-event kernel time) and
-`cpu_baseline` (the CPU oracle -- a port of the reference's step sequence --
-timed on this host's cores over a bounded sample of the same workload).
+algorithmic bytes of SURVEY 8d over the live HIP-event kernel time), `cpu_baseline`
+(the CPU oracle -- a port of the reference's step sequence -- timed on this host's cores
+over a bounded sample of the same workload) and, for the default workload at N = 1,
+`others`: the secondary workloads (config 2 with the field kept batch-fastest, BASELINE config 3
+packed and on 128-B lines, config-4 geometry) timed in the same run, each with kernel time,
+algorithmic bytes, roofline fraction, replayed PMC traffic and a bit-equality spot check
+of its timed output against the CPU oracle.
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -98,8 +110,19 @@ def parse_args():
                     help="N>1: also time the steps followed by the RCCL gather of the Y shards to rank 0")
     ap.add_argument("--gather-tiles", type=int, default=8,
                     help="row tiles of the overlapped gather (tile k travels while tile k+1 is computed)")
-    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
-                    help="N>1 plumbing: torch.distributed (nccl == RCCL) or the library's smm_comm_* (no torch)")
+    ap.add_argument("--comm", default="native", choices=["native", "torch"],
+                    help="N>1 gather plumbing: the library's smm_comm_* over RCCL (no torch in the process) "
+                         "or torch.distributed (nccl == RCCL; gloo with --dry-run)")
+    ap.add_argument("--gather-timeout", type=float, default=300.0,
+                    help="seconds the gather phase may take before the line is printed without it")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, no kernel: a stand-in step exercises launcher, rendezvous, barriers, "
+                         "max over ranks and the JSON line (CPU tests of the N>1 path)")
+    ap.add_argument("--others", default="default",
+                    help="secondary workloads timed after the headline at N=1 (comma list, 'default' or 'none')")
+    ap.add_argument("--others-steps", type=int, default=10)
+    ap.add_argument("--others-budget", type=float, default=240.0,
+                    help="seconds after which remaining secondary workloads are skipped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -189,6 +212,44 @@ class Problem2D:
             self.op.apply_sb(self.x, y=y, masked=False, remap_area_min=0.5, packed=self.layout == "sbp",
                              flags=flags)
 
+    def spot_check(self, y, max_dst=65536):
+        """One batch row of the timed output against oracle/oracle.c (bit equality; NaN positions
+        identical).  The oracle builds its own CSR from the links (restricted to the first
+        `max_dst` destination cells for the 50-M-link operator)."""
+        from oracle import oracle
+        from smmregrid_amd import _lib
+        import ctypes
+        r = self.n_batch // 2
+        isz = np.dtype(self.np_dt).itemsize
+        if self.layout == "bs":
+            xrow = self.x.rows(r, r + 1).to_host().reshape(-1)[:self.n_src]
+        else:                                   # column r of the (S or U, B) field
+            n_rows = self.x.shape[0]
+            col = np.empty(n_rows, dtype=self.np_dt)
+            _lib.call("smm_memcpy2d_d2h", col.ctypes.data_as(ctypes.c_void_p), isz,
+                      ctypes.c_void_p(self.x.ptr + r * isz), self.n_batch * isz, isz, n_rows, None)
+            if self.layout == "sbp":
+                xrow = np.zeros(self.n_src, dtype=self.np_dt)
+                xrow[self.op.used_sources()] = col
+            else:
+                xrow = col
+        got = y.rows(r, r + 1).to_host().reshape(-1)
+        w = self.weights
+        n_chk = int(min(self.n_dst, max_dst))
+        dst = w["dst_address"].values
+        keep = slice(None) if n_chk == self.n_dst else (dst <= n_chk)
+        rm = w["remap_matrix"].values
+        csr = oracle.coo_to_csr_c(self.n_src, n_chk, w["src_address"].values[keep], dst[keep],
+                                  (rm[:, 0] if rm.ndim == 2 else rm)[keep])
+        ref = oracle.apply_c(csr, xrow[None, :], False, None, w["dst_grid_frac"].values[:n_chk], 0.5)[0]
+        got = got[:n_chk]
+        same = np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
+        return {"batch_row": int(r), "cells": n_chk, "bit_equal_to_oracle": bool(same)}
+
+    def free(self):
+        self.x.free()
+        self.op.close()
+
     def run_rows(self, y, flags, r0, r1):
         """The same product restricted to batch rows [r0, r1) (one tile of the overlapped gather)."""
         if self.layout == "bs":
@@ -207,7 +268,8 @@ class Problem2D:
         """The reference's step sequence (regrid.py:545-570) on this host's cores, over a bounded
         sample of the same workload (a block of distinct batch rows passed repeatedly).  Three legs
         (SURVEY 8d): numpy + scipy.sparse on one core, oracle/oracle.c with OpenMP on this GPU's CPU
-        share (16 threads) and on every core the process may use."""
+        share (16 threads) and on every core the process may really use (affinity capped by the
+        cgroup CPU quota; one leg when the two coincide)."""
         from oracle import oracle
         w = self.weights
         csr = oracle.coo_to_csr_c(self.n_src, self.n_dst, w["src_address"].values,
@@ -242,12 +304,12 @@ class Problem2D:
             oracle.apply_c(csr, x[:min(rows, nt)], False, None, frac, 0.5, threads=nt)  # warm the team
             v, p, t = timed(lambda: oracle.apply_c(csr, x, False, None, frac, 0.5, threads=nt), rows,
                             budget_s * 0.375)
-            # (more threads than the process's CPU quota -- a 16-CPU share of a 256-thread host on the
-            # GPU box -- oversubscribes: that leg reports what "all visible cores" really delivers here)
+            # ("every core the process may use" = affinity capped by the cgroup CPU quota: cpu_threads())
             legs.append({"value": v, "unit": "cells/s", "cores": nt, "kind": "port",
                          "impl": "oracle/oracle.c (OpenMP over batch rows)",
                          "sample": f"{rows} of {self.n_batch} batch rows x {p} passes, {nt} threads of "
-                                   f"{avail} visible (os.cpu_count() = {os.cpu_count()}), {t:.1f} s"})
+                                   f"{avail} usable (affinity capped by the cgroup quota; os.cpu_count() = "
+                                   f"{os.cpu_count()}), {t:.1f} s"})
         best = max(legs, key=lambda leg: leg["value"])
         return {"value": best["value"], "unit": "cells/s", "cores": best["cores"], "kind": "port",
                 "sample": best["impl"] + ": " + best["sample"], "legs": legs}
@@ -281,11 +343,28 @@ class ProblemLevels:
         slab = (10.0 + 5.0 * rng.standard_normal((n_lev, self.n_src), dtype=np.float32)).astype(np.float64)
         slab[masks == 0] = np.nan
         self.slab, self.masks = slab, masks
-        self.padded = len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "pad"
         self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "sb" else "bs"
-        ldx = -(-self.n_src // 16) * 16 if self.padded else self.n_src
+        self.nx, self.ny, self.tgrid = nx, ny, tgrid
+        self.y_shape = (self.n_t, 1, n_lev, self.n_dst)
+        self.np_dt = np.float64
+        nnz = sum(op.nnz for op in self.ops)
+        self.meta = {"S": self.n_src, "D": self.n_dst, "nnz_total": nnz, "levels": n_lev,
+                     "max_row_nnz": max(op.max_row_nnz for op in self.ops),
+                     "plan": self.ops[0].plan_info()}
+        self.x = None
+        self.set_layout(name, len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "pad")
+
+    def set_layout(self, name, padded):
+        """(Re)allocate the field: rows on 128-B lines (`cfg3`) or packed back to back (`cfg3c`)."""
         from smmregrid_amd import _lib
+        from smmregrid_amd.device import DeviceArray
         import ctypes
+        if self.x is not None:
+            self.x.free()
+        self.name, self.padded = name, bool(padded)
+        n_lev, slab = self.n_lev, self.slab
+        nx, ny, tgrid = self.nx, self.ny, self.tgrid
+        ldx = -(-self.n_src // 16) * 16 if self.padded else self.n_src
         if self.layout == "sb":
             # X (L, S, T): every time step carries the same slab, so a cell's T values are one constant
             self.x = DeviceArray((n_lev, self.n_src, self.n_t), np.float64)
@@ -299,16 +378,41 @@ class ProblemLevels:
             for t in range(1, self.n_t):
                 _lib.call("smm_memcpy_d2d", ctypes.c_void_p(self.x.rows(t, t + 1).ptr),
                           ctypes.c_void_p(self.x.ptr), first.nbytes, None)
-        self.y_shape = (self.n_t, 1, n_lev, self.n_dst)
-        self.np_dt = np.float64
-        nnz = sum(op.nnz for op in self.ops)
         self.desc = (f"{name}: {nx}x{ny} tripolar-like -> {tgrid} conservative, {self.n_t} time steps x "
                      f"{n_lev} masked levels per GPU, f64, remap_area_min 0.5, grouped launch, "
                      + ("X (L, S, T) batch-fastest per level" if self.layout == "sb" else
                         "X (T, L, S) " + (f"with rows on 128-B lines (pitch {ldx})" if self.padded else "packed")))
-        self.meta = {"S": self.n_src, "D": self.n_dst, "nnz_total": nnz, "levels": n_lev,
-                     "max_row_nnz": max(op.max_row_nnz for op in self.ops),
-                     "plan": self.ops[0].plan_info()}
+
+    def spot_check(self, y):
+        """One (time step, level) row of the timed output per probed level against oracle/oracle.c,
+        the oracle building its own CSR from that level's links."""
+        from oracle import oracle
+        w3 = self.weights
+        ll = w3["link_length"].values
+        frac = w3["dst_grid_frac"].values
+        t = self.n_t // 2
+        yv = y.reshape(self.n_t, self.n_lev, self.n_dst)
+        same, cells, levels = True, 0, []
+        for lv in sorted({0, self.n_lev // 2, self.n_lev - 1}):
+            n = int(ll[lv])
+            rm = w3["remap_matrix"].values[lv, :n]
+            csr = oracle.coo_to_csr_c(self.n_src, self.n_dst, w3["src_address"].values[lv, :n],
+                                      w3["dst_address"].values[lv, :n], rm[:, 0] if rm.ndim == 2 else rm)
+            ref = oracle.apply_c(csr, self.slab[lv][None, :], bool(self.masked_levels[lv]), self.dst_imask[lv],
+                                 frac[lv], 0.5)[0]
+            got = yv.rows(t, t + 1).to_host().reshape(self.n_lev, self.n_dst)[lv]
+            ok = ~np.isnan(ref)
+            same = same and np.array_equal(np.isnan(got), ~ok) and np.array_equal(got[ok], ref[ok])
+            cells += self.n_dst
+            levels.append(int(lv))
+        return {"time_step": int(t), "levels": levels, "cells": cells, "bit_equal_to_oracle": bool(same)}
+
+    def free(self):
+        if self.x is not None:
+            self.x.free()
+        self.group.close()
+        for op in self.ops:
+            op.close()
 
     def cells(self):
         return float(self.n_dst) * self.n_t * self.n_lev
@@ -374,117 +478,75 @@ class ProblemLevels:
             legs.append({"value": v, "unit": "cells/s", "cores": nt, "kind": "port",
                          "impl": "oracle/oracle.c level by level (OpenMP over rows)",
                          "sample": f"{t_rows} of {self.n_t} time steps x {self.n_lev} levels x {p} passes, "
-                                   f"{nt} threads of {avail} visible (os.cpu_count() = {os.cpu_count()}), {t:.1f} s"})
+                                   f"{nt} threads of {avail} usable (affinity capped by the cgroup quota; "
+                                   f"os.cpu_count() = {os.cpu_count()}), {t:.1f} s"})
         best = max(legs, key=lambda leg: leg["value"])
         return {"value": best["value"], "unit": "cells/s", "cores": best["cores"], "kind": "port",
                 "sample": best["impl"] + ": " + best["sample"], "legs": legs}
 
 
-class TorchDist:
-    """torch.distributed over RCCL; torch owns the Y buffers so the collective can move them."""
+class DryProblem:
+    """--dry-run: no GPU, no kernel.  A stand-in step (a small numpy product) so that the launcher,
+    the rendezvous, the barriers, the max over ranks, the tiled gather schedule (gloo with --comm
+    torch) and the JSON line of the N>1 path can be exercised on any host."""
 
-    def __init__(self, local_rank):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist, self.dev = torch, dist, f"cuda:{local_rank}"
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.y_t = self.parts = None
+    x_dtype = "f64"
 
-    def alloc_y(self, shape):
-        from smmregrid_amd.device import DeviceArray
-        self.y_t = self.torch.empty(shape, dtype=self.torch.float64, device=self.dev)
-        return DeviceArray(shape, np.float64, ptr=self.y_t.data_ptr())
+    def __init__(self, name, rank):
+        self.n_batch, self.n_dst, self.rank = 64, 96, rank
+        self.w = np.random.default_rng(7).standard_normal((32, self.n_dst))
+        self.x = np.random.default_rng(11 + rank).standard_normal((self.n_batch, 32))
+        self.y_shape = (self.n_batch, self.n_dst)
+        self.desc = f"dry run of {name}: stand-in step, no GPU"
+        self.meta = {"dry_run": True}
 
-    def prepare_gather(self, y, root=0, tiles=8):
-        """Tiled gather (smmregrid_amd.distributed.TiledRingGather): tile k is gathered (async, on
-        RCCL's own stream) while the kernel of tile k+1 runs; the root receives into a ring of two
-        tile buffers per rank, so the full Y of all ranks never has to fit on one GPU."""
-        from smmregrid_amd.distributed import TiledRingGather
-        self.root = root
-        self.ring = TiledRingGather(self.dist, self.torch, self.y_t, root=root, tiles=tiles, slots=2)
-        self.tiles = self.ring.tiles
+    def cells(self):
+        return float(self.n_batch * self.n_dst)
 
-    def gather_tile(self, k):
-        self.ring.gather_tile(k)
+    def alg_bytes(self):
+        return self.x.nbytes + self.n_batch * self.n_dst * 8
 
-    def finish_gather(self):
-        self.ring.finish()
+    def full_stream_bytes(self):
+        return self.alg_bytes()
 
-    def barrier(self):
-        self.dist.barrier()
-        self.torch.cuda.synchronize()
+    def line_bytes(self):
+        return None
 
-    def max(self, value):
-        t = self.torch.tensor([value], dtype=self.torch.float64, device=self.dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
+    def run(self, y, flags):
+        y[...] = self.x @ self.w
 
-    def close(self):
-        self.dist.destroy_process_group()
+    def run_rows(self, y, flags, r0, r1):
+        y[r0:r1] = self.x[r0:r1] @ self.w
 
 
-class NativeDist:
-    """The library's RCCL communicator (smm_comm_*): id exchange over TCP, no torch."""
+class HostEvent:
+    """Wall-clock stand-in for a HIP event (--dry-run)."""
 
-    def __init__(self, rank, world):
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_ms(self, stop):
+        return (stop.t - self.t) * 1e3
+
+
+def make_comm(args, rank, world, local_rank, rdv):
+    """The data-plane communicator of the gather phase (created AFTER the compute measurement, so a
+    failure here can never touch `value`)."""
+    if args.comm == "native":
+        if args.dry_run:
+            raise RuntimeError("--dry-run has no RCCL: use --comm torch (gloo) or --gather none")
         from smmregrid_amd.comm import Comm
-        from smmregrid_amd.device import DeviceArray
-        self.rank, self.world = rank, world
-        self.comm = Comm(rank, world)
-        self.scalar = DeviceArray((1,), np.float64)
-        self.scalars = DeviceArray((world, 1), np.float64)
-        self.y = self.out = None
-
-    def alloc_y(self, shape):
-        from smmregrid_amd.device import DeviceArray
-        self.y = DeviceArray(shape, np.float64)
-        return self.y
-
-    def prepare_gather(self, y, root=0, tiles=8):
-        """Same tiling; the collective runs on a communication stream that waits for an event
-        recorded behind each tile's kernel, so it overlaps the next tile's kernel."""
-        from smmregrid_amd.device import DeviceArray, Event, Stream
-        self.root = root
-        n = y.shape[0]
-        per = -(-n // max(1, min(tiles, n)))
-        self.tiles = [(r0, min(n, r0 + per)) for r0 in range(0, n, per)]
-        self.comm_stream = Stream()
-        self.events = [Event() for _ in self.tiles]
-        self.ring = None
-        if self.rank == root:
-            self.ring = [DeviceArray((self.world, per) + tuple(y.shape[1:]), np.float64) for _ in range(2)]
-
-    def gather_tile(self, k):
-        r0, r1 = self.tiles[k]
-        self.events[k].record()                    # behind the kernel of tile k (null stream)
-        self.comm_stream.wait_event(self.events[k])
-        shard = self.y.rows(r0, r1)
-        out = None
-        if self.rank == self.root:                 # gathers serialise on the comm stream: ring reuse is ordered
-            out = self.ring[k % 2].reshape(self.world * self.ring[k % 2].shape[1], -1)
-        import ctypes
-        from smmregrid_amd import _lib
-        _lib.call("smm_comm_gather", self.comm.handle, ctypes.c_void_p(shard.ptr),
-                  ctypes.c_void_p(out.ptr) if out is not None else None, shard.size, _lib.SMM_F64,
-                  int(self.root), self.comm_stream.handle)
-
-    def finish_gather(self):
-        self.comm_stream.synchronize()
-
-    def max(self, value):
-        from smmregrid_amd.device import synchronize
-        self.scalar.copy_from_host(np.array([value]))
-        self.comm.allgather(self.scalar, out=self.scalars)
-        synchronize()
-        return float(self.scalars.to_host().max())
-
-    def barrier(self):
-        self.max(0.0)
-
-    def close(self):
-        self.comm.close()
+        return Comm(rank, world, rendezvous=rdv), None
+    import torch
+    import torch.distributed as dist
+    from tools.torch_comm import TorchComm
+    if args.dry_run:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    return TorchComm(), dist
 
 
 def stream_copy_gbs(nbytes=2 << 30, reps=5):
@@ -520,49 +582,245 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def cgroup_cpu_quota():
+    """CPUs the cgroup's CFS quota grants this process (None = unlimited / unknown): the tightest
+    `cpu.max` (cgroup v2) or cfs_quota / cfs_period (v1) from the process's own cgroup up to the root."""
+    best = None
+
+    def take(q, period):
+        nonlocal best
+        try:
+            q, period = float(q), float(period)
+        except ValueError:
+            return
+        if q > 0 and period > 0:
+            best = q / period if best is None else min(best, q / period)
+
+    rel, rel_v1 = "", None
+    try:
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and parts[0] == "0":
+                rel = parts[2]                                   # cgroup v2
+            elif len(parts) == 3 and "cpu" in parts[1].split(","):
+                rel_v1 = parts[2]                                # cgroup v1 cpu controller
+    except OSError:
+        pass
+
+    def up(root, rel_path):
+        paths, cur = [root], rel_path.strip("/")
+        while cur:
+            paths.append(os.path.join(root, cur))
+            cur = os.path.dirname(cur)
+        return paths
+
+    for base in up("/sys/fs/cgroup", rel):
+        try:
+            q, period = open(os.path.join(base, "cpu.max")).read().split()[:2]
+            if q != "max":
+                take(q, period)
+        except (OSError, ValueError):
+            pass
+    for root in ("/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"):
+        for base in up(root, rel_v1 or ""):
+            try:
+                take(open(os.path.join(base, "cpu.cfs_quota_us")).read().strip(),
+                     open(os.path.join(base, "cpu.cfs_period_us")).read().strip())
+            except OSError:
+                pass
+    return best
+
+
 def cpu_threads():
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    return int(os.environ.get("SMM_CPU_THREADS", min(avail, 16))), avail  # 16 = one GPU's CPU share
+    """(threads of the share leg, threads of the all-cores leg): the cores this process may REALLY
+    use = scheduler affinity capped by the cgroup CPU quota (a 16-CPU share of a 256-thread host has
+    affinity 256 and a quota of 16: 256 OpenMP threads there only oversubscribe)."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    usable = affinity if quota is None else max(1, min(affinity, int(math.floor(quota + 0.5))))
+    return int(os.environ.get("SMM_CPU_THREADS", min(usable, 16))), usable  # 16 = one GPU's CPU share
+
+
+def launch_ranks(n_ranks):
+    """`--gpus N` without WORLD_SIZE: start N rank processes of this script (fresh interpreters, one
+    per GPU; this parent never initialises HIP), relay rank 0's stdout, exit non-zero if any rank
+    fails.  Ranks that are still running when one has failed are terminated by their own PIDs."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+
+    def relay():
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    rc = 0
+    alive = set(range(n_ranks))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in alive:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    th.join(timeout=5.0)
+    return rc
+
+
+def traffic_entry(args, workload, batch):
+    """PMC traffic cannot be collected inside this run (rocprofv3 counter passes are separate
+    processes): it is replayed from profiles/traffic.json, but only while the kernel sources
+    are the ones the PMC pass ran (sha recorded by tools/summarize_pmc.py); else null."""
+    if not (args.traffic_json and os.path.exists(args.traffic_json)):
+        return None, None
+    key = f"{workload}/{batch or 'default'}/{args.kernel}/{args.variant}"
+    entry = json.load(open(args.traffic_json)).get(key)
+    if not entry:
+        return None, None
+    now = kernel_source_sha()
+    fresh = entry.get("kernel_sha") == now
+    return (entry.get("hbm_bytes_per_launch") if fresh else None,
+            {"file": os.path.relpath(args.traffic_json, ROOT), "key": key, "summary": entry.get("source"),
+             "pmc_kernel_sha": entry.get("kernel_sha"), "pmc_git_head": entry.get("git_head"),
+             "current_kernel_sha": now, "fresh": fresh})
+
+
+def roofline_block(args, prob, k_avg, workload, batch, with_copy_rate=True):
+    b_alg = prob.alg_bytes()
+    achieved = b_alg / k_avg / 1e9
+    traffic, traffic_source = traffic_entry(args, workload, batch)
+    line = prob.line_bytes()
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+           "kernel_ms": k_avg * 1e3, "algorithmic_bytes": b_alg,
+           "full_stream_bytes": prob.full_stream_bytes(), "line_granular_bytes": line,
+           "line_granular_frac": (line / k_avg / 1e9 / HBM_PEAK_GBS) if line else None,
+           "traffic_GBs": (traffic / k_avg / 1e9) if traffic else None}
+    if with_copy_rate:
+        out["stream_copy_GBs"] = stream_copy_gbs()
+    return out
+
+
+OTHERS_DEFAULT = ["cfg2sb", "cfg3", "cfg3c", "cfg4s"]
+
+
+def run_others(args, names, local_rank, flags, t_start):
+    """Secondary workloads in the same run (N = 1): W warm-up launches, K launches timed with HIP
+    events on the launch stream, roofline accounting as for the headline, and a bit-equality spot
+    check of the timed output against the CPU oracle.  `cfg3` and `cfg3c` share their 75 operators
+    (only the field's row pitch differs)."""
+    from smmregrid_amd.device import DeviceArray, Event, synchronize
+    out, shared = {}, {}
+    for name in names:
+        if time.perf_counter() - t_start > args.others_budget:
+            out[name] = {"skipped": f"time budget of {args.others_budget:.0f} s used up"}
+            continue
+        t0 = time.perf_counter()
+        try:
+            levels = WORKLOADS[name][0] == "con3d"
+            if levels and "levels" in shared:
+                prob = shared["levels"]
+                prob.set_layout(name, len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "pad")
+            else:
+                prob = (ProblemLevels if levels else Problem2D)(name, local_rank, 0)
+                if levels:
+                    shared["levels"] = prob
+            y = DeviceArray(prob.y_shape, np.float64)
+            for _ in range(2):
+                prob.run(y, flags)
+            synchronize()
+            ev = [(Event(), Event()) for _ in range(args.others_steps)]
+            w0 = time.perf_counter()
+            for a, b in ev:
+                a.record()
+                prob.run(y, flags)
+                b.record()
+            synchronize()
+            wall = time.perf_counter() - w0
+            k_avg = float(np.mean([a.elapsed_ms(b) for a, b in ev])) * 1e-3
+            entry = {"workload": prob.desc, "steps": args.others_steps, "warmup": 2,
+                     "value": prob.cells() * args.others_steps / wall, "unit": "cells/s",
+                     "ms_per_step": wall / args.others_steps * 1e3, "dtype": prob.x_dtype}
+            entry.update(roofline_block(args, prob, k_avg, name, None, with_copy_rate=False))
+            entry["spot_check"] = prob.spot_check(y)
+            if not entry["spot_check"]["bit_equal_to_oracle"]:
+                raise SystemExit(f"bench.py: {name}: the timed output differs from the CPU oracle: "
+                                 f"{entry['spot_check']}")
+            y.free()
+            if not levels:
+                prob.free()
+            entry["setup_and_run_s"] = time.perf_counter() - t0
+            out[name] = entry
+        except SystemExit:
+            raise
+        except Exception as exc:   # one secondary workload must not lose the headline
+            out[name] = {"error": repr(exc)}
+    if "levels" in shared:
+        shared["levels"].free()
+    return out
 
 
 def main():
+    t_start = time.perf_counter()
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))      # this parent process never touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, the two must agree")
     use_dist = world > 1 or bool(os.environ.get("SMM_BENCH_FORCE_DIST"))  # rehearsal of the N>1 path on one GPU
-    if world > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run and os.environ.get("SMM_BENCH_TEST_FAIL_RANK") == str(rank):
+        raise SystemExit(7)                    # tests/test_bench_launch.py: a rank that dies early
 
-    from smmregrid_amd import _lib
-    from smmregrid_amd.device import DeviceArray, Event, device_name, set_device, synchronize
+    # control plane: host-side TCP rendezvous (barrier, max over ranks, RCCL id hand-over); no GPU involved
+    rdv = None
+    n_ranks = 1
+    if use_dist:
+        from smmregrid_amd.comm import HostRendezvous
+        rdv = HostRendezvous(rank, world)
+        n_ranks = len({int(p) for p in rdv.allgather(str(rank).encode())})   # ranks that really joined
 
-    # multi-process plumbing: torch.distributed (backend nccl == RCCL) by default, or the library's
-    # own RCCL communicator (--comm native: no torch in the process at all)
-    comm = None
-    if use_dist and args.comm == "torch":
-        comm = TorchDist(local_rank)
-    set_device(local_rank)
-    if use_dist and args.comm == "native":
-        comm = NativeDist(rank, world)
+    if args.dry_run:
+        prob = DryProblem(args.workload, rank)
+        y = np.zeros(prob.y_shape)
+        flags = 0
+        new_event, synchronize, dev_name = HostEvent, (lambda: None), "none (dry run)"
+    else:
+        from smmregrid_amd import _lib
+        from smmregrid_amd.device import DeviceArray, Event, device_name, set_device, synchronize
+        set_device(local_rank)
+        cls = ProblemLevels if WORKLOADS[args.workload][0] == "con3d" else Problem2D
+        prob = cls(args.workload, local_rank, rank, batch=args.batch)
+        y = DeviceArray(prob.y_shape, np.float64)
+        flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
+        flags |= (args.variant << 16) | (args.jpb << 20)
+        new_event, dev_name = Event, device_name(local_rank)
 
-    cls = ProblemLevels if WORKLOADS[args.workload][0] == "con3d" else Problem2D
-    prob = cls(args.workload, local_rank, rank, batch=args.batch)
-
-    y = comm.alloc_y(prob.y_shape) if comm else DeviceArray(prob.y_shape, np.float64)
-    if comm and args.gather == "root":
-        comm.prepare_gather(y, root=0, tiles=args.gather_tiles)
-
-    flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
-    flags |= (args.variant << 16) | (args.jpb << 20)
+    ring = None
 
     def step(events=None, gather=False):
         if gather:
-            # tile k's gather (RCCL stream) overlaps tile k+1's kernel (null stream)
-            for k, (r0, r1) in enumerate(comm.tiles):
+            # tile k's gather (communication stream) overlaps tile k+1's kernel (null stream)
+            for k, (r0, r1) in enumerate(ring.tiles):
                 prob.run_rows(y, flags, r0, r1)
-                comm.gather_tile(k)
-            comm.finish_gather()
+                ring.gather_tile(k)
+            ring.finish()
             return
         if events:
             events[0].record()
@@ -572,66 +830,40 @@ def main():
 
     def barrier():
         synchronize()
-        if comm:
-            comm.barrier()
+        if rdv:
+            rdv.barrier()
 
     def timed(gather):
         """W warm-up steps, then exactly K steps between barriers; MAX over ranks."""
         for _ in range(args.warmup):
             step(gather=gather)
         barrier()
-        ev = [(Event(), Event()) for _ in range(args.steps)]
+        ev = [(new_event(), new_event()) for _ in range(args.steps)]
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(ev[k], gather=gather)
         barrier()
         dt = time.perf_counter() - t0
-        if comm:
-            dt = comm.max(dt)
+        if rdv:
+            dt = rdv.max(dt)
         return dt, ([] if gather else [a.elapsed_ms(b) for a, b in ev])   # tiles are not timed one by one
 
     # the measured job: every rank regrids its shard, Y shards stay resident on their GPUs
     elapsed, kernel_ms = timed(gather=False)
-    # the same job followed by the RCCL gather of the Y shards to rank 0 (north star's exchange
-    # step), reported beside it: xGMI-link bound, see DESIGN.md "Multi-GPU"
-    with_gather = None
-    if comm and args.gather == "root":
-        try:
-            g_elapsed, _ = timed(gather=True)
-            with_gather = {"value": prob.cells() * world * args.steps / g_elapsed, "unit": "cells/s",
-                           "ms_per_step": g_elapsed / args.steps * 1e3,
-                           "gathered_bytes_per_step": int(np.prod(prob.y_shape)) * 8 * (world - 1),
-                           "tiles": len(comm.tiles), "overlapped_with_compute": True}
-        except Exception as exc:  # report, never lose the compute measurement
-            with_gather = {"error": repr(exc)}
 
+    out = None
     if rank == 0:
         k_avg = float(np.mean(kernel_ms)) * 1e-3
-        b_alg = prob.alg_bytes()
-        achieved = b_alg / k_avg / 1e9
-        # PMC traffic cannot be collected inside this run (rocprofv3 counter passes are separate
-        # processes): it is replayed from profiles/traffic.json, but only while the kernel sources
-        # are the ones the PMC pass ran (sha recorded by tools/summarize_pmc.py); else null.
-        traffic, traffic_source = None, None
-        if args.traffic_json and os.path.exists(args.traffic_json):
-            key = f"{args.workload}/{args.batch or 'default'}/{args.kernel}/{args.variant}"
-            entry = json.load(open(args.traffic_json)).get(key)
-            if entry:
-                now = kernel_source_sha()
-                fresh = entry.get("kernel_sha") == now
-                traffic = entry.get("hbm_bytes_per_launch") if fresh else None
-                traffic_source = {"file": os.path.relpath(args.traffic_json, ROOT), "key": key,
-                                  "summary": entry.get("source"), "pmc_kernel_sha": entry.get("kernel_sha"),
-                                  "pmc_git_head": entry.get("git_head"), "current_kernel_sha": now,
-                                  "fresh": fresh}
-        cfg = {"workload": prob.desc, "kernel": args.kernel,
-               "gather": args.gather if comm else "n/a", "comm": args.comm if comm else "n/a", "device": device_name(local_rank)}
+        cfg = {"workload": prob.desc, "kernel": args.kernel, "gather": args.gather if use_dist else "n/a",
+               "comm": args.comm if use_dist else "n/a", "device": dev_name,
+               "launched_by": "bench.py" if os.environ.get("LOCAL_WORLD_SIZE") and "TORCHELASTIC_RUN_ID" not in os.environ
+               and world > 1 else ("external launcher" if world > 1 else "single process")}
         cfg.update(prob.meta)
         out = {
             "metric": "regridded cells/sec (dst_pts x time x lev)",
-            "value": prob.cells() * world * args.steps / elapsed,
+            "value": prob.cells() * n_ranks * args.steps / elapsed,
             "unit": "cells/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -641,26 +873,78 @@ def main():
             "dtype": prob.x_dtype,
             "data": "synthetic",
             "config": cfg,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_source,
-                         "kernel_ms": k_avg * 1e3, "algorithmic_bytes": b_alg,
-                         "full_stream_bytes": prob.full_stream_bytes(),
-                         "line_granular_bytes": prob.line_bytes(),
-                         "line_granular_frac": (prob.line_bytes() / k_avg / 1e9 / HBM_PEAK_GBS)
-                         if prob.line_bytes() else None,
-                         "traffic_GBs": (traffic / k_avg / 1e9) if traffic else None,
-                         "stream_copy_GBs": stream_copy_gbs()},
         }
-        if with_gather is not None:
-            out["with_gather"] = with_gather
-        if not args.no_cpu_baseline and world == 1:   # CPU baseline: rank 0 at N=1 only
+        if args.dry_run:
+            out["roofline"] = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                               "traffic": None, "kernel_ms": k_avg * 1e3, "dry_run": True}
+        else:
+            out["roofline"] = roofline_block(args, prob, k_avg, args.workload, args.batch)
+            if hasattr(prob, "spot_check"):
+                out["spot_check"] = prob.spot_check(y)
+                if not out["spot_check"]["bit_equal_to_oracle"]:
+                    raise SystemExit(f"bench.py: the timed output differs from the CPU oracle: {out['spot_check']}")
+
+    # the same job followed by the RCCL gather of the Y shards to rank 0 (north star's exchange step),
+    # reported beside it: xGMI-link bound, see DESIGN.md "Multi-GPU".  The communicator is created only
+    # now; a watchdog prints the line without the gather figures if the phase does not finish in time.
+    if use_dist and args.gather == "root":
+        done = threading.Event()
+
+        def give_up():
+            if done.is_set():
+                return
+            if rank == 0:
+                out["with_gather"] = {"error": f"gather phase exceeded {args.gather_timeout:.0f} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0 if rank == 0 else 3)
+
+        dog = threading.Timer(args.gather_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        comm = dist_mod = None
+        try:
+            from smmregrid_amd.distributed import TiledRingGather
+            comm, dist_mod = make_comm(args, rank, world, local_rank, rdv)
+            ring = TiledRingGather(comm, y, root=0, tiles=args.gather_tiles, slots=2)
+            g_elapsed, _ = timed(gather=True)
+            if rank == 0:
+                out["with_gather"] = {"value": prob.cells() * n_ranks * args.steps / g_elapsed, "unit": "cells/s",
+                                      "ms_per_step": g_elapsed / args.steps * 1e3, "ranks": comm.world,
+                                      "gathered_bytes_per_step": ring.gathered_bytes // max(args.steps + args.warmup, 1),
+                                      "tiles": len(ring.tiles), "ring_slots": 2, "overlapped_with_compute": True}
+        except Exception as exc:  # report, never lose the compute measurement
+            if rank == 0:
+                out["with_gather"] = {"error": repr(exc)}
+        done.set()
+        dog.cancel()
+        try:
+            if dist_mod is not None:
+                dist_mod.destroy_process_group()
+            elif comm is not None:
+                comm.close()
+        except Exception:
+            pass
+
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not args.dry_run:   # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = prob.cpu_baseline(args.cpu_seconds)
+        names = OTHERS_DEFAULT if args.others == "default" else [n for n in args.others.split(",") if n and n != "none"]
+        if names and world == 1 and not args.dry_run and args.workload == "cfg2" and args.batch is None:
+            unknown = [n for n in names if n not in WORKLOADS]
+            if unknown:
+                raise SystemExit(f"bench.py: unknown workload(s) in --others: {unknown}")
+            y.free()
+            prob.free()
+            out["others"] = run_others(args, names, local_rank, flags, t_start)
+        out["wall_s"] = time.perf_counter() - t_start
         print(json.dumps(out), flush=True)
 
-    if comm:
-        comm.barrier()
-        comm.close()
+    if rdv:
+        try:
+            rdv.barrier()
+        except Exception:
+            pass
+        rdv.close()
 
 
 if __name__ == "__main__":

@@ -62,6 +62,7 @@ enum {
   SMM_APPLY_NO_FILL = 1u << 1,  /* skip the 1e20 fill: the caller guarantees finite X (results are undefined otherwise) */
   SMM_APPLY_SB_PACKED = 1u << 2, /* smm_apply_sb: X holds only the used source cells (smm_operator_used_sources order) */
   SMM_APPLY_HOST_NO_PACK = 1u << 3, /* smm_apply_host: always ship whole rows (no packing of the used source cells) */
+  SMM_APPLY_SB_Y_SB = 1u << 4,   /* smm_apply_sb: the result is kept batch-fastest too, Y (n_dst, ldy >= n_batch) */
   SMM_APPLY_KERNEL_SELL = 1u << 8, /* force the row-per-lane SELL-64 kernel                  */
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };
@@ -235,7 +236,10 @@ int smm_apply(smm_operator_t op,
  *   x : device, (n_src, ldx) -- the n_batch values of source cell s are contiguous at x + s*ldx
  *       (ldx >= n_batch); with SMM_APPLY_SB_PACKED x holds only the U used source cells, row r =
  *       the r-th entry of smm_operator_used_sources (ascending source index)
- *   y : device, (n_batch, ldy) exactly as smm_apply writes it (regrid.py:550 layout)
+ *   y : device, (n_batch, ldy) exactly as smm_apply writes it (regrid.py:550 layout); with
+ *       SMM_APPLY_SB_Y_SB the result stays batch-fastest as well -- y (n_dst, ldy >= n_batch), entry b of
+ *       destination cell d at y + d*ldy + b -- which is the x a following smm_apply_sb on the target
+ *       grid consumes without any transpose (chains of regrids on device-resident fields)
  * In the reference's native (B, S) layout a stencil that needs 16-B pairs on a 32-B stride (config
  * 2: bilinear 4:1) wastes half of every 128-B line fetched; here every needed source cell is one
  * contiguous run, so HBM traffic equals the algorithmic bytes.  Results are bit-identical to
@@ -292,7 +296,8 @@ int smm_group_apply(smm_group_t g,
  * Masked-level apply for a field kept batch-fastest per level: data level l is an (S, ldx >= n_batch)
  * slab at x + l * xs_lev (the n_batch values of a source cell contiguous), its results go to
  * y + l * ys_lev + b * ys_batch + d.  Y as regrid3d lays it out with transpose (B, L, D):
- * ys_lev = D, ys_batch = L * D; without (L, B, D): ys_lev = B * D, ys_batch = D.  Same level_index /
+ * ys_lev = D, ys_batch = L * D; without (L, B, D): ys_lev = B * D, ys_batch = D.  With SMM_APPLY_SB_Y_SB
+ * the result stays batch-fastest per level, Y (L, D, ys_batch >= B): ys_lev = D * ys_batch.  Same level_index /
  * masked_levels semantics and the same bits as smm_group_apply (one kernel launch per data level, all
  * on `stream`).  smm_group_prepare_sb uploads the members' CSRs ahead of time (else done by the first call).
  */

@@ -24,6 +24,7 @@ APPLY_MASKED = 1 << 0
 APPLY_NO_FILL = 1 << 1
 APPLY_SB_PACKED = 1 << 2
 APPLY_HOST_NO_PACK = 1 << 3
+APPLY_SB_Y_SB = 1 << 4
 CREATE_PRUNE_ZEROS = 1 << 0
 APPLY_KERNEL_SELL = 1 << 8
 APPLY_KERNEL_TILE = 1 << 9

@@ -963,8 +963,8 @@ int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, voi
   if (!x || !y) return fail(SMM_ERR_INVALID, "null field pointer");
   if ((x_dtype != SMM_F32 && x_dtype != SMM_F64) || (y_dtype != SMM_F32 && y_dtype != SMM_F64))
     return fail(SMM_ERR_UNSUPPORTED, "field dtype must be SMM_F32 or SMM_F64");
-  if (ldx < n_batch || ldy < op->csr.n_dst)
-    return fail(SMM_ERR_INVALID, "ldx smaller than the batch or ldy smaller than the destination grid");
+  if (ldx < n_batch || ldy < ((flags & SMM_APPLY_SB_Y_SB) ? n_batch : op->csr.n_dst))
+    return fail(SMM_ERR_INVALID, "ldx smaller than the batch or ldy smaller than a row of Y");
   if (!(remap_area_min >= 0.0 && remap_area_min <= 1.0))
     return fail(SMM_ERR_INVALID, "remap_area_min must be within [0, 1]");  // regrid.py:124-125
   if ((flags & SMM_APPLY_MASKED) && !op->d_imask)
@@ -1391,8 +1391,8 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
   // the whole call is validated before the first launch (as smm_group_apply does): a later level's
   // missing dst_imask / dst_frac or a bad stride must not surface after earlier levels wrote part of Y
   if (ldx < n_batch) return fail(SMM_ERR_INVALID, "ldx smaller than the batch");
-  if (ys_batch < g->ops[0]->csr.n_dst)
-    return fail(SMM_ERR_INVALID, "ys_batch smaller than the destination grid");
+  if (ys_batch < ((flags & SMM_APPLY_SB_Y_SB) ? n_batch : g->ops[0]->csr.n_dst))
+    return fail(SMM_ERR_INVALID, "ys_batch smaller than a row of Y");
   if ((uintptr_t)x % xsz || (uintptr_t)y % ysz) return fail(SMM_ERR_INVALID, "field pointer is not element aligned");
   {
     int vrc = check_sb_levels(g, n_lev, level_index, masked_levels, remap_area_min, flags);

@@ -69,7 +69,7 @@ struct SbArgs {
   const uint8_t* imask;    // [n_dst] or null
   const double* frac;      // [n_dst] or null
   const void* x;           // (n_rows_x, ldx): row = source cell, batch entry fastest
-  void* y;                 // batch entry b of destination cell d at y + b * ldy + d
+  void* y;                 // batch entry b of destination cell d at y + b * ldy + d  (YSB: at y + d * ldy + b)
   int64_t ldx, ldy, n_batch, n_dst;
   int64_t n_dtiles, n_btiles, n_blocks;
   double area_min;
@@ -845,14 +845,17 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
 // [TD][BT] that is read back transposed, so that Y is written in runs of TD consecutive
 // destination cells per batch row (TD = 16 doubles = one 128-B line).
 
-template <typename XT, typename YT, int TD, int U, bool FILL>
+// YSB: the result is kept batch-fastest too -- Y (D, ldy >= B), the layout a second regrid consumes
+// without a transpose (SMM_APPLY_SB_Y_SB).  A finished row is then one contiguous 1-KiB wave store and
+// the kernel needs no LDS at all.
+template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
 __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   constexpr int VEC = 2;                    // batch entries per lane
   constexpr int BT = 64 * VEC;              // batch entries per tile
   constexpr int PAD = 16 / (int)sizeof(YT); // LDS row padding: one 16-B slot (conflict-free transposed reads)
   constexpr int LROW = BT + PAD;
   static_assert(TD % 2 == 0 && 128 % TD == 0 && TD <= 64, "store phase: TD / 2 lanes per batch row");
-  __shared__ __attribute__((aligned(16))) YT tile[TD * LROW];
+  __shared__ __attribute__((aligned(16))) YT tile[YSB ? 1 : TD * LROW];
   typedef XT xvec __attribute__((ext_vector_type(VEC)));
   typedef xvec xvec_u __attribute__((aligned(sizeof(XT))));   // element-aligned (any ldx / base)
 
@@ -924,7 +927,18 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
     yvec o;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = out[v];
-    *(yvec*)(&tile[d_local * LROW + lane * VEC]) = o;
+    if constexpr (YSB) {
+      // batch-fastest result: this row's 128 batch entries are one contiguous run of Y row d
+      typedef yvec yvec_u __attribute__((aligned(sizeof(YT))));
+      const int64_t b = b0 + (int64_t)lane * VEC;
+      YT* dst = (YT*)a.y + (d0 + d_local) * a.ldy + b;
+      if (b + VEC <= a.n_batch)
+        __builtin_nontemporal_store(o, (yvec_u*)dst);
+      else if (b < a.n_batch)
+        __builtin_nontemporal_store(out[0], dst);   // odd batch: the last entry (shift1 put it in element 0)
+    } else {
+      *(yvec*)(&tile[d_local * LROW + lane * VEC]) = o;
+    }
     ++d_local;
     row_end = row_end_next;
     const int nxt = d_local + 2 <= rows ? d_local + 2 : rows;
@@ -985,6 +999,7 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
     }
   }
   while (d_local < rows) flush_row();
+  if constexpr (YSB) return;
   __syncthreads();
 
   // transposed read-back: TD / 2 lanes cover one batch row's TD destination cells (two per lane)

@@ -201,9 +201,14 @@ int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
   // (config 2: 1.76 -> 1.65 ms against destination-tile-fastest order over the whole grid; strips of 1, 4,
   // 8, 16 tiles within 3 % of it).  Tuning variants: 3 = whole-grid order, 4 / 5 = strips of 1 / 8.
   args.b_fastest = variant == 3 ? 0 : (variant == 4 ? 1 : (variant == 5 ? 8 : 2));
+  const bool ysb = (flags & SMM_APPLY_SB_Y_SB) != 0;   // result kept batch-fastest: Y (D, ldy >= B)
   auto go = [&](auto u_tag, auto fill_tag) {
-    hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, decltype(u_tag)::value, decltype(fill_tag)::value>),
-                       dim3((unsigned)total), dim3(64), 0, s, args);
+    if (ysb)
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, decltype(u_tag)::value, decltype(fill_tag)::value, true>),
+                         dim3((unsigned)total), dim3(64), 0, s, args);
+    else
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, decltype(u_tag)::value, decltype(fill_tag)::value>),
+                         dim3((unsigned)total), dim3(64), 0, s, args);
   };
   auto with_fill = [&](auto u_tag) {
     if (fill) go(u_tag, std::true_type());

@@ -1,0 +1,155 @@
+// Practical HBM ceilings of MI355X for the access SHAPES of the regrid kernels (measurement tool, not
+// part of the product): how fast can the chip move bytes when reads come in runs of a given length at
+// scattered addresses and writes go out in segments of a given length on a given stride, at a given
+// read : write mix?  The kernels' PMC traffic rates are held against these numbers in DESIGN.md.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/exp/ceiling.hip -o tools/exp/ceiling
+//   tools/exp/ceiling <read_run_B> <read_B_per_unit> <write_seg_B> <write_B_per_unit> <write_stride_B> [units] [wg_per_cu] [reps]
+//
+// One wave = one "unit" at a time: it reads read_B_per_unit bytes as 1-KiB wave loads (16 B per lane,
+// eight in flight) whose bytes are cut into runs of read_run_B at pseudo-random 128-B-aligned places
+// of an 8-GiB buffer (beyond the 256-MiB Infinity Cache), and writes write_B_per_unit bytes as 1-KiB
+// wave stores (non-temporal) cut into segments of write_seg_B placed write_stride_B apart, neighbouring
+// units writing neighbouring segments of the same rows (the Y tiles of the regrid kernels).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                      \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                         \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Args {
+  const char* src;
+  char* dst;
+  uint64_t slot_mask;      // number of run-sized slots in src (a power of two) - 1
+  uint32_t slot_shift;     // log2 of the slot size (>= read_run, >= 128)
+  uint32_t run_shift, seg_shift;   // log2(read_run), log2(write_seg): both powers of two, no division per piece
+  uint32_t read_run, read_unit, write_seg, write_unit;
+  uint64_t write_stride;
+  uint64_t n_units;
+  uint32_t cols;           // segments per row of the write pattern
+};
+
+__device__ __forceinline__ uint64_t mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void ceiling_kernel(Args a) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  const uint32_t n_rp = a.read_unit / 1024, n_wp = a.write_unit / 1024;
+  const uint32_t runs_per_unit = (a.read_unit + a.read_run - 1) >> a.run_shift;
+  const uint32_t segs_per_unit = (a.write_unit + a.write_seg - 1) >> a.seg_shift;
+  u32x4 acc = {0, 0, 0, 0};
+  for (uint64_t u = wave; u < a.n_units; u += n_waves) {
+    for (uint32_t p0 = 0; p0 < n_rp; p0 += 8) {
+      u32x4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t p = p0 + q < n_rp ? p0 + q : n_rp - 1;
+        const uint32_t o = p * 1024 + lane * 16;
+        const uint32_t run = o >> a.run_shift, within = o & (a.read_run - 1);
+        const uint64_t slot = mix(u * runs_per_unit + run + 0x9E3779B97F4A7C15ull) & a.slot_mask;
+        v[q] = __builtin_nontemporal_load((const u32x4*)(a.src + (slot << a.slot_shift) + within));
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc ^= v[q];
+    }
+    const uint64_t urow = u / a.cols, ucol = u - urow * a.cols;   // once per unit
+    for (uint32_t p = 0; p < n_wp; ++p) {
+      const uint32_t o = p * 1024 + lane * 16;
+      const uint32_t seg = o >> a.seg_shift, within = o & (a.write_seg - 1);
+      char* d = a.dst + (urow * segs_per_unit + seg) * a.write_stride + ucol * a.write_seg + within;
+      u32x4 out = acc;
+      out.x += p;
+      __builtin_nontemporal_store(out, (u32x4*)d);
+    }
+  }
+  if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u && n_wp == 0) a.dst[0] = 1;   // keeps the loads alive
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    fprintf(stderr, "usage: %s read_run_B read_B_per_unit write_seg_B write_B_per_unit write_stride_B [units] [wg_per_cu] [reps]\n", argv[0]);
+    return 2;
+  }
+  Args a{};
+  a.read_run = (uint32_t)atoll(argv[1]);
+  a.read_unit = (uint32_t)atoll(argv[2]);
+  a.write_seg = (uint32_t)atoll(argv[3]);
+  a.write_unit = (uint32_t)atoll(argv[4]);
+  a.write_stride = (uint64_t)atoll(argv[5]);
+  a.n_units = argc > 6 ? (uint64_t)atoll(argv[6]) : 400000;
+  const int wg_per_cu = argc > 7 ? atoi(argv[7]) : 8;
+  const int reps = argc > 8 ? atoi(argv[8]) : 5;
+  auto pow2 = [](uint32_t v) { return v >= 16 && (v & (v - 1)) == 0; };
+  if (a.read_unit % 1024 || a.write_unit % 1024 || !pow2(a.read_run) || !pow2(a.write_seg) ||
+      a.write_stride < a.write_seg || a.write_stride % a.write_seg) {
+    fprintf(stderr, "bytes per unit: multiples of 1024; runs / segments: powers of two >= 16; stride: a multiple of the segment\n");
+    return 2;
+  }
+  const uint64_t src_bytes = 8ull << 30;
+  auto lg = [](uint64_t v) { uint32_t s = 0; while ((1ull << s) < v) ++s; return s; };
+  a.run_shift = lg(a.read_run);
+  a.seg_shift = lg(a.write_seg);
+  a.slot_shift = a.run_shift < 7 ? 7 : a.run_shift;
+  a.slot_mask = (src_bytes >> a.slot_shift) - 1;
+  a.cols = a.write_unit ? (uint32_t)(a.write_stride / a.write_seg) : 1;
+  const uint32_t segs_per_unit = a.write_unit ? (a.write_unit + a.write_seg - 1) / a.write_seg : 0;
+  const uint64_t rows = (a.n_units + a.cols - 1) / a.cols;
+  const uint64_t dst_bytes = a.write_unit ? rows * segs_per_unit * a.write_stride + 4096 : 4096;
+  if (dst_bytes > (200ull << 30)) {
+    fprintf(stderr, "write pattern needs %.1f GB\n", dst_bytes / 1e9);
+    return 2;
+  }
+  char *src = nullptr, *dst = nullptr;
+  CHECK(hipMalloc((void**)&src, src_bytes));
+  CHECK(hipMalloc((void**)&dst, dst_bytes));
+  CHECK(hipMemset(src, 1, src_bytes));
+  CHECK(hipMemset(dst, 0, dst_bytes));
+  a.src = src;
+  a.dst = dst;
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const unsigned grid = (unsigned)(prop.multiProcessorCount * wg_per_cu);
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(ceiling_kernel, dim3(grid), dim3(256), 0, nullptr, a);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int r = 0; r < reps; ++r) {
+    CHECK(hipEventRecord(e0, nullptr));
+    hipLaunchKernelGGL(ceiling_kernel, dim3(grid), dim3(256), 0, nullptr, a);
+    CHECK(hipEventRecord(e1, nullptr));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+    sum += ms;
+  }
+  const double rb = (double)a.n_units * a.read_unit, wb = (double)a.n_units * a.write_unit;
+  printf("{\"read_run\": %u, \"read_unit\": %u, \"write_seg\": %u, \"write_unit\": %u, \"write_stride\": %llu, "
+         "\"units\": %llu, \"wg_per_cu\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, \"read_GBs\": %.1f, "
+         "\"write_GBs\": %.1f, \"total_GBs\": %.1f, \"write_share\": %.3f}\n",
+         a.read_run, a.read_unit, a.write_seg, a.write_unit, (unsigned long long)a.write_stride,
+         (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
+         (rb + wb) / (sum / reps) / 1e6, wb / (rb + wb + 1e-30));
+  CHECK(hipFree(src));
+  CHECK(hipFree(dst));
+  return 0;
+}
