@@ -58,6 +58,8 @@ WORKLOADS = {
     # "sb" = X (S, B), "sbp" = X (U, B) holding only the used source cells
     "cfg2sb": ("bil", "r1440x721", "r360x180", 3600, "f64", "sb"),
     "cfg2sbp": ("bil", "r1440x721", "r360x180", 3600, "f64", "sbp"),
+    # ... and the result kept batch-fastest too, Y (D, B): what a chain of regrids passes on (SMM_APPLY_SB_Y_SB)
+    "cfg2sbk": ("bil", "r1440x721", "r360x180", 3600, "f64", "sbk"),
     # config 2 with the exact-zero links dropped at operator creation (SMM_CREATE_PRUNE_ZEROS: the grids are
     # aligned, 3 of the 4 bilinear links of every row weigh exactly 0) -- same results, a quarter of the links
     "cfg2z": ("bil", "r1440x721", "r360x180", 3600, "f64", "bs+z"),
@@ -120,7 +122,7 @@ def parse_args():
                          "max over ranks and the JSON line (CPU tests of the N>1 path)")
     ap.add_argument("--others", default="default",
                     help="secondary workloads timed after the headline at N=1 (comma list, 'default' or 'none')")
-    ap.add_argument("--others-steps", type=int, default=10)
+    ap.add_argument("--others-steps", type=int, default=20)
     ap.add_argument("--others-budget", type=float, default=240.0,
                     help="seconds after which remaining secondary workloads are skipped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,15 +168,17 @@ class Problem2D:
         self.op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
         self.np_dt = np.float64 if self.x_dtype == "f64" else np.float32
         x_shape = {"bs": (self.n_batch, self.n_src), "sb": (self.n_src, self.n_batch),
-                   "sbp": (self.op.n_used_src, self.n_batch)}[self.layout]
+                   "sbp": (self.op.n_used_src, self.n_batch), "sbk": (self.n_src, self.n_batch)}[self.layout]
         self.x = DeviceArray(x_shape, self.np_dt)
         self.x.fill_random(seed=20260723 + 1000003 * rank, mean=250.0, sigma=30.0)
         if self.layout != "bs":
             self.op.prepare_sb()
-        self.y_shape = (self.n_batch, self.n_dst)
-        lay = {"bs": "X (B, S) native layout", "sb": "X (S, B) batch-fastest", "sbp": "X (U, B) batch-fastest, used cells only"}
+        self.y_shape = (self.n_dst, self.n_batch) if self.layout == "sbk" else (self.n_batch, self.n_dst)
+        lay = {"bs": "X (B, S) native layout", "sb": "X (S, B) batch-fastest", "sbp": "X (U, B) batch-fastest, used cells only",
+               "sbk": "X (S, B) batch-fastest"}
         self.desc = (f"{name}: {sgrid}->{tgrid} {method}, {self.n_batch} batch rows per GPU, "
-                     f"{self.x_dtype} in / f64 out, {lay[self.layout]}, Y (B, D), X and Y resident in HBM")
+                     f"{self.x_dtype} in / f64 out, {lay[self.layout]}, "
+                     f"{'Y (D, B) kept batch-fastest' if self.layout == 'sbk' else 'Y (B, D)'}, X and Y resident in HBM")
         self.meta = {"S": self.n_src, "D": self.n_dst, "nnz": self.op.nnz, "U": self.op.n_used_src,
                      "plan": self.op.plan_info()}
         if self.prune:
@@ -210,7 +214,7 @@ class Problem2D:
             self.op.apply(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags)
         else:
             self.op.apply_sb(self.x, y=y, masked=False, remap_area_min=0.5, packed=self.layout == "sbp",
-                             flags=flags)
+                             flags=flags, keep_batch_fastest=self.layout == "sbk")
 
     def spot_check(self, y, max_dst=65536):
         """One batch row of the timed output against oracle/oracle.c (bit equality; NaN positions
@@ -233,7 +237,12 @@ class Problem2D:
                 xrow[self.op.used_sources()] = col
             else:
                 xrow = col
-        got = y.rows(r, r + 1).to_host().reshape(-1)
+        if self.layout == "sbk":                # column r of the (D, B) result
+            got = np.empty(self.n_dst, dtype=np.float64)
+            _lib.call("smm_memcpy2d_d2h", got.ctypes.data_as(ctypes.c_void_p), 8, ctypes.c_void_p(y.ptr + r * 8),
+                      self.n_batch * 8, 8, self.n_dst, None)
+        else:
+            got = y.rows(r, r + 1).to_host().reshape(-1)
         w = self.weights
         n_chk = int(min(self.n_dst, max_dst))
         dst = w["dst_address"].values
@@ -255,6 +264,8 @@ class Problem2D:
         if self.layout == "bs":
             self.op.apply(self.x.rows(r0, r1), y=y.rows(r0, r1), masked=False, remap_area_min=0.5, flags=flags)
             return
+        if self.layout == "sbk":
+            raise SystemExit("the tiled gather moves (B, D) row tiles: use cfg2 / cfg2sb with --gpus N")
         import ctypes
         from smmregrid_amd import _lib
         from smmregrid_amd.device import dtype_code
@@ -715,7 +726,7 @@ def roofline_block(args, prob, k_avg, workload, batch, with_copy_rate=True):
     return out
 
 
-OTHERS_DEFAULT = ["cfg2sb", "cfg3", "cfg3c", "cfg4s"]
+OTHERS_DEFAULT = ["cfg2sb", "cfg2sbk", "cfg3", "cfg3c", "cfg4s", "cfg5tile"]
 
 
 def run_others(args, names, local_rank, flags, t_start):
@@ -739,8 +750,8 @@ def run_others(args, names, local_rank, flags, t_start):
                 prob = (ProblemLevels if levels else Problem2D)(name, local_rank, 0)
                 if levels:
                     shared["levels"] = prob
-            y = DeviceArray(prob.y_shape, np.float64)
-            for _ in range(2):
+            y = DeviceArray(prob.y_shape, np.float64, layout="sb" if getattr(prob, "layout", "") == "sbk" else "bs")
+            for _ in range(3):
                 prob.run(y, flags)
             synchronize()
             ev = [(Event(), Event()) for _ in range(args.others_steps)]
@@ -752,7 +763,7 @@ def run_others(args, names, local_rank, flags, t_start):
             synchronize()
             wall = time.perf_counter() - w0
             k_avg = float(np.mean([a.elapsed_ms(b) for a, b in ev])) * 1e-3
-            entry = {"workload": prob.desc, "steps": args.others_steps, "warmup": 2,
+            entry = {"workload": prob.desc, "steps": args.others_steps, "warmup": 3,
                      "value": prob.cells() * args.others_steps / wall, "unit": "cells/s",
                      "ms_per_step": wall / args.others_steps * 1e3, "dtype": prob.x_dtype}
             entry.update(roofline_block(args, prob, k_avg, name, None, with_copy_rate=False))

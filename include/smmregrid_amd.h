@@ -191,7 +191,8 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
                            int64_t* staged_src_elems);
 
 /* Launch geometry smm_apply would use for n_batch rows of x_dtype under `flags` (nothing is
- * launched; for tests and tuning).  kernel: 0 = SELL row-per-lane, 1 = LDS tile; j_per_block: batch
+ * launched; for tests and tuning).  kernel: 0 = SELL row-per-lane, 1 = LDS tile staged through registers,
+ * 2 = LDS tile staged by LDS-DMA into a ring of two slots (small tiles of 16-B aligned fields); j_per_block: batch
  * rows walked by one workgroup; rows_per_step: batch rows staged per barrier pair; rows_per_block:
  * destination rows per workgroup; n_blocks: grid size; lds_bytes: dynamic LDS per workgroup;
  * big_operator: the links do not stay in L2, walks are lengthened to amortise their re-read.

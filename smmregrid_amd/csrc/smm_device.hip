@@ -343,7 +343,7 @@ int ensure_sb(smm_operator* op) {
 }
 
 struct LaunchInfo {
-  bool tile = false, big_operator = false;
+  bool tile = false, big_operator = false, dma = false;
   int j_per_block = 0, rows_per_step = 1, rows_per_block = 0;
   int64_t n_jtiles = 0, n_blocks = 0, lds_bytes = 0;
 };
@@ -420,6 +420,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
       info_only->rows_per_step = c.rows;
       info_only->lds_bytes = (int64_t)c.lds;
       info_only->big_operator = c.big_operator;
+      info_only->dma = c.dma;
       info_only->rows_per_block = (int)shape_rows(tile_which);
     } else {
       const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
@@ -1413,7 +1414,7 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
 extern "C++" {
 static void fill_launch_info(const LaunchInfo& li, int* kernel, int* j_per_block, int* rows_per_step,
                              int* rows_per_block, int64_t* n_blocks, int64_t* lds_bytes, int* big_operator) {
-  if (kernel) *kernel = li.tile ? 1 : 0;
+  if (kernel) *kernel = li.tile ? (li.dma ? 2 : 1) : 0;
   if (j_per_block) *j_per_block = li.j_per_block;
   if (rows_per_step) *rows_per_step = li.rows_per_step;
   if (rows_per_block) *rows_per_block = li.rows_per_block;

@@ -254,15 +254,27 @@ constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPer
 // registers; per batch row the G = 1 << sub_shift lane groups run one after the other, each starting
 // from the sum its predecessor handed over (a shuffle), so every row is still accumulated link by
 // link in ascending source order -- bit-identical -- while no link is re-read from L2.
-template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SPLIT = false>
+// DMA: the staging pieces go HBM -> LDS directly (global_load_lds_dwordx4, the gfx950 LDS-DMA path) into
+// a ring of two tile slots instead of HBM -> VGPR -> ds_write: row j + 1 lands in the other slot while
+// row j is consumed.  No prefetch registers, one barrier per batch row, the fill test moves to the
+// gather -- at twice the LDS per workgroup.  That trade pays exactly where LDS is NOT what limits the
+// workgroups per CU: small tiles of the 4-wave shape (HEALPix targets: two slots of <= 8 KB keep 8
+// workgroups = 32 waves per CU; config-4 geometry 5.44 -> 4.81 ms against four-row register steps).
+// Larger tiles lose workgroups to the second slot (config 2: 2.71 -> 2.99 ms; the 64-row single-wave
+// kernels of config 3: 12.4 -> 15.1 ms, 15-KiB tiles: 5 instead of 8 waves per CU -- the register file
+// is the bigger store on this chip, 512 KB against 160 KB per CU, and the prefetched row lives there).
+// Rings of 3 / 4 slots with counted s_waitcnt vmcnt(N) and a raw s_barrier were built and measured
+// slower than two slots everywhere (config-4 geometry 4.99 / 5.56 ms): again fewer workgroups per CU.
+template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SPLIT = false, bool DMA = false>
 __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   constexpr int WPB = tile_waves(MAXK);
   constexpr int T = WPB * 64;
+  static_assert(!DMA || (R == 1 && !SPLIT && MAXK > 0), "LDS-DMA staging: single-row steps, links in registers");
   // Where the 1e20 fill happens: rows of more than 16 links test the staging pieces on their way into
   // LDS (a 48-link row would test 48 gathered values per batch row, its ~15 pieces hold 30); short
   // rows gather few values from comparatively many staged ones (config 4: 4 links, 8 staged f32 per
   // lane and step) and test what they gather.
-  constexpr bool kFixAtStage = (MAXK == 0 || MAXK > 16);
+  constexpr bool kFixAtStage = !DMA && (MAXK == 0 || MAXK > 16);   // LDS-DMA bypasses the registers: test at the gather
   static_assert(!SPLIT || (WPB == 1 && R == 1 && MAXK > 0), "split rows: single-wave, single-row steps");
   static_assert(R == 1 || (MAXK > 0 && MAXK <= 16), "multi-row steps exist for the 4-wave shape only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -485,7 +497,81 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
     return;
   }
 
-  if constexpr (R == 1) {
+  if constexpr (DMA) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int tile_bytes = a.tile_bytes;   // one slot of the ring
+    // piece k of this wave lands at (wave * 64 + k * T) * 16 + lane * 16 of the slot: the LDS-DMA
+    // destination is a wave-uniform base plus lane * 16, the source address is per lane
+    auto issue_row = [&](int64_t xoff, int slot) {
+      const XT* __restrict__ xrow = (const XT*)a.x + xoff;
+      char* base = smem + (size_t)slot * tile_bytes + (size_t)wave * 64 * 16;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        if (k >= np_w) break;
+        __builtin_amdgcn_global_load_lds((gptr_t)(xrow + poff[k]), (lptr_t)(base + (size_t)k * T * 16), 16, 0,
+                                         (NT & 1) ? 2 : 0);
+      }
+    };
+    RowWalker xw(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
+    RowWalker yw(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
+    YT pend_out = (YT)0;
+    int64_t pend_off = 0;
+    auto flush_pending = [&]() {
+      YT* __restrict__ yrow = (YT*)a.y + pend_off;
+      if (NT & 2)
+        __builtin_nontemporal_store(pend_out, yrow + dy);
+      else
+        yrow[dy] = pend_out;
+    };
+    issue_row(xw.off, 0);
+    int slot = 0;
+    for (int64_t j = j_begin; j < j_end; ++j) {
+      asm volatile("" : "+s"(np_w), "+s"(wmax));
+      if (MAXK > 16) {
+#pragma unroll
+        for (int q = 0; q < KREG / 2; ++q) asm volatile("" : "+v"(lc2[q]));
+      }
+      // row j has landed (and every wave is done with the other slot, which row j + 1 is about to overwrite)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (WPB > 1) __syncthreads();
+      if (row_live && j > j_begin) flush_pending();   // row j - 1's result: issued before the next DMA
+      if (j + 1 < j_end) {
+        xw.next();
+        issue_row(xw.off, slot ^ 1);
+      }
+      if (slice_live) {
+        const char* lds_b = smem + (size_t)slot * tile_bytes;
+        double acc = 0.0;
+#pragma unroll
+        for (int k0 = 0; k0 < KREG; k0 += 4) {
+          if (k0 < wmax) {
+            double xv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int k = k0 + kk;
+              const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16) : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
+              xv[kk] = load_fixed((const XT*)(lds_b + li), fill);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              const int k = k0 + kk;
+              if (k < KREG) {
+                const double p = w[k] * xv[kk];
+                acc = acc + p;
+              }
+            }
+          }
+        }
+        acc = len > 0 ? acc : 0.0;
+        pend_out = (YT)epilogue(acc, dead);
+        pend_off = yw.off;
+      }
+      yw.next();
+      slot ^= 1;
+    }
+    if (row_live) flush_pending();
+  } else if constexpr (R == 1) {
     const XT* lds_x = (const XT*)smem;
     u32x4 v[NP];
     auto load_row = [&](int64_t xoff) {
@@ -846,8 +932,13 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
 // destination cells per batch row (TD = 16 doubles = one 128-B line).
 
 // YSB: the result is kept batch-fastest too -- Y (D, ldy >= B), the layout a second regrid consumes
-// without a transpose (SMM_APPLY_SB_Y_SB).  A finished row is then one contiguous 1-KiB wave store and
-// the kernel needs no LDS at all.
+// without a transpose (SMM_APPLY_SB_Y_SB).  The finished rows still wait in the LDS tile and leave at
+// the end of the tile, each as one contiguous 1-KiB wave store: a store issued in the middle of the
+// link walk sits in the in-order memory counter in front of the loads that follow it, and the walk
+// then waits for its acknowledgement (measured: config 2 1.70 ms with stores in the walk).
+// (Workgroups of 2 / 4 waves sharing one tile -- 18 / 20 instead of 9 waves per CU -- were built and
+// measured level with single-wave workgroups, 1.69 / 1.59 vs 1.62 ms on config 2: the kernel runs at
+// the rate the chip sustains for this read : write mix, occupancy is not what bounds it.)
 template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
 __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   constexpr int VEC = 2;                    // batch entries per lane
@@ -855,7 +946,7 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   constexpr int PAD = 16 / (int)sizeof(YT); // LDS row padding: one 16-B slot (conflict-free transposed reads)
   constexpr int LROW = BT + PAD;
   static_assert(TD % 2 == 0 && 128 % TD == 0 && TD <= 64, "store phase: TD / 2 lanes per batch row");
-  __shared__ __attribute__((aligned(16))) YT tile[YSB ? 1 : TD * LROW];
+  __shared__ __attribute__((aligned(16))) YT tile[TD * LROW];
   typedef XT xvec __attribute__((ext_vector_type(VEC)));
   typedef xvec xvec_u __attribute__((aligned(sizeof(XT))));   // element-aligned (any ldx / base)
 
@@ -927,18 +1018,7 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
     yvec o;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = out[v];
-    if constexpr (YSB) {
-      // batch-fastest result: this row's 128 batch entries are one contiguous run of Y row d
-      typedef yvec yvec_u __attribute__((aligned(sizeof(YT))));
-      const int64_t b = b0 + (int64_t)lane * VEC;
-      YT* dst = (YT*)a.y + (d0 + d_local) * a.ldy + b;
-      if (b + VEC <= a.n_batch)
-        __builtin_nontemporal_store(o, (yvec_u*)dst);
-      else if (b < a.n_batch)
-        __builtin_nontemporal_store(out[0], dst);   // odd batch: the last entry (shift1 put it in element 0)
-    } else {
-      *(yvec*)(&tile[d_local * LROW + lane * VEC]) = o;
-    }
+    *(yvec*)(&tile[d_local * LROW + lane * VEC]) = o;
     ++d_local;
     row_end = row_end_next;
     const int nxt = d_local + 2 <= rows ? d_local + 2 : rows;
@@ -999,8 +1079,25 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
     }
   }
   while (d_local < rows) flush_row();
-  if constexpr (YSB) return;
   __syncthreads();
+
+  if constexpr (YSB) {
+    // batch-fastest result: row r's 128 batch entries are one contiguous run of Y row d0 + r
+    typedef YT yvec __attribute__((ext_vector_type(VEC)));
+    typedef yvec yvec_u __attribute__((aligned(sizeof(YT))));
+    const int64_t b = b0 + (int64_t)lane * VEC;
+    YT* __restrict__ yb = (YT*)a.y + d0 * a.ldy + b;
+#pragma unroll 4
+    for (int r = 0; r < rows; ++r) {
+      const yvec o = *(const yvec*)(&tile[r * LROW + lane * VEC]);
+      YT* dst = yb + (int64_t)r * a.ldy;
+      if (b + VEC <= a.n_batch)
+        __builtin_nontemporal_store(o, (yvec_u*)dst);
+      else if (b < a.n_batch)
+        __builtin_nontemporal_store(o[0], dst);   // odd batch: the last entry (shift1 put it in element 0)
+    }
+    return;
+  }
 
   // transposed read-back: TD / 2 lanes cover one batch row's TD destination cells (two per lane)
   constexpr int LPB = TD / 2;            // lanes per batch row

@@ -62,6 +62,7 @@ struct TileLaunchCfg {
   int threads = 0;
   int np_needed = 0;       // 16-B staging pieces per thread of the widest block
   int rows = 1;            // batch rows staged per barrier pair (R)
+  bool dma = false;        // staging by LDS-DMA into a ring of two tile slots (single-row steps)
   size_t tile = 0, lds = 0;
   bool big_operator = false;
 };
@@ -95,7 +96,17 @@ inline TileLaunchCfg tile_launch_cfg(const ApplyArgs& a, int64_t n_lev, int tile
   c.rows = 1;
   if (!tile_which && variant != 12) c.rows = c.np_needed <= 1 ? 4 : (c.np_needed <= 2 ? 2 : 1);
   while (c.rows > 1 && c.rows > c.j_per_block) c.rows /= 2;
-  c.lds = c.tile * (size_t)c.rows;
+  // LDS-DMA staging instead (smm_kernels.hpp, DMA): on by default for the small tiles the multi-row
+  // steps serve (two slots of <= 8 KB keep every workgroup slot of the CU), variant 10 forces it for
+  // any tile of either block shape that keeps its links in registers, variants 8 / 12 switch it off.
+  // The DMA moves aligned 16-B pieces: base, strides and row length must be multiples of 16 B.
+  const bool aligned = ((uintptr_t)a.x % 16 == 0) && (a.xs_o * (int64_t)xsz % 16 == 0) &&
+                       (a.xs_l * (int64_t)xsz % 16 == 0) && (a.xs_i * (int64_t)xsz % 16 == 0) &&
+                       (a.n_src * (int64_t)xsz % 16 == 0);
+  const bool wanted = variant == 10 || (!tile_which && c.np_needed <= 2 && variant != 8 && variant != 12);
+  c.dma = wanted && aligned && a.sub_shift == 0 && max_row_nnz > 0 && max_row_nnz <= 48 && 2 * c.tile <= 65536;
+  if (c.dma) c.rows = 1;
+  c.lds = c.dma ? 2 * c.tile : c.tile * (size_t)c.rows;
   return c;
 }
 
@@ -117,6 +128,18 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   args.tile_bytes = (int)cfg.tile;
   const size_t lds = cfg.lds;
 
+  const bool dma = cfg.dma;   // LDS-DMA staging into a ring of two tile slots (tile_launch_cfg)
+  auto go_dma = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
+    constexpr int MAXK = decltype(k_tag)::value;
+    if constexpr (MAXK > 0) {
+      hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, false, true>),
+                         dim3((unsigned)total), dim3(tile_waves(MAXK) * 64), lds, s, args, fill);
+      SMM_LAUNCH_HIP(hipGetLastError());
+      return SMM_OK;
+    } else {
+      return smm::fail_msg(SMM_ERR_UNSUPPORTED, "LDS-DMA staging needs the links in registers");
+    }
+  };
   auto go3 = [&](auto k_tag, auto np_tag, auto nt_tag, auto r_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
     constexpr int NP = decltype(np_tag)::value;
@@ -134,6 +157,7 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   const int64_t per_grp = (max_row_nnz + n_grp - 1) / n_grp;
   auto go2 = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
+    if (dma) return go_dma(k_tag, np_tag, nt_tag);
     if constexpr (MAXK == 32 || MAXK == 48) {
       if (split) {
         hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, true>),
@@ -203,12 +227,12 @@ int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
   args.b_fastest = variant == 3 ? 0 : (variant == 4 ? 1 : (variant == 5 ? 8 : 2));
   const bool ysb = (flags & SMM_APPLY_SB_Y_SB) != 0;   // result kept batch-fastest: Y (D, ldy >= B)
   auto go = [&](auto u_tag, auto fill_tag) {
+    constexpr int UU = decltype(u_tag)::value;
+    constexpr bool FF = decltype(fill_tag)::value;
     if (ysb)
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, decltype(u_tag)::value, decltype(fill_tag)::value, true>),
-                         dim3((unsigned)total), dim3(64), 0, s, args);
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), 0, s, args);
     else
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, decltype(u_tag)::value, decltype(fill_tag)::value>),
-                         dim3((unsigned)total), dim3(64), 0, s, args);
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), 0, s, args);
   };
   auto with_fill = [&](auto u_tag) {
     if (fill) go(u_tag, std::true_type());

@@ -23,7 +23,7 @@ def _launch_info(fn, handle, dt, sizes, flags):
     _lib.call(fn, handle, dt, *sizes, int(flags), ctypes.byref(ints[0]), ctypes.byref(ints[1]),
               ctypes.byref(ints[2]), ctypes.byref(ints[3]), ctypes.byref(nb), ctypes.byref(lds),
               ctypes.byref(ints[4]))
-    return {"kernel": "tile" if ints[0].value else "sell", "j_per_block": ints[1].value,
+    return {"kernel": ("sell", "tile", "tile-dma")[ints[0].value], "j_per_block": ints[1].value,
             "rows_per_step": ints[2].value, "rows_per_block": ints[3].value, "n_blocks": nb.value,
             "lds_bytes": lds.value, "big_operator": bool(ints[4].value)}
 
@@ -163,11 +163,18 @@ class SparseOperator:
         return out
 
     def apply(self, x, y=None, masked=False, remap_area_min=0.0, out_dtype=np.float64,
-              flags=0, stream=None):
+              flags=0, stream=None, keep_batch_fastest=False):
         """Y = epilogue(fill(X) . W) for a device-resident X of shape (B, S), or (B, ldx) with a
-        padded row pitch ldx >= S (rows that start on 128-B lines are staged without straddling)."""
+        padded row pitch ldx >= S (rows that start on 128-B lines are staged without straddling).
+        A field tagged batch-fastest (`x.layout == "sb"`, shape (S, B)) goes through the batch-fastest
+        kernel (`apply_sb`); with keep_batch_fastest the result stays batch-fastest too, (D, B)."""
         if not isinstance(x, DeviceArray):
             raise TypeError("SparseOperator.apply takes a DeviceArray (use Regridder for host data)")
+        if x.layout == "sb":
+            return self.apply_sb(x, y=y, masked=masked, remap_area_min=remap_area_min, out_dtype=out_dtype,
+                                 flags=flags, stream=stream, keep_batch_fastest=keep_batch_fastest)
+        if keep_batch_fastest:
+            raise ValueError("keep_batch_fastest needs a batch-fastest field (DeviceArray(..., layout='sb'))")
         if x.ndim != 2 or x.shape[1] < self.n_src:
             raise ValueError(f"X must be (B, >= {self.n_src}), got {x.shape}")
         n_batch = x.shape[0]
@@ -194,25 +201,30 @@ class SparseOperator:
         return self
 
     def apply_sb(self, x, y=None, masked=False, remap_area_min=0.0, packed=False, out_dtype=np.float64,
-                 flags=0, stream=None):
+                 flags=0, stream=None, keep_batch_fastest=False):
         """The same product for a device-resident field kept batch-fastest: x of shape (S, B) -- or
         (n_used_src, B) with packed=True, rows in `used_sources()` order -- holds the B batch values
         of each source cell contiguously.  Y is (B, D) as `apply` returns it, bit-identical to
         ``apply`` on the transposed field; HBM traffic equals the algorithmic bytes because every
-        needed source cell is one contiguous run (smm_apply_sb)."""
+        needed source cell is one contiguous run (smm_apply_sb).  keep_batch_fastest: the result
+        stays batch-fastest as well -- Y (D, B), tagged layout "sb" -- which is what a following regrid
+        on the target grid consumes without any transpose (SMM_APPLY_SB_Y_SB)."""
         if not isinstance(x, DeviceArray):
             raise TypeError("SparseOperator.apply_sb takes a DeviceArray")
         rows = self.n_used_src if packed else self.n_src
         if x.ndim != 2 or x.shape[0] != rows:
             raise ValueError(f"X must be ({rows}, B), got {x.shape}")
         n_batch = x.shape[1]
+        y_shape = (self.n_dst, n_batch) if keep_batch_fastest else (n_batch, self.n_dst)
         if y is None:
-            y = DeviceArray((n_batch, self.n_dst), out_dtype)
-        elif y.shape != (n_batch, self.n_dst):
-            raise ValueError(f"Y must be ({n_batch}, {self.n_dst}), got {y.shape}")
+            y = DeviceArray(y_shape, out_dtype, layout="sb" if keep_batch_fastest else "bs")
+        elif y.shape != y_shape:
+            raise ValueError(f"Y must be {y_shape}, got {y.shape}")
         fl = int(flags) | (_lib.APPLY_MASKED if masked else 0) | (_lib.APPLY_SB_PACKED if packed else 0)
+        if keep_batch_fastest:
+            fl |= _lib.APPLY_SB_Y_SB
         _lib.call("smm_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), max(n_batch, 1),
-                  ctypes.c_void_p(y.ptr), dtype_code(y.dtype), self.n_dst, n_batch, float(remap_area_min), fl,
+                  ctypes.c_void_p(y.ptr), dtype_code(y.dtype), max(y_shape[1], 1), n_batch, float(remap_area_min), fl,
                   _stream_handle(stream))
         return y
 
@@ -335,22 +347,26 @@ class OperatorGroup:
         return y
 
     def apply_sb(self, x, level_index, masked_levels=None, y=None, masked=False, remap_area_min=0.0,
-                 transpose=True, out_dtype=np.float64, flags=0, stream=None):
+                 transpose=True, out_dtype=np.float64, flags=0, stream=None, keep_batch_fastest=False):
         """Masked levels for a field kept batch-fastest per level: x is a DeviceArray (n_lev, S, B) --
         per data level the B batch values of each source cell contiguous.  Returns (B, n_lev, D) when
-        transpose (regrid.py:420-427) else (n_lev, B, D); bit-identical to `apply` on the transposed field."""
+        transpose (regrid.py:420-427) else (n_lev, B, D); bit-identical to `apply` on the transposed field.
+        keep_batch_fastest: the result stays batch-fastest per level, (n_lev, D, B) tagged "sb"."""
         if not isinstance(x, DeviceArray) or x.ndim != 3 or x.shape[1] != self.n_src:
             raise ValueError(f"X must be a DeviceArray (n_lev, {self.n_src}, B)")
         n_lev, S, B = x.shape
         D = self.n_dst
         lev, ml = self._level_args(level_index, masked_levels, n_lev)
-        shape = (B, n_lev, D) if transpose else (n_lev, B, D)
-        ys_lev, ys_b = (D, n_lev * D) if transpose else (B * D, D)
+        if keep_batch_fastest:
+            shape, ys_lev, ys_b = (n_lev, D, B), D * max(B, 1), max(B, 1)
+        else:
+            shape = (B, n_lev, D) if transpose else (n_lev, B, D)
+            ys_lev, ys_b = (D, n_lev * D) if transpose else (B * D, D)
         if y is None:
-            y = DeviceArray(shape, out_dtype)
+            y = DeviceArray(shape, out_dtype, layout="sb" if keep_batch_fastest else "bs")
         elif y.shape != shape:
             raise ValueError(f"Y must be {shape}, got {y.shape}")
-        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
+        fl = int(flags) | (_lib.APPLY_MASKED if masked else 0) | (_lib.APPLY_SB_Y_SB if keep_batch_fastest else 0)
         _lib.call("smm_group_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), S * max(B, 1),
                   max(B, 1), ctypes.c_void_p(y.ptr), dtype_code(y.dtype), ys_lev, ys_b, B, n_lev, _cptr(lev),
                   _cptr(ml), float(remap_area_min), fl, _stream_handle(stream))

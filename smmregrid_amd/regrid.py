@@ -55,7 +55,7 @@ class Regridder(object):
                  method='con', remap_area_min=DEFAULT_AREA_MIN, transpose=True, mask_dim=None,
                  vertical_dim=None, horizontal_dims=None, cdo_extra=None, cdo_options=None,
                  check_nan=False, cdo='cdo', loglevel='WARNING', device=None, out_dtype=np.float64,
-                 lazy=False, prune_zero_weights=False):
+                 lazy=False, prune_zero_weights=False, keep_batch_fastest=False):
         if (source_grid is None or target_grid is None) and (weights is None):
             raise ValueError("Either weights or source_grid/target_grid must be supplied")
 
@@ -73,6 +73,11 @@ class Regridder(object):
         # opt-in: links of weight exactly 0 (3 of 4 bilinear links between aligned grids) are dropped when
         # the operators are built; results are bit-identical (SMM_CREATE_PRUNE_ZEROS)
         self.prune_zero_weights = bool(prune_zero_weights)
+        # Device-resident fields kept batch-fastest (`DeviceArray(..., layout="sb")`: horizontal
+        # dimensions first, e.g. (lat, lon, time)) run through the batch-fastest kernel; with
+        # keep_batch_fastest the result stays in that layout too -- (lat, lon, time) on the target grid,
+        # HBM-resident -- so a second Regridder consumes it without a transpose.
+        self.keep_batch_fastest = bool(keep_batch_fastest)
         # the reference always yields float64 (result_type(x, f64)); float32 is an opt-in narrowing store
         self.out_dtype = np.dtype(out_dtype)
         if self.out_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
@@ -319,6 +324,18 @@ class Regridder(object):
 
         src = source_data.data
         area_min, out_dtype = self.remap_area_min, self.out_dtype
+        sb_in = isinstance(src, DeviceArray) and src.layout == "sb"
+        if sb_in:
+            n_h = len(source_data.dims) - len(kept_dims)
+            if any(d not in horizontal_dims for d in source_data.dims[:n_h]):
+                raise ValueError("a batch-fastest field (layout='sb') carries its horizontal dimensions first, "
+                                 f"got dims {tuple(source_data.dims)}")
+        elif self.keep_batch_fastest:
+            raise ValueError("keep_batch_fastest needs a device-resident batch-fastest field "
+                             "(source_data.data = DeviceArray(..., layout='sb'))")
+        sb_out = sb_in and self.keep_batch_fastest
+        out_shape = (tgt_shape + kept_shape) if sb_out else (kept_shape + tgt_shape)
+        out_dims = (tgt_dims + kept_dims) if sb_out else (kept_dims + tgt_dims)
 
         def apply_rows(host):
             """(rows, S) host block -> (rows, D): chunks stream through the library's H2D / kernel /
@@ -332,6 +349,13 @@ class Regridder(object):
             return op.apply_host(host, masked=masked, remap_area_min=area_min, out_dtype=out_dtype)
 
         def compute():
+            if sb_in:
+                x = src.reshape(-1, n_batch)                  # (S, B): the batch values of a cell contiguous
+                if x.shape[0] != op.n_src:
+                    raise ValueError(f"source grid has {x.shape[0]} cells, weights expect {op.n_src}")
+                y = op.apply(x, masked=masked, remap_area_min=area_min, out_dtype=out_dtype,
+                             keep_batch_fastest=sb_out)
+                return y.reshape(*out_shape)
             if isinstance(src, DeviceArray):
                 x = src.reshape(n_batch, -1)
                 if x.shape[1] != op.n_src:
@@ -346,11 +370,11 @@ class Regridder(object):
             out_data = map_batch_blocks(src, len(source_data.dims) - len(kept_dims), tgt_shape, apply_rows,
                                         dtype=out_dtype)
         elif self.lazy:
-            out_data = LazyArray(kept_shape + tgt_shape, out_dtype, compute)
+            out_data = LazyArray(out_shape, out_dtype, compute)
         else:
             out_data = compute()
 
-        return self._finish(out_data, kept_dims + tgt_dims, source_data, kept_dims, weights,
+        return self._finish(out_data, out_dims, source_data, kept_dims, weights,
                             tgt_shape, tgt_dims)
 
     # ------------------------------------------------------------------ apply (masked levels)
@@ -404,8 +428,29 @@ class Regridder(object):
         src = source_data.data
         S, D = group.n_src, group.n_dst
         area_min, out_dtype, transpose = self.remap_area_min, self.out_dtype, self.transpose
+        sb_in = isinstance(src, DeviceArray) and src.layout == "sb"
+        if sb_in:
+            # batch-fastest per level: (mask_dim, horizontal..., everything else...)
+            n_h = len(source_data.dims) - len(kept_dims)
+            if source_data.dims[0] != mask_dim or any(d not in horizontal_dims for d in source_data.dims[1:1 + n_h]):
+                raise ValueError("a batch-fastest masked field (layout='sb') is laid out (mask_dim, horizontal "
+                                 f"dims..., other dims...), got dims {tuple(source_data.dims)}")
+        elif self.keep_batch_fastest:
+            raise ValueError("keep_batch_fastest needs a device-resident batch-fastest field "
+                             "(source_data.data = DeviceArray(..., layout='sb'))")
+        sb_out = sb_in and self.keep_batch_fastest
+        if sb_out:
+            out_dims = [mask_dim] + tgt_dims + rest_dims
+            out_shape = [n_lev] + tgt_shape + rest_shape
 
         def compute():
+            if sb_in:
+                x = src.reshape(n_lev, -1, n_outer * n_inner)
+                if x.shape[1] != S:
+                    raise ValueError(f"source grid has {x.shape[1]} cells, weights expect {S}")
+                y = group.apply_sb(x, level_index, masked_levels, masked=any_masked, remap_area_min=area_min,
+                                   transpose=transpose, out_dtype=out_dtype, keep_batch_fastest=sb_out)
+                return y.reshape(*out_shape)
             if isinstance(src, DeviceArray):
                 x = src.reshape(n_outer, n_lev, n_inner, -1)
                 y = group.apply(x, level_index, masked_levels, masked=any_masked, remap_area_min=area_min,

@@ -98,9 +98,9 @@ def test_config5_production_walk(hip):
 
 def test_config4_geometry_f32(hip):
     """Gaussian n1280 (5120x2560) -> HEALPix nside 1024, 50 M links, f32 in / f64 out: the paths
-    only this geometry takes -- an operator larger than L2 (walks of 128 batch rows), multi-row
-    steps on its small tiles, the tightened tile budget with the widest blocks demoted to direct
-    gathers."""
+    only this geometry takes -- an operator larger than L2 (walks of 128 batch rows), LDS-DMA staging
+    (or multi-row register steps) on its small tiles, the tightened tile budget with the widest blocks
+    demoted to direct gathers."""
     w = gridgen.generate_weights("n1280", "hp1024", method="bil")
     assert (w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w.sizes["num_links"]) == \
         (13107200, 12582912, 50331648)
@@ -111,11 +111,17 @@ def test_config4_geometry_f32(hip):
     assert 0 < plan["lds_bytes"] <= 32768
     B = 130                                                    # one full walk of 128 rows + a ragged one
     info = op.launch_info(B, np.float32)
-    assert info["kernel"] == "tile" and info["big_operator"] and info["j_per_block"] == 128
-    assert info["rows_per_step"] > 1                           # multi-row steps (R = 2 or 4)
+    # small tiles of a 16-B aligned field: staged by LDS-DMA into a ring of two slots, single-row steps
+    assert info["kernel"] == "tile-dma" and info["big_operator"] and info["j_per_block"] == 128
+    assert info["rows_per_step"] == 1 and info["lds_bytes"] <= 16384
     x, host = _device_field(B, op.n_src, np.float32, 13, poke_rows=[1, 129])
     y = _check_2d(op, x, host, [0, 1, 127, 128, 129], False, 0.0, None, None)
     assert y.dtype == np.float64                               # result_type(f32, f64), regrid.py:550
+    # register staging with multi-row steps (R = 2 or 4) serves fields that are not 16-B aligned and is
+    # what tuning variant 8 forces: same bits
+    info8 = op.launch_info(B, np.float32, flags=8 << 16)
+    assert info8["kernel"] == "tile" and info8["rows_per_step"] > 1
+    _assert_device_equal(op.apply(x, flags=8 << 16), y)
     # a short batch takes the same kernels with a clipped walk
     x8 = x.rows(0, 8)
     y8 = op.apply(x8)

@@ -37,7 +37,8 @@ def test_sb_random_matrix(hip, rng, dtype, packed):
         x = field(rng, n_batch, n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.004)
         for masked, amin in [(False, 0.0), (True, 0.0), (True, 0.5), (False, 0.9)]:
             y = run_sb(op, x, masked, amin, packed)
-            assert_same(y, oracle.apply_c(csr, x, masked, imask, frac, amin), exact=True)
+            ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
+            assert_same(y, ref, exact=True)
 
 
 def test_sb_ragged_and_empty_rows(hip, rng):
@@ -215,3 +216,93 @@ def test_group_host_pipeline_packs_per_level(hip, rng, transpose):
         y = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.4, transpose=transpose,
                            flags=_lib.APPLY_HOST_NO_PACK)
         assert_same(y, ref, exact=True)
+
+
+# ------------------------------------------------------------------ results kept batch-fastest (SMM_APPLY_SB_Y_SB)
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sb_result_kept_batch_fastest(hip, rng, dtype):
+    """Y (D, B): the transpose of what smm_apply_sb / smm_apply write, bit for bit -- every batch size
+    around the 128-entry tile and the odd tails, packed and whole fields, f32 store, row pitches."""
+    n_src, n_dst = 3000, 517
+    src, dst, w = random_links(rng, n_src, n_dst, 5000)
+    op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+    csr = op.export_csr()
+    imask = (rng.random(n_dst) > 0.2).astype(np.int32)
+    frac = rng.random(n_dst)
+    op.set_epilogue(imask, frac)
+    for n_batch in (1, 2, 3, 64, 127, 128, 129, 301):
+        x = field(rng, n_batch, n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.004)
+        xt = np.ascontiguousarray(x.T)
+        for masked, amin in [(False, 0.0), (True, 0.5)]:
+            ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
+            y = op.apply_sb(to_device(xt), masked=masked, remap_area_min=amin, keep_batch_fastest=True)
+            assert y.shape == (n_dst, n_batch) and y.layout == "sb"
+            assert_same(y.to_host().T, ref, exact=True)
+        yp = op.apply_sb(to_device(np.ascontiguousarray(xt[op.used_sources()])), packed=True, keep_batch_fastest=True)
+        assert_same(yp.to_host().T, oracle.apply_c(csr, x), exact=True)
+        y32 = op.apply_sb(to_device(xt), out_dtype=np.float32, keep_batch_fastest=True).to_host()
+        assert y32.dtype == np.float32
+        assert_same(y32.T, oracle.apply_c(csr, x).astype(np.float32), exact=True)
+    # odd pitches on both sides: 16-B accesses are element aligned only; the padding stays untouched
+    B, ldx, ldy = 50, 57, 53
+    x = field(rng, B, n_src, dtype=dtype)
+    xw = np.full((n_src, ldx), np.nan, dtype=dtype)
+    xw[:, :B] = x.T
+    yw = np.full((n_dst, ldy), -7.0)
+    dx, dy = to_device(xw), to_device(yw)
+    _lib.call("smm_apply_sb", op.handle, ctypes.c_void_p(dx.ptr), _lib.SMM_F64 if dtype == np.float64 else _lib.SMM_F32,
+              ldx, ctypes.c_void_p(dy.ptr), _lib.SMM_F64, ldy, B, 0.0, _lib.APPLY_SB_Y_SB, None)
+    got = dy.to_host()
+    assert_same(got[:, :B].T, oracle.apply_c(csr, x), exact=True)
+    assert (got[:, B:] == -7.0).all()
+    with pytest.raises(_lib.SmmError):               # ldy must hold a batch now, not a destination row
+        _lib.call("smm_apply_sb", op.handle, ctypes.c_void_p(dx.ptr), _lib.SMM_F64, ldx, ctypes.c_void_p(dy.ptr),
+                  _lib.SMM_F64, B - 1, B, 0.0, _lib.APPLY_SB_Y_SB, None)
+
+
+def test_chain_of_regrids_stays_batch_fastest(hip, rng):
+    """r144x72 -> r72x36 -> r24x12 on a device-resident batch-fastest field: the first result feeds the
+    second operator as it is, and `SparseOperator.apply` routes by the layout tag."""
+    w1 = gridgen.generate_weights("r144x72", "r72x36", method="con")
+    w2 = gridgen.generate_weights("r72x36", "r24x12", method="bil")
+    ops = []
+    for w in (w1, w2):
+        op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                            w["dst_address"].values, w["remap_matrix"].values, device=0)
+        op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
+        ops.append(op)
+    x = field(rng, 45, ops[0].n_src, nan_frac=0.01)
+    mid = oracle.apply_c(ops[0].export_csr(), x, False, None, w1["dst_grid_frac"].values, 0.5)
+    ref = oracle.apply_c(ops[1].export_csr(), mid, False, None, w2["dst_grid_frac"].values, 0.5)
+    x_sb = to_device(np.ascontiguousarray(x.T), layout="sb")
+    y1 = ops[0].apply(x_sb, remap_area_min=0.5, keep_batch_fastest=True)          # routed by the tag
+    assert y1.layout == "sb" and y1.shape == (ops[0].n_dst, 45)
+    y2 = ops[1].apply(y1, remap_area_min=0.5)                                     # (B, D) out at the end
+    assert y2.layout == "bs" and y2.shape == (45, ops[1].n_dst)
+    assert_same(y2.to_host(), ref, exact=True)
+    with pytest.raises(ValueError):                  # a native-layout field cannot keep a layout it is not in
+        ops[0].apply(to_device(x), keep_batch_fastest=True)
+
+
+def test_group_result_kept_batch_fastest(hip, rng):
+    S, D, n_ops, B = 2500, 300, 3, 70
+    ops, csrs = [], []
+    imask = (rng.random((n_ops, D)) > 0.3).astype(np.int32)
+    frac = rng.random((n_ops, D))
+    for i in range(n_ops):
+        src, dst, w = random_links(rng, S, D, 2000 + 500 * i)
+        op = SparseOperator(S, D, src, dst, w, device=0)
+        op.set_epilogue(imask[i], frac[i])
+        ops.append(op)
+        csrs.append(op.export_csr())
+    from smmregrid_amd import OperatorGroup
+    grp = OperatorGroup(ops)
+    level_index = [2, 0, 1, 2]
+    masked_levels = np.array([1, 0, 1], np.uint8)
+    x = field(rng, B * 4, S, nan_frac=0.03).reshape(B, 4, S)                       # (B, L, S) for the oracle
+    ref = oracle.apply_levels(csrs, x, 1, np.asarray(level_index), masked_levels.astype(bool), imask, frac, 0.4, True)
+    x_sb = to_device(np.ascontiguousarray(x.transpose(1, 2, 0)), layout="sb")      # (L, S, B)
+    y = grp.apply_sb(x_sb, level_index, masked_levels, masked=True, remap_area_min=0.4, keep_batch_fastest=True)
+    assert y.shape == (4, D, B) and y.layout == "sb"
+    assert_same(y.to_host().transpose(2, 0, 1), ref, exact=True)                   # (B, L, D)

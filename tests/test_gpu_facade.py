@@ -507,3 +507,79 @@ def test_masked_source_with_pointwise_methods(hip, rng, method):
         assert not np.isnan(out).any()                         # nearest unmasked cell always exists
     ref = oracle_2d(w, x.reshape(3, -1))
     assert_same(out.reshape(3, -1), ref, exact=True)
+
+
+# ------------------------------------------------------------------ batch-fastest device fields through the facade
+
+def test_facade_routes_batch_fastest_device_fields(hip, rng):
+    """A device-resident field laid out (lat, lon, time) -- DeviceArray(layout="sb") -- runs through the
+    batch-fastest kernel; the result is the reference's (time, lat, lon) and bit-equal to the oracle.
+    With keep_batch_fastest=True it stays (lat, lon, time) in HBM and a second Regridder consumes it."""
+    src = gridgen.parse_grid("r96x48")
+    w1 = CdoGenerate("r96x48", "r36x18").weights(method="bil")
+    w2 = CdoGenerate("r36x18", "r12x6").weights(method="con")
+    nt = 21
+    x = 250.0 + 30.0 * rng.standard_normal((nt, 48, 96))
+    x[3, 10:14, 20:30] = np.nan
+    ref1 = oracle_2d(w1, x.reshape(nt, -1))
+    xt = np.ascontiguousarray(x.transpose(1, 2, 0))                                 # (lat, lon, time)
+    fld = DataArray(to_device(xt, layout="sb"), dims=("lat", "lon", "time"),
+                    coords={"time": np.arange(nt), "lat": src.lat, "lon": src.lon}, name="tas")
+    out = Regridder(weights=w1).regrid(fld)
+    assert out.dims == ("time", "lat", "lon") and out.shape == (nt, 18, 36)
+    assert_same(out.values.reshape(nt, -1), ref1, exact=True)
+    assert np.array_equal(out.coords["time"].values, np.arange(nt))
+
+    rg1 = Regridder(weights=w1, keep_batch_fastest=True)
+    mid = rg1.regrid(fld)
+    assert mid.dims == ("lat", "lon", "time") and mid.shape == (18, 36, nt)
+    assert mid.data.layout == "sb"                                                  # still in HBM, still batch-fastest
+    assert_same(mid.values.transpose(2, 0, 1).reshape(nt, -1), ref1, exact=True)
+    out2 = Regridder(weights=w2).regrid(mid)                                        # consumes it without a transpose
+    assert out2.dims == ("time", "lat", "lon") and out2.shape == (nt, 6, 12)
+    assert_same(out2.values.reshape(nt, -1), oracle_2d(w2, ref1), exact=True)
+
+    with pytest.raises(ValueError):                                                 # horizontal dims must lead
+        Regridder(weights=w1).regrid(DataArray(to_device(x, layout="sb"), dims=("time", "lat", "lon"),
+                                               coords={"lat": src.lat, "lon": src.lon}, name="tas"))
+    with pytest.raises(ValueError):                                                 # nothing to keep for host fields
+        rg1.regrid(DataArray(x, dims=("time", "lat", "lon"), coords={"lat": src.lat, "lon": src.lon}, name="tas"))
+
+
+def test_facade_batch_fastest_masked_levels(hip, rng):
+    """(lev, lat, lon, time) device field through regrid3d: one batch-fastest launch per level, results in
+    the reference's order (time, lev, lat, lon) / (lev, time, lat, lon), or kept (lev, lat, lon, time)."""
+    g = gridgen.parse_grid("r72x36")
+    nlev, nt = 4, 9
+    masks = gridgen.synthetic_ocean_masks(72, 36, nlev, top=0.8, bottom=0.3)
+    x = 3.0 + rng.standard_normal((nt, nlev, 36, 72))
+    for lv in range(nlev):
+        x[:, lv].reshape(nt, -1)[:, masks[lv] == 0] = np.nan
+    coords = {"time": np.arange(nt), "lev": np.arange(nlev, dtype=float), "lat": g.lat, "lon": g.lon}
+    host = DataArray(x, dims=("time", "lev", "lat", "lon"), coords=coords, name="thetao")
+    rg = Regridder(source_grid=Dataset({"thetao": host}), target_grid="r24x12", mask_dim="lev")
+    want = rg.regrid(host).values                                                   # (time, lev, lat, lon)
+    dev = DataArray(to_device(np.ascontiguousarray(x.transpose(1, 2, 3, 0)), layout="sb"),
+                    dims=("lev", "lat", "lon", "time"), coords=coords, name="thetao")
+    got = rg.regrid(dev)
+    assert got.dims == ("time", "lev", "lat", "lon")
+    assert_same(got.values, want, exact=True)
+    rg.keep_batch_fastest = True
+    kept = rg.regrid(dev)
+    assert kept.dims == ("lev", "lat", "lon", "time") and kept.data.layout == "sb"
+    assert_same(kept.values.transpose(3, 0, 1, 2), want, exact=True)
+
+
+def test_pitched_upload_helper(hip, rng):
+    """to_device_pitched: rows on 128-B lines (what the tile kernels like); same bits as a packed field."""
+    from smmregrid_amd import SparseOperator
+    from smmregrid_amd.device import aligned_pitch, to_device_pitched
+    assert aligned_pitch(1442 * 1021, np.float64) == 1472288 and aligned_pitch(64, np.float32) == 64
+    w = gridgen.conservative_weights("r145x73", "r36x18")                            # S = 10585: rows start mid-line
+    op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                        w["dst_address"].values, w["remap_matrix"].values, device=0)
+    for dtype in (np.float64, np.float32):
+        x = (250.0 + rng.standard_normal((11, op.n_src))).astype(dtype)
+        xp = to_device_pitched(x)
+        assert xp.shape == (11, aligned_pitch(op.n_src, dtype)) and xp.shape[1] % (128 // x.itemsize) == 0
+        assert_same(op.apply(xp).to_host(), op.apply(to_device(x)).to_host(), exact=True)
