@@ -81,6 +81,8 @@ WORKLOADS = {
     "scatter": ("bilperm", "r1440x721", "r360x180", 1024, "f64"),
     # config-4 geometry (regular Gaussian n1280 = 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch
     "cfg4s": ("bil", "n1280", "hp1024", 128, "f32"),
+    # the same with the opt-in narrowing store (y_dtype = SMM_F32; the reference always yields f64, regrid.py:550)
+    "cfg4sf32": ("bil", "n1280", "hp1024", 128, "f32", "bs+y32"),
     "cfg4": ("bil", "n1280", "hp1024", 1095, "f32"),              # one GPU's share of config 4 (8760 / 8)
     # one masked level of config 3 as a 2-D problem (ocean fraction in the name), for kernel tuning
     "cfg3L66": ("conmask", (1442, 1021, 0.66), "r360x180", 1024, "f64"),
@@ -146,7 +148,9 @@ class Problem2D:
         from smmregrid_amd.device import DeviceArray
         method, sgrid, tgrid, n_batch, self.x_dtype = WORKLOADS[name][:5]
         self.layout = WORKLOADS[name][5] if len(WORKLOADS[name]) > 5 else "bs"
-        self.prune = self.layout.endswith("+z")
+        opts = self.layout.split("+")[1:]
+        self.prune = "z" in opts
+        self.y_dt = np.float32 if "y32" in opts else np.float64     # f64 = the reference's result_type(x, f64)
         self.layout = self.layout.split("+")[0]
         self.n_batch = batch or n_batch
         if method == "conmask":
@@ -177,7 +181,7 @@ class Problem2D:
         lay = {"bs": "X (B, S) native layout", "sb": "X (S, B) batch-fastest", "sbp": "X (U, B) batch-fastest, used cells only",
                "sbk": "X (S, B) batch-fastest"}
         self.desc = (f"{name}: {sgrid}->{tgrid} {method}, {self.n_batch} batch rows per GPU, "
-                     f"{self.x_dtype} in / f64 out, {lay[self.layout]}, "
+                     f"{self.x_dtype} in / {'f32' if self.y_dt == np.float32 else 'f64'} out, {lay[self.layout]}, "
                      f"{'Y (D, B) kept batch-fastest' if self.layout == 'sbk' else 'Y (B, D)'}, X and Y resident in HBM")
         self.meta = {"S": self.n_src, "D": self.n_dst, "nnz": self.op.nnz, "U": self.op.n_used_src,
                      "plan": self.op.plan_info()}
@@ -194,10 +198,11 @@ class Problem2D:
         return float(self.n_dst) * self.n_batch
 
     def alg_bytes(self):
-        return algorithmic_bytes(self.op, self.n_batch, np.dtype(self.np_dt).itemsize, 8)
+        return algorithmic_bytes(self.op, self.n_batch, np.dtype(self.np_dt).itemsize, np.dtype(self.y_dt).itemsize)
 
     def full_stream_bytes(self):
-        return self.n_batch * (self.n_src * np.dtype(self.np_dt).itemsize + self.n_dst * 8) + self.op.nnz * 12
+        return (self.n_batch * (self.n_src * np.dtype(self.np_dt).itemsize + self.n_dst * np.dtype(self.y_dt).itemsize)
+                + self.op.nnz * 12)
 
     def line_bytes(self):
         """Bytes of the whole 128-B source lines the links touch (what any kernel must move
@@ -207,7 +212,8 @@ class Problem2D:
         staged = self.op.plan_info()["staged_src_elems"]
         if not staged:
             return None
-        return self.n_batch * (staged * np.dtype(self.np_dt).itemsize + self.n_dst * 8) + self.op.nnz * 12
+        return (self.n_batch * (staged * np.dtype(self.np_dt).itemsize + self.n_dst * np.dtype(self.y_dt).itemsize)
+                + self.op.nnz * 12)
 
     def run(self, y, flags):
         if self.layout == "bs":
@@ -252,6 +258,7 @@ class Problem2D:
                                   (rm[:, 0] if rm.ndim == 2 else rm)[keep])
         ref = oracle.apply_c(csr, xrow[None, :], False, None, w["dst_grid_frac"].values[:n_chk], 0.5)[0]
         got = got[:n_chk]
+        ref = ref.astype(got.dtype)              # an f32 store is the rounded f64 result
         same = np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])
         return {"batch_row": int(r), "cells": n_chk, "bit_equal_to_oracle": bool(same)}
 
@@ -750,7 +757,8 @@ def run_others(args, names, local_rank, flags, t_start):
                 prob = (ProblemLevels if levels else Problem2D)(name, local_rank, 0)
                 if levels:
                     shared["levels"] = prob
-            y = DeviceArray(prob.y_shape, np.float64, layout="sb" if getattr(prob, "layout", "") == "sbk" else "bs")
+            y = DeviceArray(prob.y_shape, getattr(prob, "y_dt", np.float64),
+                            layout="sb" if getattr(prob, "layout", "") == "sbk" else "bs")
             for _ in range(3):
                 prob.run(y, flags)
             synchronize()
@@ -818,7 +826,7 @@ def main():
         set_device(local_rank)
         cls = ProblemLevels if WORKLOADS[args.workload][0] == "con3d" else Problem2D
         prob = cls(args.workload, local_rank, rank, batch=args.batch)
-        y = DeviceArray(prob.y_shape, np.float64)
+        y = DeviceArray(prob.y_shape, getattr(prob, "y_dt", np.float64))
         flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
         flags |= (args.variant << 16) | (args.jpb << 20)
         new_event, dev_name = Event, device_name(local_rank)

@@ -271,7 +271,9 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_
   plan.n_blocks = n_blocks;
   plan.blk_chunk_off.assign((size_t)n_blocks + 1, 0);
   plan.blk_direct.assign((size_t)n_blocks, 0);
+  plan.blk_lines.assign((size_t)n_blocks, 0);
   plan.lcol.assign((size_t)sell.n_slots, 0);
+  constexpr int32_t kLineElems = 16;   // a 128-B line of f64
 
   std::vector<int32_t> chunks, cols;
   for (int64_t b = 0; b < n_blocks; ++b) {
@@ -295,6 +297,17 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_
       continue;
     }
     plan.max_block_chunks = std::max(plan.max_block_chunks, (int64_t)chunks.size());
+    {
+      int32_t lines = 0, last = -1;
+      for (int32_t c : cols) {
+        if (c / kLineElems != last) {
+          last = c / kLineElems;
+          ++lines;
+        }
+      }
+      plan.blk_lines[(size_t)b] = lines;
+      plan.total_lines += lines;
+    }
     const int64_t base = (int64_t)plan.chunk_src.size();
     plan.chunk_src.insert(plan.chunk_src.end(), chunks.begin(), chunks.end());
     plan.blk_chunk_off[(size_t)b + 1] = base + (int64_t)chunks.size();
@@ -353,6 +366,8 @@ int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_b
     if (o1 - o0 > chosen) {
       plan.blk_direct[(size_t)b] = 1;
       plan.direct_links += block_links(b);
+      plan.total_lines -= plan.blk_lines[(size_t)b];
+      plan.blk_lines[(size_t)b] = 0;
     } else {
       kept.insert(kept.end(), plan.chunk_src.begin() + o0, plan.chunk_src.begin() + o1);
       new_max = std::max(new_max, o1 - o0);

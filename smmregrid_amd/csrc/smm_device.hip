@@ -159,7 +159,7 @@ struct smm_operator {
   // create time, the others on demand when it joins a group of another shape.
   struct TilePlan {
     bool built = false, valid = false;
-    int64_t max_chunks = 0, total_chunks = 0;
+    int64_t max_chunks = 0, total_chunks = 0, total_lines = 0;
     bool preferred = false;  // staged lines are used well enough to beat direct gathers
     bool reuse = false;      // some staged lines are shared by several blocks (keep them cacheable)
     int64_t* d_blk_chunk_off = nullptr;
@@ -296,12 +296,13 @@ int ensure_plan(smm_operator* op, int which) {
   pl.valid = true;
   pl.max_chunks = hp.max_block_chunks;
   pl.total_chunks = hp.total_chunks;
+  pl.total_lines = hp.total_lines;
   pl.reuse = hp.total_chunks * 50 > hp.distinct_chunks * 51;  // > 2 % of lines staged twice
   // at least a tenth of every staged 128-B line is consumed: the lines are the ones a gather would
   // fetch anyway, and staging fetches them coalesced (r3600x1800 -> r360x180 bilinear uses 20 %:
   // tile 0.48 ms, SELL 0.64 ms; HEALPix-nested source, nearest neighbour, 14 %: 1.87 vs 2.10 ms;
   // r3600x1800 nearest neighbour, 10 %: equal)
-  pl.preferred = hp.total_distinct * 10 >= hp.total_chunks * (int64_t)hp.chunk_elems;
+  pl.preferred = hp.total_distinct * 10 >= hp.total_lines * 16;
   return SMM_OK;
 }
 
@@ -916,7 +917,7 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
   if (kernel_kind)
     *kernel_kind = (pl.valid ? 1 : 0) | (pl.preferred ? 2 : 0) | (shape_rows(op->native_plan()) << 8);
   if (lds_bytes) *lds_bytes = pl.valid ? pl.max_chunks * kChunkElems * 8 : 0;
-  if (staged_src_elems) *staged_src_elems = pl.valid ? pl.total_chunks * kChunkElems : 0;
+  if (staged_src_elems) *staged_src_elems = pl.valid ? pl.total_lines * 16 : 0;   // whole 128-B lines of f64
   return SMM_OK;
 }
 

@@ -54,7 +54,9 @@ void build_sell(const HostCsr& csr, HostSell& out);
 // blocks of `rows_per_block` consecutive rows (4 SELL slices, 1 slice, or 1/2, 1/4, 1/8 of a slice
 // for rows whose footprint is wide); the distinct source cells a block
 // references are covered by aligned chunks of `chunk_elems` source elements
-// (one chunk = one 128-B line of f64).  The kernel copies a block's chunks to
+// (4 elements: 32 B of f64, one 16-B staging piece of f32 -- the L2 fetches whole 128-B lines whatever
+// is staged, but fine chunks keep rows that do not start on a line boundary, and sparse stencils, from
+// staging and straddling lines they do not need).  The kernel copies a block's chunks to
 // LDS in list order with 16-B-per-lane coalesced loads, so LDS element
 // (c*chunk_elems + e) holds source element chunk_src[c]*chunk_elems + e, and
 // the block's links address LDS through lcol.
@@ -64,7 +66,10 @@ struct HostTilePlan {
   int32_t chunk_elems = 0;
   int64_t n_blocks = 0;
   int64_t max_block_chunks = 0;       // largest chunk count of any block
-  int64_t total_chunks = 0;           // sum over blocks = staged lines per batch row
+  int64_t total_chunks = 0;           // sum over blocks = staged chunks per batch row
+  int64_t total_lines = 0;            // sum over staged blocks of the distinct 16-element groups (128-B lines of
+                                      // f64) their chunks touch: what HBM moves per batch row
+  std::vector<int32_t> blk_lines;     // n_blocks: that count per block
   int64_t total_distinct = 0;         // sum over blocks of distinct source cells referenced
   int64_t distinct_chunks = 0;        // distinct source chunks over the whole operator
   int64_t direct_links = 0;           // links of blocks too wide to stage (gathered from X directly)

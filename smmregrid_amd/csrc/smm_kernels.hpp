@@ -84,10 +84,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging
 typedef u32x4 u32x4_t;
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * 64;
+// Granularity of the tile plan's staged chunks.  4 elements = 32 B of f64, one 16-B staging piece of f32.
+// Measured against 16 (whole 128-B lines of f64), same box: config 3 with its rows packed back to back
+// (S * 8 B = 80 mod 128: every row starts mid-line) 12.84 -> 11.49 ms, on 128-B lines 11.45 -> 11.26,
+// config 2 2.88 -> 2.69, the others level; 2 elements (f64 only) another 2 % on packed rows.
 #ifndef SMM_CHUNK_ELEMS
-#define SMM_CHUNK_ELEMS 16
+#define SMM_CHUNK_ELEMS 4
 #endif
-constexpr int kChunkElems = SMM_CHUNK_ELEMS;               // staged chunk: 128 B of f64, 64 B of f32
+constexpr int kChunkElems = SMM_CHUNK_ELEMS;
+static_assert(SMM_CHUNK_ELEMS >= 4 && (SMM_CHUNK_ELEMS & (SMM_CHUNK_ELEMS - 1)) == 0, "a chunk holds at least one 16-B piece of f32");
 constexpr int64_t kTileMaxChunks = 8192 / SMM_CHUNK_ELEMS;  // 64 KiB of f64 per staged batch row
 
 template <typename T>

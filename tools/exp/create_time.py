@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from bench import WORKLOADS
 from smmregrid_amd import SparseOperator, gridgen
 for name in sys.argv[1:]:
-    method, sgrid, tgrid, _, _ = WORKLOADS[name]
+    method, sgrid, tgrid, _, _ = WORKLOADS[name][:5]
     t = time.time(); w = gridgen.generate_weights(sgrid, tgrid, method=method); tg = time.time() - t
     t = time.time()
     op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
