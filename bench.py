@@ -823,6 +823,14 @@ def main():
     else:
         from smmregrid_amd import _lib
         from smmregrid_amd.device import DeviceArray, Event, device_name, set_device, synchronize
+        n_dev = _lib.device_count()
+        if n_dev <= 0:
+            raise SystemExit("bench.py: no HIP device (there is no CPU fallback; --dry-run exercises the plumbing)")
+        if local_rank >= n_dev:
+            if not os.environ.get("SMM_BENCH_SHARE_GPUS"):
+                raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({n_dev} visible): one rank per GPU "
+                                 "(SMM_BENCH_SHARE_GPUS=1 lets ranks share devices for a rehearsal)")
+            local_rank %= n_dev              # rehearsal on a smaller box: ranks share devices, RCCL will refuse
         set_device(local_rank)
         cls = ProblemLevels if WORKLOADS[args.workload][0] == "con3d" else Problem2D
         prob = cls(args.workload, local_rank, rank, batch=args.batch)
