@@ -95,7 +95,11 @@ WORKLOADS = {
     "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "pad"),
     "cfg3c": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
     # config 3 with the field kept batch-fastest per level, X (L, S, T) (smm_group_apply_sb)
+    # (kernel D stages every cell's 16-entry run: cells start on 128-B lines with the pitch T rounded up to 16;
+    # "cfg3sbc": pitch T itself -- 120 entries = 960 B, every other run straddles a line)
     "cfg3sb": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "sb"),
+    "cfg3sbc": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "sbc"),
+    "cfg3sbs": ("con3d", (1442, 1021), "r360x180", (120, 6), "f64", "sb"),      # six levels of it: quick runs
     "cfg3s": ("con3d", (1442, 1021), "r360x180", (16, 8), "f64"),
 }
 
@@ -361,7 +365,7 @@ class ProblemLevels:
         slab = (10.0 + 5.0 * rng.standard_normal((n_lev, self.n_src), dtype=np.float32)).astype(np.float64)
         slab[masks == 0] = np.nan
         self.slab, self.masks = slab, masks
-        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "sb" else "bs"
+        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] in ("sb", "sbc") else "bs"
         self.nx, self.ny, self.tgrid = nx, ny, tgrid
         self.y_shape = (self.n_t, 1, n_lev, self.n_dst)
         self.np_dt = np.float64
@@ -384,10 +388,11 @@ class ProblemLevels:
         nx, ny, tgrid = self.nx, self.ny, self.tgrid
         ldx = -(-self.n_src // 16) * 16 if self.padded else self.n_src
         if self.layout == "sb":
-            # X (L, S, T): every time step carries the same slab, so a cell's T values are one constant
-            self.x = DeviceArray((n_lev, self.n_src, self.n_t), np.float64)
+            # X (L, S, pitch >= T): every time step carries the same slab, so a cell's T values are one constant
+            self.ldt = self.n_t if WORKLOADS[name][5] == "sbc" else -(-self.n_t // 16) * 16
+            self.x = DeviceArray((n_lev, self.n_src, self.ldt), np.float64)
             for lv in range(n_lev):
-                self.x.rows(lv, lv + 1).copy_from_host(np.repeat(slab[lv][:, None], self.n_t, axis=1)[None])
+                self.x.rows(lv, lv + 1).copy_from_host(np.repeat(slab[lv][:, None], self.ldt, axis=1)[None])
         else:
             self.x = DeviceArray((self.n_t, n_lev, 1, ldx), np.float64)
             first = np.zeros((1, n_lev, 1, ldx))
@@ -398,7 +403,7 @@ class ProblemLevels:
                           ctypes.c_void_p(self.x.ptr), first.nbytes, None)
         self.desc = (f"{name}: {nx}x{ny} tripolar-like -> {tgrid} conservative, {self.n_t} time steps x "
                      f"{n_lev} masked levels per GPU, f64, remap_area_min 0.5, grouped launch, "
-                     + ("X (L, S, T) batch-fastest per level" if self.layout == "sb" else
+                     + (f"X (L, S, pitch {getattr(self, 'ldt', 0)}) batch-fastest per level" if self.layout == "sb" else
                         "X (T, L, S) " + (f"with rows on 128-B lines (pitch {ldx})" if self.padded else "packed")))
 
     def spot_check(self, y):
@@ -452,7 +457,7 @@ class ProblemLevels:
     def run(self, y, flags):
         if self.layout == "sb":
             self.group.apply_sb(self.x, self.level_index, self.masked_levels, y=y.reshape(self.n_t, self.n_lev, self.n_dst),
-                                masked=True, remap_area_min=0.5, transpose=True, flags=flags)
+                                masked=True, remap_area_min=0.5, transpose=True, flags=flags, n_batch=self.n_t)
             return
         self.group.apply(self.x, self.level_index, self.masked_levels, y=y, masked=True,
                          remap_area_min=0.5, transpose=True, flags=flags)

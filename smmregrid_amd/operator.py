@@ -201,20 +201,25 @@ class SparseOperator:
         return self
 
     def apply_sb(self, x, y=None, masked=False, remap_area_min=0.0, packed=False, out_dtype=np.float64,
-                 flags=0, stream=None, keep_batch_fastest=False):
+                 flags=0, stream=None, keep_batch_fastest=False, n_batch=None):
         """The same product for a device-resident field kept batch-fastest: x of shape (S, B) -- or
         (n_used_src, B) with packed=True, rows in `used_sources()` order -- holds the B batch values
         of each source cell contiguously.  Y is (B, D) as `apply` returns it, bit-identical to
         ``apply`` on the transposed field; HBM traffic equals the algorithmic bytes because every
         needed source cell is one contiguous run (smm_apply_sb).  keep_batch_fastest: the result
         stays batch-fastest as well -- Y (D, B), tagged layout "sb" -- which is what a following regrid
-        on the target grid consumes without any transpose (SMM_APPLY_SB_Y_SB)."""
+        on the target grid consumes without any transpose (SMM_APPLY_SB_Y_SB).  n_batch: batch entries
+        when the last axis of x is a padded pitch (cells that start on 128-B lines -- a pitch of a multiple
+        of 16 doubles -- are what the cell-staging kernel likes: every 16-entry run is then one line)."""
         if not isinstance(x, DeviceArray):
             raise TypeError("SparseOperator.apply_sb takes a DeviceArray")
         rows = self.n_used_src if packed else self.n_src
         if x.ndim != 2 or x.shape[0] != rows:
             raise ValueError(f"X must be ({rows}, B), got {x.shape}")
-        n_batch = x.shape[1]
+        ldx = x.shape[1]
+        n_batch = ldx if n_batch is None else int(n_batch)
+        if not 0 <= n_batch <= ldx:
+            raise ValueError(f"n_batch must be within the pitch {ldx}")
         y_shape = (self.n_dst, n_batch) if keep_batch_fastest else (n_batch, self.n_dst)
         if y is None:
             y = DeviceArray(y_shape, out_dtype, layout="sb" if keep_batch_fastest else "bs")
@@ -223,7 +228,7 @@ class SparseOperator:
         fl = int(flags) | (_lib.APPLY_MASKED if masked else 0) | (_lib.APPLY_SB_PACKED if packed else 0)
         if keep_batch_fastest:
             fl |= _lib.APPLY_SB_Y_SB
-        _lib.call("smm_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), max(n_batch, 1),
+        _lib.call("smm_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), max(ldx, 1),
                   ctypes.c_void_p(y.ptr), dtype_code(y.dtype), max(y_shape[1], 1), n_batch, float(remap_area_min), fl,
                   _stream_handle(stream))
         return y
@@ -347,14 +352,18 @@ class OperatorGroup:
         return y
 
     def apply_sb(self, x, level_index, masked_levels=None, y=None, masked=False, remap_area_min=0.0,
-                 transpose=True, out_dtype=np.float64, flags=0, stream=None, keep_batch_fastest=False):
+                 transpose=True, out_dtype=np.float64, flags=0, stream=None, keep_batch_fastest=False, n_batch=None):
         """Masked levels for a field kept batch-fastest per level: x is a DeviceArray (n_lev, S, B) --
         per data level the B batch values of each source cell contiguous.  Returns (B, n_lev, D) when
         transpose (regrid.py:420-427) else (n_lev, B, D); bit-identical to `apply` on the transposed field.
-        keep_batch_fastest: the result stays batch-fastest per level, (n_lev, D, B) tagged "sb"."""
+        keep_batch_fastest: the result stays batch-fastest per level, (n_lev, D, B) tagged "sb".
+        n_batch: batch entries when the last axis of x is a padded pitch (see SparseOperator.apply_sb)."""
         if not isinstance(x, DeviceArray) or x.ndim != 3 or x.shape[1] != self.n_src:
             raise ValueError(f"X must be a DeviceArray (n_lev, {self.n_src}, B)")
-        n_lev, S, B = x.shape
+        n_lev, S, ldx = x.shape
+        B = ldx if n_batch is None else int(n_batch)
+        if not 0 <= B <= ldx:
+            raise ValueError(f"n_batch must be within the pitch {ldx}")
         D = self.n_dst
         lev, ml = self._level_args(level_index, masked_levels, n_lev)
         if keep_batch_fastest:
@@ -367,8 +376,8 @@ class OperatorGroup:
         elif y.shape != shape:
             raise ValueError(f"Y must be {shape}, got {y.shape}")
         fl = int(flags) | (_lib.APPLY_MASKED if masked else 0) | (_lib.APPLY_SB_Y_SB if keep_batch_fastest else 0)
-        _lib.call("smm_group_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), S * max(B, 1),
-                  max(B, 1), ctypes.c_void_p(y.ptr), dtype_code(y.dtype), ys_lev, ys_b, B, n_lev, _cptr(lev),
+        _lib.call("smm_group_apply_sb", self.handle, ctypes.c_void_p(x.ptr), dtype_code(x.dtype), S * max(ldx, 1),
+                  max(ldx, 1), ctypes.c_void_p(y.ptr), dtype_code(y.dtype), ys_lev, ys_b, B, n_lev, _cptr(lev),
                   _cptr(ml), float(remap_area_min), fl, _stream_handle(stream))
         return y
 

@@ -306,3 +306,93 @@ def test_group_result_kept_batch_fastest(hip, rng):
     y = grp.apply_sb(x_sb, level_index, masked_levels, masked=True, remap_area_min=0.4, keep_batch_fastest=True)
     assert y.shape == (4, D, B) and y.layout == "sb"
     assert_same(y.to_host().transpose(2, 0, 1), ref, exact=True)                   # (B, L, D)
+
+
+# ------------------------------------------------------------------ conservative operators, padded pitches
+
+def _con_operator(src, dst, mask=None):
+    w = gridgen.generate_weights(src, dst, method="con", src_mask=mask)
+    op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                        w["dst_address"].values, w["remap_matrix"].values, device=0)
+    return w, op
+
+
+@pytest.mark.parametrize("src,dst", [("r144x72", "r36x18"), ("r360x180", "r72x36"), ("r720x360", "r120x60"),
+                                     ("r200x100", "r90x45")])
+def test_sb_conservative_masked_operators(hip, rng, src, dst):
+    """Conservative operators with a source mask (cells shared between links and rows, ragged rows at the
+    coasts) in the batch-fastest layout: batch sizes around the tile and its tails, masks, thresholds,
+    non-finite values, f32 stores, results kept batch-fastest."""
+    g = gridgen.parse_grid(src)
+    mask = (rng.random(g.size) > 0.3).astype(np.int32)
+    w, op = _con_operator(src, dst, mask)
+    imask = op.mask_apply(mask)
+    frac = w["dst_grid_frac"].values
+    op.set_epilogue(imask, frac)
+    csr = op.export_csr()
+    for n_batch in (2, 3, 15, 16, 17, 33, 120, 257):
+        x = field(rng, n_batch, op.n_src, nan_frac=0.05, inf_frac=0.003)
+        x[:, mask == 0] = np.nan
+        for masked, amin in [(False, 0.0), (True, 0.5)]:
+            assert_same(run_sb(op, x, masked, amin), oracle.apply_c(csr, x, masked, imask, frac, amin), exact=True)
+        xt = to_device(np.ascontiguousarray(x.T))
+        ref = oracle.apply_c(csr, x, True, imask, frac, 0.5)
+        y = op.apply_sb(xt, masked=True, remap_area_min=0.5, keep_batch_fastest=True)
+        assert_same(y.to_host().T, ref, exact=True)
+        y32 = op.apply_sb(xt, masked=True, remap_area_min=0.5, out_dtype=np.float32).to_host()
+        assert_same(y32, ref.astype(np.float32), exact=True)
+    xf = field(rng, 40, op.n_src)
+    yf = op.apply_sb(to_device(np.ascontiguousarray(xf.T)), flags=_lib.APPLY_NO_FILL).to_host()
+    assert_same(yf, oracle.apply_c(csr, xf), exact=True)
+
+
+def test_sb_padded_pitch_through_n_batch(hip, rng):
+    """`n_batch` with a padded pitch: cells that start on 128-B lines (pitch a multiple of 16 doubles)."""
+    w, op = _con_operator("r144x72", "r36x18")
+    op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
+    csr = op.export_csr()
+    for B, ldx in [(120, 128), (50, 57), (33, 48)]:
+        x = field(rng, B, op.n_src, nan_frac=0.02)
+        xw = np.full((op.n_src, ldx), np.nan)
+        xw[:, :B] = x.T
+        ref = oracle.apply_c(csr, x, False, None, w["dst_grid_frac"].values, 0.5)
+        y = op.apply_sb(to_device(xw), remap_area_min=0.5, n_batch=B)
+        assert y.shape == (B, op.n_dst)
+        assert_same(y.to_host(), ref, exact=True)
+        yk = op.apply_sb(to_device(xw), remap_area_min=0.5, n_batch=B, keep_batch_fastest=True)
+        assert yk.shape == (op.n_dst, B)
+        assert_same(yk.to_host().T, ref, exact=True)
+    with pytest.raises(ValueError):
+        op.apply_sb(to_device(np.zeros((op.n_src, 8))), n_batch=9)
+
+
+def test_group_sb_with_padded_pitch(hip, rng):
+    """Masked levels kept batch-fastest per level with a pitch on 128-B lines, (L, S, 128) for T = 120:
+    (T, L, D) and (L, D, T) results."""
+    from smmregrid_amd import OperatorGroup
+    from smmregrid_amd.weights import compute_weights_matrix3d
+    nx, ny, n_lev, T = 288, 144, 3, 120
+    srcg = gridgen.regular_grid(nx, ny)
+    masks = gridgen.synthetic_ocean_masks(nx, ny, n_lev, top=0.7, bottom=0.2)
+    w3 = gridgen.ConservativeLevels(srcg, "r72x36").stack(masks, np.arange(n_lev, dtype=float))
+    ops = compute_weights_matrix3d(w3, "lev", device=0)
+    imask = np.stack([op.mask_apply(masks[i]) for i, op in enumerate(ops)])
+    frac = w3["dst_grid_frac"].values
+    for i, op in enumerate(ops):
+        op.set_epilogue(imask[i], frac[i])
+    grp = OperatorGroup(ops)
+    x = 5.0 + rng.standard_normal((T, n_lev, nx * ny))
+    for lv in range(n_lev):
+        x[:, lv, masks[lv] == 0] = np.nan
+    ml = np.ones(n_lev, np.uint8)
+    ref = oracle.apply_levels([op.export_csr() for op in ops], x, 1, np.arange(n_lev), ml.astype(bool), imask, frac, 0.5, True)
+    xp = np.full((n_lev, nx * ny, 128), np.nan)
+    xp[:, :, :T] = x.transpose(1, 2, 0)
+    dxp = to_device(xp)
+    y = grp.apply_sb(dxp, np.arange(n_lev, dtype=np.int32), ml, masked=True, remap_area_min=0.5, n_batch=T)
+    assert y.shape == (T, n_lev, ops[0].n_dst)
+    assert_same(y.to_host(), ref, exact=True)
+    yk = grp.apply_sb(dxp, np.arange(n_lev, dtype=np.int32), ml, masked=True, remap_area_min=0.5, n_batch=T,
+                      keep_batch_fastest=True)
+    assert yk.shape == (n_lev, ops[0].n_dst, T)
+    assert_same(yk.to_host().transpose(2, 0, 1), ref, exact=True)
