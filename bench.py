@@ -928,7 +928,7 @@ def main():
             if rank == 0:
                 out["with_gather"] = {"error": f"gather phase exceeded {args.gather_timeout:.0f} s"}
                 print(json.dumps(out), flush=True)
-            os._exit(0 if rank == 0 else 3)
+            os._exit(0)     # the compute measurement stands; the line carries the error
 
         dog = threading.Timer(args.gather_timeout, give_up)
         dog.daemon = True
@@ -936,7 +936,17 @@ def main():
         comm = dist_mod = None
         try:
             from smmregrid_amd.distributed import TiledRingGather
-            comm, dist_mod = make_comm(args, rank, world, local_rank, rdv)
+            setup_error = b""
+            try:
+                comm, dist_mod = make_comm(args, rank, world, local_rank, rdv)
+            except Exception as exc:
+                setup_error = repr(exc).encode()
+            # all ranks agree before anyone enters the collective loop: one rank without a communicator
+            # would leave the others waiting at the first barrier of the gather phase
+            failures = [(r, e.decode()) for r, e in enumerate(rdv.allgather(setup_error)) if e]
+            if failures:
+                raise RuntimeError("communicator set-up failed on rank(s) "
+                                   + "; ".join(f"{r}: {e}" for r, e in failures[:3]))
             ring = TiledRingGather(comm, y, root=0, tiles=args.gather_tiles, slots=2)
             g_elapsed, _ = timed(gather=True)
             if rank == 0:

@@ -29,7 +29,9 @@ for seed in range(n):
     if op.plan_info()["tile_plan"]:
         # default tile kernel, other block orders, single-row steps, odd walk lengths (tails of multi-row steps)
         t = _lib.APPLY_KERNEL_TILE
-        ks += [t, t | (6 << 16), t | (7 << 16), t | (13 << 16), t | (12 << 16), t | (15 << 16)] + [t | (j << 20) for j in (1, 3, 5, 7)]
+        # (10: LDS-DMA staging forced wherever the field is 16-B aligned, 8: register staging forced)
+        ks += [t, t | (6 << 16), t | (7 << 16), t | (13 << 16), t | (12 << 16), t | (15 << 16), t | (10 << 16),
+               t | (8 << 16), t | (10 << 16) | (3 << 20)] + [t | (j << 20) for j in (1, 3, 5, 7)]
     dx = to_device(x)
     for fl in ks:
         for rep in range(3):
@@ -44,6 +46,9 @@ for seed in range(n):
         y = op.apply_sb(to_device(xx), masked=masked, remap_area_min=amin, packed=packed).to_host()
         if not (np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])):
             bad += 1; print("MISMATCH seed", seed, "apply_sb packed", packed, flush=True)
+        yk = op.apply_sb(to_device(xx), masked=masked, remap_area_min=amin, packed=packed, keep_batch_fastest=True).to_host().T
+        if not (np.array_equal(np.isnan(yk), np.isnan(ref)) and np.array_equal(yk[~np.isnan(yk)], ref[~np.isnan(ref)])):
+            bad += 1; print("MISMATCH seed", seed, "apply_sb kept batch-fastest, packed", packed, flush=True)
     y = op.apply_host(x, masked=masked, remap_area_min=amin, chunk_rows=int(rng.integers(0, 40)))
     if not (np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])):
         bad += 1; print("MISMATCH seed", seed, "apply_host", flush=True)
