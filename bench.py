@@ -669,13 +669,17 @@ def launch_ranks(n_ranks):
     per GPU; this parent never initialises HIP), relay rank 0's stdout, exit non-zero if any rank
     fails.  Ranks that are still running when one has failed are terminated by their own PIDs."""
     import socket
-    with socket.socket() as sk:
+    # two distinct free ports: a torch store's (MASTER_PORT) and the control plane's TCP rendezvous
+    socks = [socket.socket() for _ in range(2)]
+    for sk in socks:
         sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    ports = [sk.getsockname()[1] for sk in socks]
+    for sk in socks:
+        sk.close()
     procs = []
     for r in range(n_ranks):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n_ranks),
-                   LOCAL_WORLD_SIZE=str(n_ranks), RANK=str(r), LOCAL_RANK=str(r))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(ports[0]), SMM_RDV_PORT=str(ports[1]),
+                   WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
 

@@ -3,8 +3,8 @@
 Two pieces, one process per GPU:
 
 * `HostRendezvous`: the CONTROL plane.  Rank 0 listens on MASTER_ADDR:MASTER_PORT+23 (the variables
-  ``torch.distributed.run`` and ``bench.py``'s own launcher export), every other rank keeps one TCP
-  connection to it.  Barriers, the max-over-ranks of a timing and the hand-over of the RCCL unique id
+  ``torch.distributed.run`` and ``bench.py``'s own launcher export; ``SMM_RDV_PORT`` names another port),
+  every other rank keeps one TCP connection to it.  Barriers, the max-over-ranks of a timing and the hand-over of the RCCL unique id
   are small host-side all-gathers over those sockets -- nothing of it touches a GPU, so it runs (and
   is tested) on any host.
 * `Comm`: the DATA plane, RCCL over xGMI behind the C ABI (`smm_comm_*`): the gather / all-gather
@@ -62,7 +62,9 @@ class HostRendezvous:
         if self.world <= 0 or not 0 <= self.rank < self.world:
             raise ValueError("bad rank / world size")
         self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
-        self.port = int(port if port is not None else int(os.environ.get("MASTER_PORT", "29500")) + PORT_OFFSET)
+        if port is None:   # a launcher may name a port of its own (bench.py does); else MASTER_PORT + 23
+            port = os.environ.get("SMM_RDV_PORT") or int(os.environ.get("MASTER_PORT", "29500")) + PORT_OFFSET
+        self.port = int(port)
         self.timeout = float(timeout)
         self.peers = {}          # rank 0: rank -> socket
         self.sock = None         # other ranks: the connection to rank 0
