@@ -33,6 +33,8 @@ def ragged_links(rng, n_src, n_dst, max_len=40):
         src.append(cols + 1)
         dst.append(np.full(cols.size, d + 1))
         w.append(ww)
+    if not src:                            # every row drew "no links" (tiny n_dst): an empty operator
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)
     src = np.concatenate(src).astype(np.int32)
     dst = np.concatenate(dst).astype(np.int32)
     w = np.concatenate(w)
