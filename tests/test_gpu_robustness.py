@@ -168,3 +168,66 @@ def test_host_pipeline_error_drains_in_flight_copies(hip, rng, pinned):
     # the pipeline is usable again afterwards
     y = op.apply_host(xin, chunk_rows=chunk)
     assert_same(y, ref, exact=True)
+
+
+def test_group_pipeline_error_path_and_whole_call_validation(hip, rng):
+    """The level-group host pipeline: an injected failure at chunk c returns an error (nothing hangs, the
+    pipeline is usable afterwards); and a call whose LAST level lacks dst_frac is refused before any level
+    has written to Y -- by the device-resident batch-fastest entry and by the host pipeline's pack branch."""
+    S, D, L = 3000, 260, 3
+    ops, csrs = [], []
+    imask = (rng.random((L, D)) > 0.3).astype(np.int32)
+    frac = rng.random((L, D))
+    for i in range(L):
+        src, dst, w = random_links(rng, S, D, 400 + 100 * i)          # few used cells: the pack branch qualifies
+        op = SparseOperator(S, D, src, dst, w, device=0)
+        op.set_epilogue(imask[i], frac[i] if i < L - 1 else None)      # the last level has no dst_frac
+        ops.append(op)
+        csrs.append(op.export_csr())
+    grp = OperatorGroup(ops)
+    x = field(rng, 40 * L, S).reshape(40, L, 1, S)
+    lev = np.arange(L, dtype=np.int32)
+    # remap_area_min > 0 needs every selected level's dst_frac: refused as a whole
+    xsb = to_device(np.ascontiguousarray(x.reshape(40, L, S).transpose(1, 2, 0)), layout="sb")
+    y = DeviceArray((40, L, D), np.float64).fill_bytes(0)
+    with pytest.raises(_lib.SmmError) as e:
+        grp.apply_sb(xsb, lev, y=y, remap_area_min=0.4)
+    assert e.value.code == _lib.SMM_ERR_INVALID and "dst_frac" in str(e.value)
+    assert (y.to_host() == 0.0).all()                                  # no level was launched
+    with pytest.raises(_lib.SmmError):
+        grp.apply_host(x, lev, remap_area_min=0.4)
+    # without the threshold the same calls work, and an injected chunk failure surfaces as an error
+    ref = oracle.apply_levels(csrs, x, 1, lev, np.ones(L, bool), imask, None, 0.0, True)
+    assert_same(grp.apply_host(x, lev, masked=True), ref, exact=True)
+    _lib.call("smm_debug_fail_at_chunk", 0)
+    try:
+        with pytest.raises(_lib.SmmError) as e:
+            grp.apply_host(x, lev, masked=True)
+        assert "injected failure" in str(e.value)
+    finally:
+        _lib.call("smm_debug_fail_at_chunk", -1)
+    assert_same(grp.apply_host(x, lev, masked=True), ref, exact=True)
+
+
+def test_pitched_copies_and_their_errors(hip, rng):
+    """smm_memcpy2d_h2d / _d2h: rows of `width` bytes on different pitches; a pitch below the width is refused."""
+    import ctypes
+    rows, cols, pitch = 7, 13, 24
+    host = rng.standard_normal((rows, cols))
+    dev = DeviceArray((rows, pitch), np.float64).fill_bytes(0)
+    _lib.call("smm_memcpy2d_h2d", ctypes.c_void_p(dev.ptr), pitch * 8, host.ctypes.data_as(ctypes.c_void_p), cols * 8,
+              cols * 8, rows, None)
+    full = dev.to_host()
+    assert np.array_equal(full[:, :cols], host) and (full[:, cols:] == 0.0).all()
+    back = np.zeros((rows, cols))
+    _lib.call("smm_memcpy2d_d2h", back.ctypes.data_as(ctypes.c_void_p), cols * 8, ctypes.c_void_p(dev.ptr), pitch * 8,
+              cols * 8, rows, None)
+    assert np.array_equal(back, host)
+    col = np.zeros(rows)                                               # one column: width 8 B
+    _lib.call("smm_memcpy2d_d2h", col.ctypes.data_as(ctypes.c_void_p), 8, ctypes.c_void_p(dev.ptr + 3 * 8), pitch * 8,
+              8, rows, None)
+    assert np.array_equal(col, host[:, 3])
+    with pytest.raises(_lib.SmmError) as e:
+        _lib.call("smm_memcpy2d_h2d", ctypes.c_void_p(dev.ptr), 8, host.ctypes.data_as(ctypes.c_void_p), cols * 8,
+                  cols * 8, rows, None)
+    assert e.value.code == _lib.SMM_ERR_INVALID

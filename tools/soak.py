@@ -56,7 +56,7 @@ for seed in range(n):
     if seed % 50 == 49: print(f"{seed+1} cases, {bad} mismatches, {time.time()-t0:.0f}s", flush=True)
 # level groups (grouped launch, both Y layouts, host pipeline): the fuzz test body on many more seeds
 from tests.test_gpu_fuzz import test_fuzz_levels
-n_groups = max(1, n // 4)
+n_groups = int(sys.argv[2]) if len(sys.argv) > 2 else max(1, n // 4)      # soak.py <operators> [<level groups>]
 for seed in range(100, 100 + n_groups):
     try:
         test_fuzz_levels(_lib, seed)
