@@ -67,7 +67,8 @@ enum {
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };
 /* tuning knobs for benchmarks (0 = library default; results are identical for every value):
- * kernel variant in bits 16..19 -- tile kernel: 3 / 4 non-temporal / cached X loads,
+ * kernel variant in bits 16..19 -- tile kernel: 3 / 4 non-temporal / cached X loads, 10 / 9 / 11 LDS-DMA staging
+ * forced with one / two / four batch rows per step, 8 register staging forced,
  * 6 dispatcher block order instead of runs of 32 consecutive blocks per XCD (7 / 13: runs of
  * 8 / 128), 12 single-row steps on small tiles; SELL kernel: 1 / 2 = 8 / 2 batch rows per thread -- and the batch rows walked per
  * workgroup of the tile kernel in bits 20..27 */

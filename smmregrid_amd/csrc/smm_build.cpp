@@ -336,6 +336,9 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_
   plan.valid = plan.direct_links * 4 <= csr.nnz;
 }
 
+#ifndef SMM_TIGHTEN_PCT
+#define SMM_TIGHTEN_PCT 1   // per cent of the links that may sit in blocks demoted to direct gathering
+#endif
 int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_budget) {
   if (!plan.valid || plan.n_blocks == 0) return full_budget;
   const int64_t rows_per_block = plan.rows_per_block;
@@ -349,7 +352,7 @@ int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_b
     int64_t demoted = 0;
     for (int64_t b = 0; b < plan.n_blocks; ++b)
       if (plan.blk_chunk_off[(size_t)b + 1] - plan.blk_chunk_off[(size_t)b] > cand) demoted += block_links(b);
-    if ((plan.direct_links + demoted) * 100 <= csr.nnz) {
+    if ((plan.direct_links + demoted) * 100 <= csr.nnz * SMM_TIGHTEN_PCT) {
       chosen = cand;
       break;
     }

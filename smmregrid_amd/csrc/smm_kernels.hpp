@@ -274,7 +274,7 @@ template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SP
 __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   constexpr int WPB = tile_waves(MAXK);
   constexpr int T = WPB * 64;
-  static_assert(!DMA || (R == 1 && !SPLIT && MAXK > 0), "LDS-DMA staging: single-row steps, links in registers");
+  static_assert(!DMA || (!SPLIT && MAXK > 0 && (R == 1 || MAXK <= 16)), "LDS-DMA staging: links in registers; multi-row steps for the 4-wave shape");
   // Where the 1e20 fill happens: rows of more than 16 links test the staging pieces on their way into
   // LDS (a 48-link row would test 48 gathered values per batch row, its ~15 pieces hold 30); short
   // rows gather few values from comparatively many staged ones (config 4: 4 links, 8 staged f32 per
@@ -518,62 +518,86 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                                          (NT & 1) ? 2 : 0);
       }
     };
-    RowWalker xw(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);
-    RowWalker yw(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);
-    YT pend_out = (YT)0;
-    int64_t pend_off = 0;
+    // A step covers R batch rows (R > 1: small tiles whose round trip, not their bytes, bounds a step): the
+    // ring holds two groups of R slots, rows jb + R .. jb + 2R - 1 land in one group while rows
+    // jb .. jb + R - 1 are consumed from the other.
+    RowWalker xw(j_begin, l, a.n_inner, a.xs_o, a.xs_l, a.xs_i);   // next row to issue
+    RowWalker yw(j_begin, l, a.n_inner, a.ys_o, a.ys_l, a.ys_i);   // next row to compute
+    YT pend_out[R];
+    int64_t pend_off[R];
+    int n_pend = 0;
     auto flush_pending = [&]() {
-      YT* __restrict__ yrow = (YT*)a.y + pend_off;
-      if (NT & 2)
-        __builtin_nontemporal_store(pend_out, yrow + dy);
-      else
-        yrow[dy] = pend_out;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (r < n_pend) {
+          YT* __restrict__ yrow = (YT*)a.y + pend_off[r];
+          if (NT & 2)
+            __builtin_nontemporal_store(pend_out[r], yrow + dy);
+          else
+            yrow[dy] = pend_out[r];
+        }
+      }
     };
-    issue_row(xw.off, 0);
-    int slot = 0;
-    for (int64_t j = j_begin; j < j_end; ++j) {
+    int64_t j_issue = j_begin;
+    auto issue_group = [&](int group) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (j_issue < j_end) {
+          issue_row(xw.off, group * R + r);
+          ++j_issue;
+          if (j_issue < j_end) xw.next();
+        }
+      }
+    };
+    issue_group(0);
+    int group = 0;
+    for (int64_t jb = j_begin; jb < j_end; jb += R) {
       asm volatile("" : "+s"(np_w), "+s"(wmax));
       if (MAXK > 16) {
 #pragma unroll
         for (int q = 0; q < KREG / 2; ++q) asm volatile("" : "+v"(lc2[q]));
       }
-      // row j has landed (and every wave is done with the other slot, which row j + 1 is about to overwrite)
+      // this step's rows have landed (and every wave is done with the other group, about to be refilled)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (WPB > 1) __syncthreads();
-      if (row_live && j > j_begin) flush_pending();   // row j - 1's result: issued before the next DMA
-      if (j + 1 < j_end) {
-        xw.next();
-        issue_row(xw.off, slot ^ 1);
-      }
-      if (slice_live) {
-        const char* lds_b = smem + (size_t)slot * tile_bytes;
-        double acc = 0.0;
+      if (row_live) flush_pending();   // the previous step's results: issued before the next DMAs
+      issue_group(group ^ 1);
+      n_pend = 0;
 #pragma unroll
-        for (int k0 = 0; k0 < KREG; k0 += 4) {
-          if (k0 < wmax) {
-            double xv[4];
+      for (int r = 0; r < R; ++r) {
+        if (jb + r < j_end) {
+          if (slice_live) {
+            const char* lds_b = smem + (size_t)(group * R + r) * tile_bytes;
+            double acc = 0.0;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const int k = k0 + kk;
-              const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16) : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
-              xv[kk] = load_fixed((const XT*)(lds_b + li), fill);
-            }
+            for (int k0 = 0; k0 < KREG; k0 += 4) {
+              if (k0 < wmax) {
+                double xv[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              const int k = k0 + kk;
-              if (k < KREG) {
-                const double p = w[k] * xv[kk];
-                acc = acc + p;
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int k = k0 + kk;
+                  const uint32_t li = (k & 1) ? (lc2[(k < KREG ? k : 0) / 2] >> 16) : (lc2[(k < KREG ? k : 0) / 2] & 0xFFFFu);
+                  xv[kk] = load_fixed((const XT*)(lds_b + li), fill);
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                  const int k = k0 + kk;
+                  if (k < KREG) {
+                    const double p = w[k] * xv[kk];
+                    acc = acc + p;
+                  }
+                }
               }
             }
+            acc = len > 0 ? acc : 0.0;
+            pend_out[r] = (YT)epilogue(acc, dead);
+            pend_off[r] = yw.off;
           }
+          n_pend = r + 1;
+          yw.next();
         }
-        acc = len > 0 ? acc : 0.0;
-        pend_out = (YT)epilogue(acc, dead);
-        pend_off = yw.off;
       }
-      yw.next();
-      slot ^= 1;
+      group ^= 1;
     }
     if (row_live) flush_pending();
   } else if constexpr (R == 1) {

@@ -103,10 +103,21 @@ inline TileLaunchCfg tile_launch_cfg(const ApplyArgs& a, int64_t n_lev, int tile
   const bool aligned = ((uintptr_t)a.x % 16 == 0) && (a.xs_o * (int64_t)xsz % 16 == 0) &&
                        (a.xs_l * (int64_t)xsz % 16 == 0) && (a.xs_i * (int64_t)xsz % 16 == 0) &&
                        (a.n_src * (int64_t)xsz % 16 == 0);
-  const bool wanted = variant == 10 || (!tile_which && c.np_needed <= 2 && variant != 8 && variant != 12);
+  const bool wanted = variant == 10 || variant == 9 || variant == 11 ||
+                      (!tile_which && c.np_needed <= 2 && variant != 8 && variant != 12);
   c.dma = wanted && aligned && a.sub_shift == 0 && max_row_nnz > 0 && max_row_nnz <= 48 && 2 * c.tile <= 65536;
-  if (c.dma) c.rows = 1;
-  c.lds = c.dma ? 2 * c.tile : c.tile * (size_t)c.rows;
+  if (c.dma) {
+    // Rows per step of the DMA ring (two groups of `rows` slots).  Tiles of one piece per thread (4 KB:
+    // coarse -> fine regrids, whose steps are pure round trips) take two rows per step -- 16 KB per
+    // workgroup still keeps every workgroup slot of the CU (upsampling r360x180 -> r1440x721 2.71 -> 2.39 ms);
+    // with 8-KB tiles two rows cost workgroups (config-4 geometry 4.71 -> 5.05 ms, four rows 5.92).
+    // Tuning variants: 10 = one row, 9 = two, 11 = four.
+    c.rows = 1;
+    if (!tile_which && c.np_needed <= 4)
+      c.rows = variant == 9 ? 2 : (variant == 11 ? 4 : (variant == 10 ? 1 : (c.np_needed <= 1 ? 2 : 1)));
+    while (c.rows > 1 && (c.rows > c.j_per_block || 2 * c.rows * c.tile > 65536)) c.rows /= 2;
+  }
+  c.lds = c.dma ? 2 * (size_t)c.rows * c.tile : c.tile * (size_t)c.rows;
   return c;
 }
 
@@ -132,8 +143,22 @@ int launch_tile(const ApplyArgs& a, int64_t n_lev, int tile_which, int64_t max_c
   auto go_dma = [&](auto k_tag, auto np_tag, auto nt_tag) -> int {
     constexpr int MAXK = decltype(k_tag)::value;
     if constexpr (MAXK > 0) {
-      hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, decltype(np_tag)::value, decltype(nt_tag)::value, 1, false, true>),
-                         dim3((unsigned)total), dim3(tile_waves(MAXK) * 64), lds, s, args, fill);
+      constexpr int NPV = decltype(np_tag)::value;
+      constexpr int NTV = decltype(nt_tag)::value;
+      const dim3 grid((unsigned)total), block(tile_waves(MAXK) * 64);
+      if constexpr (MAXK <= 16 && NPV <= 4) {
+        if (rows == 4) {
+          hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NPV, NTV, 4, false, true>), grid, block, lds, s, args, fill);
+          SMM_LAUNCH_HIP(hipGetLastError());
+          return SMM_OK;
+        }
+        if (rows == 2) {
+          hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NPV, NTV, 2, false, true>), grid, block, lds, s, args, fill);
+          SMM_LAUNCH_HIP(hipGetLastError());
+          return SMM_OK;
+        }
+      }
+      hipLaunchKernelGGL((smm_apply_tile2_kernel<XT, YT, MAXK, NPV, NTV, 1, false, true>), grid, block, lds, s, args, fill);
       SMM_LAUNCH_HIP(hipGetLastError());
       return SMM_OK;
     } else {

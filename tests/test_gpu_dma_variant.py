@@ -27,6 +27,7 @@ def test_dma_staging_matches_oracle(hip, rng, method, src, dst, dtype):
     for n_batch in (1, 5, 70):
         x = field(rng, n_batch, op.n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.003)
         ref = oracle.apply_c(op.export_csr(), x, True, imask, w["dst_grid_frac"].values, 0.5)
-        for fl in (T, DMA, DMA | (3 << 20), T | (8 << 16), T | (12 << 16)):
+        for fl in (T, DMA, DMA | (3 << 20), T | (8 << 16), T | (12 << 16), T | (9 << 16), T | (11 << 16),
+                   T | (9 << 16) | (3 << 20), T | (11 << 16) | (5 << 20)):
             y = op.apply(to_device(x), masked=True, remap_area_min=0.5, flags=fl).to_host()
             assert_same(y, ref, exact=True)
