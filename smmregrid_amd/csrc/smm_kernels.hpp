@@ -268,8 +268,10 @@ constexpr int tile_waves(int maxk) { return (maxk > 0 && maxk <= 16) ? kWavesPer
 // Larger tiles lose workgroups to the second slot (config 2: 2.71 -> 2.99 ms; the 64-row single-wave
 // kernels of config 3: 12.4 -> 15.1 ms, 15-KiB tiles: 5 instead of 8 waves per CU -- the register file
 // is the bigger store on this chip, 512 KB against 160 KB per CU, and the prefetched row lives there).
-// Rings of 3 / 4 slots with counted s_waitcnt vmcnt(N) and a raw s_barrier were built and measured
-// slower than two slots everywhere (config-4 geometry 4.99 / 5.56 ms): again fewer workgroups per CU.
+// Rings of 3 / 4 slots with counted s_waitcnt vmcnt(N) and a raw s_barrier were built and measured:
+// never better than two slots (config-4 geometry 4.83 ms with three slots and the wait counted so that
+// neither the younger row nor the latest Y store is waited for, against 4.86; 5.56 with four): that
+// kernel is bound by its bytes, not by a workgroup's round trips, and deeper rings cost workgroups per CU.
 template <typename XT, typename YT, int MAXK, int NP, int NT, int R = 1, bool SPLIT = false, bool DMA = false>
 __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kernel(ApplyArgs a, bool fill) {
   constexpr int WPB = tile_waves(MAXK);
