@@ -469,7 +469,7 @@ class ProblemLevels:
                          masked=True, remap_area_min=0.5, transpose=True, flags=flags)
 
     def cpu_baseline(self, budget_s):
-        """Same three legs as Problem2D.cpu_baseline, level by level as regrid.py:387-418 loops."""
+        """Same legs as Problem2D.cpu_baseline, level by level as regrid.py:387-418 loops."""
         from oracle import oracle
         threads, avail = cpu_threads()
         csrs = [op.export_csr() for op in self.ops]
