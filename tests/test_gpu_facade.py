@@ -297,7 +297,9 @@ def test_reference_test_data_ua_ipsl_check_nan(hip):
     check_nan=True finds `plev`, weights are built per level from the missing-value pattern,
     and the top level has no NaN.  The reference asserts 589 NaN cells at level 1 with CDO-made
     weights; this package's native conservative geometry gives 567 (weight generation is outside
-    the accelerated path), and the apply path must agree with the oracle bit for bit."""
+    the accelerated path; DESIGN.md section 5 and tools/known_answer_589.py list every variation of
+    geometry, mask and cut tried in round 4 with its count -- none principled gives 589), and the
+    apply path must agree with the oracle bit for bit."""
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ua_ipsl_t0.npz"))
     field = DataArray(z["ua"][None], dims=("time", "plev", "lat", "lon"),
                       coords={"time": [0], "plev": z["plev"], "lat": z["lat"], "lon": z["lon"]}, name="ua")
