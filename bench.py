@@ -131,6 +131,14 @@ def parse_args():
     ap.add_argument("--others-steps", type=int, default=20)
     ap.add_argument("--others-budget", type=float, default=240.0,
                     help="seconds after which remaining secondary workloads are skipped")
+    ap.add_argument("--configs", default="default",
+                    help="BASELINE configs run after the headline on the same ranks, each rank its share of the "
+                         "fixed total batch (comma list, 'default' = cfg4,cfg5, 'none')")
+    ap.add_argument("--config-steps", type=int, default=10)
+    ap.add_argument("--config-warmup", type=int, default=2)
+    ap.add_argument("--config-gather-steps", type=int, default=2,
+                    help="steps of the compute + gather loop of a BASELINE config (config 4 moves 110 GB per rank and step)")
+    ap.add_argument("--config-batch", type=int, default=0, help="override the rows per GPU of --configs (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -174,6 +182,7 @@ class Problem2D:
                                  w["dst_address"].values, w["remap_matrix"].values, device=device,
                                  dst_dims=w["dst_grid_dims"].values, prune_zeros=self.prune)
         self.op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
+        self.create_ms = self.op.create_ms     # smm_operator_create: sort + duplicate sum + layouts + upload
         self.np_dt = np.float64 if self.x_dtype == "f64" else np.float32
         x_shape = {"bs": (self.n_batch, self.n_src), "sb": (self.n_src, self.n_batch),
                    "sbp": (self.op.n_used_src, self.n_batch), "sbk": (self.n_src, self.n_batch)}[self.layout]
@@ -320,6 +329,7 @@ class Problem2D:
         v, p, t = timed(lambda: oracle.apply(csr, x[:srows], False, None, frac, 0.5), srows, budget_s * 0.25, 50)
         legs.append({"value": v, "unit": "cells/s", "cores": 1, "kind": "port",
                      "impl": "oracle/oracle.py (numpy + scipy.sparse CSR product)",
+                     "rows_sampled": srows, "passes": p, "seconds": round(t, 1),
                      "sample": f"{srows} of {self.n_batch} batch rows x {p} passes, {t:.1f} s"})
         # (ii) C port with OpenMP over batch rows: this GPU's CPU share, then every visible core
         for nt in sorted({threads, avail}):
@@ -329,12 +339,11 @@ class Problem2D:
             # ("every core the process may use" = affinity capped by the cgroup CPU quota: cpu_threads())
             legs.append({"value": v, "unit": "cells/s", "cores": nt, "kind": "port",
                          "impl": "oracle/oracle.c (OpenMP over batch rows)",
+                         "rows_sampled": rows, "passes": p, "seconds": round(t, 1),
                          "sample": f"{rows} of {self.n_batch} batch rows x {p} passes, {nt} threads of "
                                    f"{avail} usable (affinity capped by the cgroup quota; os.cpu_count() = "
                                    f"{os.cpu_count()}), {t:.1f} s"})
-        best = max(legs, key=lambda leg: leg["value"])
-        return {"value": best["value"], "unit": "cells/s", "cores": best["cores"], "kind": "port",
-                "sample": best["impl"] + ": " + best["sample"], "legs": legs}
+        return cpu_summary(legs, avail, f"of {self.n_batch} batch rows")
 
 
 class ProblemLevels:
@@ -352,7 +361,10 @@ class ProblemLevels:
         w3 = gridgen.ConservativeLevels(src, tgrid).stack(masks, levels)
         self.weights = w3
         self.n_src, self.n_dst = w3.sizes["src_grid_size"], w3.sizes["dst_grid_size"]
+        t0 = time.perf_counter()
         self.ops = compute_weights_matrix3d(w3, "lev", device=device)
+        self.create_ms = (time.perf_counter() - t0) * 1e3      # all levels' operators (created by a thread pool)
+        self.create_ms_sum = float(sum(op.create_ms for op in self.ops))
         self.dst_imask = np.stack([op.mask_apply(masks[i]) for i, op in enumerate(self.ops)])
         frac = w3["dst_grid_frac"].values
         for i, op in enumerate(self.ops):
@@ -494,18 +506,29 @@ class ProblemLevels:
         v, p, t = timed(2, budget_s * 0.25, 10, oracle.apply)
         legs.append({"value": v, "unit": "cells/s", "cores": 1, "kind": "port",
                      "impl": "oracle/oracle.py (numpy + scipy.sparse CSR product), level by level",
+                     "rows_sampled": 2 * self.n_lev, "passes": p, "seconds": round(t, 1),
                      "sample": f"2 of {self.n_t} time steps x {self.n_lev} levels x {p} passes, {t:.1f} s"})
         for nt in sorted({threads, avail}):
             t_rows = max(nt, 16)
             v, p, t = timed(t_rows, budget_s * 0.375, 100, oracle.apply_c, threads=nt)
             legs.append({"value": v, "unit": "cells/s", "cores": nt, "kind": "port",
                          "impl": "oracle/oracle.c level by level (OpenMP over rows)",
+                         "rows_sampled": t_rows * self.n_lev, "passes": p, "seconds": round(t, 1),
                          "sample": f"{t_rows} of {self.n_t} time steps x {self.n_lev} levels x {p} passes, "
                                    f"{nt} threads of {avail} usable (affinity capped by the cgroup quota; "
                                    f"os.cpu_count() = {os.cpu_count()}), {t:.1f} s"})
-        best = max(legs, key=lambda leg: leg["value"])
-        return {"value": best["value"], "unit": "cells/s", "cores": best["cores"], "kind": "port",
-                "sample": best["impl"] + ": " + best["sample"], "legs": legs}
+        return cpu_summary(legs, avail, f"of {self.n_t * self.n_lev} (time step, level) rows")
+
+
+def cpu_summary(legs, usable, of_what):
+    """`cpu_baseline` of the line: the best leg, its facts in keys of their own, one short sentence."""
+    best = max(legs, key=lambda leg: leg["value"])
+    one = [leg["value"] for leg in legs if leg["cores"] == 1 and "scipy" in leg["impl"]]
+    return {"value": best["value"], "unit": "cells/s", "cores": best["cores"], "kind": "port",
+            "sample": f"{best['rows_sampled']} {of_what} x {best['passes']} passes, {best['seconds']} s",
+            "impl": best["impl"].split(" (")[0], "threads": best["cores"], "usable_cores": usable,
+            "rows_sampled": best["rows_sampled"], "passes": best["passes"], "seconds": best["seconds"],
+            "scipy_1core_value": one[0] if one else None, "legs": legs}
 
 
 class DryProblem:
@@ -743,6 +766,16 @@ def roofline_block(args, prob, k_avg, workload, batch, with_copy_rate=True):
 
 
 OTHERS_DEFAULT = ["cfg2sb", "cfg2sbk", "cfg3", "cfg3c", "cfg4s", "cfg5tile"]
+# BASELINE.json configs 4 and 5: every rank regrids its share of the fixed total batch (8760 / 8 = 1095 rows
+# of f32; 137 x 744 / 8 = 12 741 rows of f64)
+BASELINE_CONFIGS = ["cfg4", "cfg5"]
+RING_SLOT_BYTES = 16 << 30      # root's receive ring: two slots of at most this size (all ranks' tile)
+
+
+def short(text, n=96):
+    """The driver's record cuts long strings mid-word: every string of the final line stays below ~100 chars."""
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
 
 
 def run_others(args, names, local_rank, flags, t_start):
@@ -782,8 +815,9 @@ def run_others(args, names, local_rank, flags, t_start):
             k_avg = float(np.mean([a.elapsed_ms(b) for a, b in ev])) * 1e-3
             entry = {"workload": prob.desc, "steps": args.others_steps, "warmup": 3,
                      "value": prob.cells() * args.others_steps / wall, "unit": "cells/s",
-                     "ms_per_step": wall / args.others_steps * 1e3, "dtype": prob.x_dtype}
-            entry.update(roofline_block(args, prob, k_avg, name, None, with_copy_rate=False))
+                     "ms_per_step": wall / args.others_steps * 1e3, "dtype": prob.x_dtype,
+                     "create_ms": prob.create_ms,
+                     "roofline": roofline_block(args, prob, k_avg, name, None, with_copy_rate=False)}
             entry["spot_check"] = prob.spot_check(y)
             if not entry["spot_check"]["bit_equal_to_oracle"]:
                 raise SystemExit(f"bench.py: {name}: the timed output differs from the CPU oracle: "
@@ -800,6 +834,202 @@ def run_others(args, names, local_rank, flags, t_start):
     if "levels" in shared:
         shared["levels"].free()
     return out
+
+
+def layout_summary(entry):
+    """{ms, frac, traffic, traffic_ratio, spot_check} of one timed workload for `roofline.layouts / configs`."""
+    if not entry or "roofline" not in entry:
+        return {"error": short((entry or {}).get("error") or (entry or {}).get("skipped") or "not run", 80)}
+    r = entry["roofline"]
+    out = {"ms": round(r["kernel_ms"], 4), "frac": round(r["frac"], 4), "traffic": r.get("traffic"),
+           "traffic_ratio": round(r["traffic"] / r["algorithmic_bytes"], 3) if r.get("traffic") else None}
+    if "spot_check" in entry:
+        out["spot_check"] = bool(entry["spot_check"].get("bit_equal_to_oracle"))
+    if entry.get("create_ms") is not None:
+        out["create_ms"] = round(entry["create_ms"], 1)
+    return out
+
+
+class Runner:
+    """The timing protocol shared by the headline, the gather phases and the BASELINE configs of one run:
+    W warm-up steps, then exactly K steps between barriers (device synchronise + host rendezvous), the
+    elapsed time as the MAX over ranks, the kernel time from HIP events recorded on the launch stream."""
+
+    def __init__(self, rdv, new_event, synchronize):
+        self.rdv, self.new_event, self.synchronize = rdv, new_event, synchronize
+
+    def barrier(self):
+        self.synchronize()
+        if self.rdv:
+            self.rdv.barrier()
+
+    def timed(self, prob, y, flags, steps, warmup, ring=None):
+        def step(events=None):
+            if ring is not None:
+                # tile k's gather (communication stream) overlaps tile k+1's kernel (null stream)
+                for k, (r0, r1) in enumerate(ring.tiles):
+                    prob.run_rows(y, flags, r0, r1)
+                    ring.gather_tile(k)
+                ring.finish()
+                return
+            if events:
+                events[0].record()
+            prob.run(y, flags)            # launches on the null stream
+            if events:
+                events[1].record()
+
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        ev = [(self.new_event(), self.new_event()) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(ev[k])
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.rdv:
+            dt = self.rdv.max(dt)
+        return dt, ([] if ring is not None else [a.elapsed_ms(b) for a, b in ev])   # tiles are not timed one by one
+
+    def kernel_ms_over_ranks(self, kernel_ms):
+        """(mean kernel ms of this rank, [mean kernel ms of every rank])."""
+        import struct
+        mine = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+        if not self.rdv:
+            return mine, [mine]
+        return mine, [struct.unpack("<d", p)[0] for p in self.rdv.allgather(struct.pack("<d", mine))]
+
+
+def gather_tiles_for(args, prob, world):
+    """Row tiles of the overlapped gather: at least --gather-tiles, and enough of them that one ring slot on
+    the root (every rank's tile) stays within RING_SLOT_BYTES (config 4: 8 x 110 GB of Y shards)."""
+    rows = prob.y_shape[0]
+    shard_bytes = int(np.prod(prob.y_shape, dtype=np.int64)) * np.dtype(getattr(prob, "y_dt", np.float64)).itemsize
+    need = -(-world * shard_bytes // RING_SLOT_BYTES)
+    return int(max(1, min(rows, max(args.gather_tiles, need))))
+
+
+def gather_phase(args, runner, prob, y, flags, comm, world, n_ranks, steps, warmup):
+    """The timed job followed by the RCCL gather of the Y shards to rank 0 after every step."""
+    from smmregrid_amd.distributed import TiledRingGather
+    ring = TiledRingGather(comm, y, root=0, tiles=gather_tiles_for(args, prob, world), slots=2)
+    g_elapsed, _ = runner.timed(prob, y, flags, steps, warmup, ring=ring)
+    res = {"value": prob.cells() * n_ranks * steps / g_elapsed, "unit": "cells/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": g_elapsed / steps * 1e3, "ranks": comm.world,
+           "gathered_bytes_per_step": ring.gathered_bytes // max(steps + warmup, 1),
+           "tiles": len(ring.tiles), "ring_slots": 2, "overlapped_with_compute": True}
+    for slot in ring.ring or []:
+        if hasattr(slot, "free"):
+            slot.free()
+    return res
+
+
+def compact(obj, digits=6):
+    """Nested blocks of the final line: floats to `digits` significant digits (the line stays small)."""
+    if isinstance(obj, float):
+        return float(f"{obj:.{digits}g}") if math.isfinite(obj) else obj
+    if isinstance(obj, dict):
+        return {k: compact(v, digits) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [compact(v, digits) for v in obj]
+    return obj
+
+
+def final_line(out, details):
+    """The compact last line (driver contract + roofline + cpu_baseline + the per-config blocks): scalars in
+    their own keys, strings short, nested blocks small.  Everything bulky went to the `details` line."""
+    line = dict(out)
+    others = details.get("others") or {}
+    roof = line.get("roofline") or {}
+    if roof.get("traffic") and roof.get("algorithmic_bytes"):
+        roof["traffic_ratio"] = round(roof["traffic"] / roof["algorithmic_bytes"], 3)
+    src = roof.pop("traffic_source", None)
+    if src:
+        roof["traffic_fresh"] = bool(src.get("fresh"))
+        roof["traffic_file"] = short(src.get("file"), 60)
+    if others:
+        native = {"ms": round(roof["kernel_ms"], 4), "frac": round(roof["frac"], 4), "traffic": roof.get("traffic"),
+                  "traffic_ratio": roof.get("traffic_ratio")}
+        if "spot_check" in line:
+            native["spot_check"] = bool(line["spot_check"].get("bit_equal_to_oracle"))
+        sb = layout_summary(others.get("cfg2sb"))
+        roof["layouts"] = {"native": native, "batch_fastest": sb}
+        if "cfg2sbk" in others:
+            roof["layouts"]["batch_fastest_y_kept"] = layout_summary(others.get("cfg2sbk"))
+        # the same figures once more as plain scalars (a record that keeps only scalars still shows them)
+        for key in ("ms", "frac", "traffic_ratio"):
+            if key in sb:
+                roof[f"batch_fastest_{key}"] = sb[key]
+        roof["configs"] = {n: layout_summary(e) for n, e in others.items() if not n.startswith("cfg2sb")}
+        for n, e in roof["configs"].items():
+            if "frac" in e:
+                roof[f"{n}_frac"] = e["frac"]
+    for name, blk in (details.get("baseline_configs") or {}).items():
+        keep = {k: v for k, v in blk.items() if k not in ("workload", "steps", "warmup", "unit", "dtype", "algorithmic_bytes")}
+        if "with_gather" in keep and "value" in keep["with_gather"]:
+            g = keep["with_gather"]
+            keep["with_gather"] = {k: g[k] for k in ("value", "ms_per_step", "ranks", "gathered_bytes_per_step", "tiles", "steps")}
+        line.setdefault("baseline_configs", {})[name] = keep
+    cpu = line.get("cpu_baseline")
+    if cpu:
+        cpu.pop("legs", None)
+        cpu["sample"] = short(cpu["sample"])
+    cfg = line.get("config") or {}
+    cfg.pop("plan", None)
+    for k, v in list(cfg.items()):
+        if isinstance(v, str):
+            cfg[k] = short(v)
+    for key in ("config", "roofline", "cpu_baseline", "with_gather", "baseline_configs", "spot_check"):
+        if key in line:
+            line[key] = compact(line[key])
+    return line
+
+
+def baseline_config_block(args, name, runner, local_rank, rank, world, n_ranks, flags, comm):
+    """One of BASELINE configs 4 / 5 on this run's ranks: every rank regrids its share of the fixed total
+    batch (compute only, then with the tiled gather to rank 0).  Returns rank 0's block (None elsewhere)."""
+    from smmregrid_amd.device import DeviceArray
+    steps, warmup = args.config_steps, args.config_warmup
+    t0 = time.perf_counter()
+    if args.dry_run:
+        prob = DryProblem(name, rank)
+        y = np.zeros(prob.y_shape)
+    else:
+        prob = Problem2D(name, local_rank, rank, batch=args.config_batch or None)
+        y = DeviceArray(prob.y_shape, prob.y_dt)
+    elapsed, kernel_ms = runner.timed(prob, y, flags, steps, warmup)
+    mine, per_rank = runner.kernel_ms_over_ranks(kernel_ms)
+    blk = None
+    if rank == 0:
+        k_avg = mine * 1e-3
+        blk = {"workload": short(prob.desc), "rows_per_gpu": int(getattr(prob, "n_batch", 0)), "dtype": prob.x_dtype,
+               "steps": steps, "warmup": warmup, "n_gpus": n_ranks,
+               "value": prob.cells() * n_ranks * steps / elapsed, "unit": "cells/s",
+               "ms_per_step": elapsed / steps * 1e3, "kernel_ms": mine,
+               "kernel_ms_min": min(per_rank), "kernel_ms_max": max(per_rank),
+               "create_ms": getattr(prob, "create_ms", None)}
+        if not args.dry_run:
+            alg = prob.alg_bytes()
+            blk.update(algorithmic_bytes=alg, frac=alg / k_avg / 1e9 / HBM_PEAK_GBS)
+            chk = prob.spot_check(y)
+            blk["spot_check"] = bool(chk["bit_equal_to_oracle"])
+            if not blk["spot_check"]:
+                raise SystemExit(f"bench.py: {name}: the timed output differs from the CPU oracle: {chk}")
+    if comm is not None and args.gather == "root":
+        try:
+            g = gather_phase(args, runner, prob, y, flags, comm, world, n_ranks, args.config_gather_steps, 1)
+            if rank == 0:
+                blk["with_gather"] = g
+        except Exception as exc:
+            if rank == 0:
+                blk["with_gather"] = {"error": short(repr(exc))}
+    if hasattr(y, "free"):
+        y.free()
+    if hasattr(prob, "free"):
+        prob.free()
+    if rank == 0:
+        blk["setup_and_run_s"] = round(time.perf_counter() - t0, 2)
+    return blk
 
 
 def main():
@@ -847,54 +1077,24 @@ def main():
         flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
         flags |= (args.variant << 16) | (args.jpb << 20)
         new_event, dev_name = Event, device_name(local_rank)
-
-    ring = None
-
-    def step(events=None, gather=False):
-        if gather:
-            # tile k's gather (communication stream) overlaps tile k+1's kernel (null stream)
-            for k, (r0, r1) in enumerate(ring.tiles):
-                prob.run_rows(y, flags, r0, r1)
-                ring.gather_tile(k)
-            ring.finish()
-            return
-        if events:
-            events[0].record()
-        prob.run(y, flags)            # launches on the null stream
-        if events:
-            events[1].record()
-
-    def barrier():
-        synchronize()
-        if rdv:
-            rdv.barrier()
-
-    def timed(gather):
-        """W warm-up steps, then exactly K steps between barriers; MAX over ranks."""
-        for _ in range(args.warmup):
-            step(gather=gather)
-        barrier()
-        ev = [(new_event(), new_event()) for _ in range(args.steps)]
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(ev[k], gather=gather)
-        barrier()
-        dt = time.perf_counter() - t0
-        if rdv:
-            dt = rdv.max(dt)
-        return dt, ([] if gather else [a.elapsed_ms(b) for a, b in ev])   # tiles are not timed one by one
+    runner = Runner(rdv, new_event, synchronize)
 
     # the measured job: every rank regrids its shard, Y shards stay resident on their GPUs
-    elapsed, kernel_ms = timed(gather=False)
+    elapsed, kernel_ms = runner.timed(prob, y, flags, args.steps, args.warmup)
+    k_mine, k_ranks = runner.kernel_ms_over_ranks(kernel_ms)
 
-    out = None
+    out, details = None, {}
     if rank == 0:
-        k_avg = float(np.mean(kernel_ms)) * 1e-3
+        k_avg = k_mine * 1e-3
         cfg = {"workload": prob.desc, "kernel": args.kernel, "gather": args.gather if use_dist else "n/a",
                "comm": args.comm if use_dist else "n/a", "device": dev_name,
                "launched_by": "bench.py" if os.environ.get("LOCAL_WORLD_SIZE") and "TORCHELASTIC_RUN_ID" not in os.environ
-               and world > 1 else ("external launcher" if world > 1 else "single process")}
+               and world > 1 else ("external launcher" if world > 1 else "single process"),
+               "rows_per_gpu": int(getattr(prob, "n_batch", getattr(prob, "n_t", 0))),
+               "layout": "native (B, S)" if getattr(prob, "layout", "bs") == "bs" else "batch-fastest",
+               "resident_in_hbm": True, "create_ms": getattr(prob, "create_ms", None)}
         cfg.update(prob.meta)
+        details["plan"] = cfg.get("plan")
         out = {
             "metric": "regridded cells/sec (dst_pts x time x lev)",
             "value": prob.cells() * n_ranks * args.steps / elapsed,
@@ -919,27 +1119,43 @@ def main():
                 out["spot_check"] = prob.spot_check(y)
                 if not out["spot_check"]["bit_equal_to_oracle"]:
                     raise SystemExit(f"bench.py: the timed output differs from the CPU oracle: {out['spot_check']}")
+        out["roofline"]["kernel_ms_min_rank"] = min(k_ranks)
+        out["roofline"]["kernel_ms_max_rank"] = max(k_ranks)
 
-    # the same job followed by the RCCL gather of the Y shards to rank 0 (north star's exchange step),
-    # reported beside it: xGMI-link bound, see DESIGN.md "Multi-GPU".  The communicator is created only
-    # now; a watchdog prints the line without the gather figures if the phase does not finish in time.
-    if use_dist and args.gather == "root":
-        done = threading.Event()
+    def emit(code=0):
+        """Rank 0: the bulky details first (a line that does not start with '{'), the compact line last."""
+        if rank == 0:
+            out["wall_s"] = time.perf_counter() - t_start
+            print("details: " + json.dumps(details), flush=True)
+            print(json.dumps(final_line(out, details)), flush=True)
+        if code:
+            os._exit(code)
 
-        def give_up():
-            if done.is_set():
-                return
-            if rank == 0:
-                out["with_gather"] = {"error": f"gather phase exceeded {args.gather_timeout:.0f} s"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)     # the compute measurement stands; the line carries the error
+    # Everything that involves RCCL runs under a watchdog: the compute measurement above stands whatever
+    # happens below; a phase that does not finish in time costs its own figures and a non-zero exit status.
+    gather_wanted = use_dist and args.gather == "root"
+    done = threading.Event()
 
+    def give_up():
+        if done.is_set():
+            return
+        if rank == 0:
+            out.setdefault("with_gather", {"error": f"gather phases exceeded {args.gather_timeout:.0f} s"})
+        emit(3)     # start nothing new: the line (with the compute value) is out, the status says what happened
+
+    dog = None
+    if gather_wanted:
         dog = threading.Timer(args.gather_timeout, give_up)
         dog.daemon = True
         dog.start()
-        comm = dist_mod = None
+        if args.dry_run and os.environ.get("SMM_BENCH_TEST_HANG_GATHER") == str(rank):
+            time.sleep(args.gather_timeout + 30)      # tests/test_bench_launch.py: a gather that never returns
+
+    comm = dist_mod = None
+    if gather_wanted:
+        # the same job followed by the RCCL gather of the Y shards to rank 0 (north star's exchange step),
+        # reported beside it: xGMI-link bound, see DESIGN.md "Multi-GPU".  The communicator is created only now.
         try:
-            from smmregrid_amd.distributed import TiledRingGather
             setup_error = b""
             try:
                 comm, dist_mod = make_comm(args, rank, world, local_rank, rdv)
@@ -949,41 +1165,65 @@ def main():
             # would leave the others waiting at the first barrier of the gather phase
             failures = [(r, e.decode()) for r, e in enumerate(rdv.allgather(setup_error)) if e]
             if failures:
+                comm = None
                 raise RuntimeError("communicator set-up failed on rank(s) "
                                    + "; ".join(f"{r}: {e}" for r, e in failures[:3]))
-            ring = TiledRingGather(comm, y, root=0, tiles=args.gather_tiles, slots=2)
-            g_elapsed, _ = timed(gather=True)
+            g = gather_phase(args, runner, prob, y, flags, comm, world, n_ranks, args.steps, args.warmup)
             if rank == 0:
-                out["with_gather"] = {"value": prob.cells() * n_ranks * args.steps / g_elapsed, "unit": "cells/s",
-                                      "ms_per_step": g_elapsed / args.steps * 1e3, "ranks": comm.world,
-                                      "gathered_bytes_per_step": ring.gathered_bytes // max(args.steps + args.warmup, 1),
-                                      "tiles": len(ring.tiles), "ring_slots": 2, "overlapped_with_compute": True}
+                out["with_gather"] = g
         except Exception as exc:  # report, never lose the compute measurement
             if rank == 0:
-                out["with_gather"] = {"error": repr(exc)}
-        done.set()
-        dog.cancel()
-        try:
-            if dist_mod is not None:
-                dist_mod.destroy_process_group()
-            elif comm is not None:
-                comm.close()
-        except Exception:
-            pass
+                out["with_gather"] = {"error": short(repr(exc), 200)}
 
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1 and not args.dry_run:   # CPU baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = prob.cpu_baseline(args.cpu_seconds)
+    if rank == 0 and world == 1 and not args.dry_run:
+        if not args.no_cpu_baseline:                 # CPU baseline: rank 0 at N = 1 only
+            cpu = prob.cpu_baseline(args.cpu_seconds)
+            details["cpu_baseline_legs"] = cpu.get("legs")
+            out["cpu_baseline"] = cpu
+    if hasattr(y, "free"):
+        y.free()
+    if hasattr(prob, "free"):
+        prob.free()
+    if rank == 0 and world == 1 and not args.dry_run:
         names = OTHERS_DEFAULT if args.others == "default" else [n for n in args.others.split(",") if n and n != "none"]
-        if names and world == 1 and not args.dry_run and args.workload == "cfg2" and args.batch is None:
+        if names and args.workload == "cfg2" and args.batch is None:
             unknown = [n for n in names if n not in WORKLOADS]
             if unknown:
                 raise SystemExit(f"bench.py: unknown workload(s) in --others: {unknown}")
-            y.free()
-            prob.free()
-            out["others"] = run_others(args, names, local_rank, flags, t_start)
-        out["wall_s"] = time.perf_counter() - t_start
-        print(json.dumps(out), flush=True)
+            details["others"] = run_others(args, names, local_rank, flags, t_start)
+
+    # BASELINE configs 4 and 5 on the same ranks (each rank its share of the fixed total batch)
+    names = [] if args.configs == "none" else (BASELINE_CONFIGS if args.configs == "default" else
+                                               [n for n in args.configs.split(",") if n])
+    if names and args.workload == "cfg2" and args.batch is None:
+        unknown = [n for n in names if n not in WORKLOADS or WORKLOADS[n][0] == "con3d"]
+        if unknown:
+            raise SystemExit(f"bench.py: --configs takes 2-D workloads, not {unknown}")
+        for name in names:
+            late = time.perf_counter() - t_start > args.others_budget     # rank 0's clock decides for all
+            if rdv:
+                late = rdv.bcast(b"1" if late else b"0") == b"1"
+            if late:
+                if rank == 0:
+                    details.setdefault("baseline_configs", {})[name] = {"skipped": "time budget used up"}
+                continue
+            blk = baseline_config_block(args, name, runner, local_rank, rank, world, n_ranks, flags, comm)
+            if rank == 0:
+                details.setdefault("baseline_configs", {})[name] = blk
+
+    done.set()
+    if dog is not None:
+        dog.cancel()
+    try:
+        if dist_mod is not None:
+            dist_mod.destroy_process_group()
+        elif comm is not None:
+            comm.close()
+    except Exception:
+        pass
+
+    if rank == 0:
+        emit()
 
     if rdv:
         try:

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SMM_ABI_VERSION 3
+#define SMM_ABI_VERSION 4
 
 /* status codes */
 enum {
@@ -197,7 +197,10 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
  * rows walked by one workgroup; rows_per_step: batch rows staged per barrier pair; rows_per_block:
  * destination rows per workgroup; n_blocks: grid size; lds_bytes: dynamic LDS per workgroup;
  * big_operator: the links do not stay in L2, walks are lengthened to amortise their re-read.
- * Any out pointer may be NULL. */
+ * The answer assumes a field whose base, row pitch and strides are multiples of 16 B (what the LDS-DMA
+ * staging needs): smm_apply checks the real field and falls back from kernel 2 to kernel 1 (with that
+ * kernel's rows_per_step / lds_bytes) when it is not.  n_blocks is the whole batch; beyond 2^31 - 1
+ * workgroups smm_apply launches it in parts.  Any out pointer may be NULL. */
 int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, unsigned flags,
                              int* kernel, int* j_per_block, int* rows_per_step, int* rows_per_block,
                              int64_t* n_blocks, int64_t* lds_bytes, int* big_operator);
@@ -327,6 +330,18 @@ int smm_group_apply_host(smm_group_t g,
  * smm_apply_host / smm_group_apply_host call fails with SMM_ERR_HIP before its copies are queued;
  * chunk < 0 (the initial state) switches it off.  Process-wide; for tests only. */
 int smm_debug_fail_at_chunk(int64_t chunk);
+
+/* Launch grids are 1-D: a batch whose grid would exceed 2^31 - 1 workgroups is cut into parts that are
+ * launched one after the other on the same stream (smm_apply / smm_group_apply: halves of the outer batch
+ * range, then of the inner one; smm_apply_sb: runs of whole 128-entry batch tiles).  This test hook lowers
+ * that limit so that small inputs reach the split path; 0 restores the default.  Process-wide; for tests only. */
+int smm_debug_set_grid_limit(int64_t max_blocks);
+
+/* Host threads of operator creation (the sort / duplicate sum replacing weights.py:25-44, the SELL layout and
+ * the tile plans are built on several cores): n > 0 fixes the count, 0 (the initial state) = automatic -- the
+ * hardware threads, at most 16, shared between the creations running at that moment.  The operator does not
+ * depend on the count.  *previous (may be NULL) receives the former setting.  Process-wide. */
+int smm_set_host_threads(int n, int* previous);
 
 /* ------------------------------------------------- multi-GPU exchange (RCCL over xGMI) */
 

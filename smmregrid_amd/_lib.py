@@ -108,6 +108,8 @@ SIGNATURES = {
     "smm_group_apply_sb": [_p, _p, _int, _i64, _i64, _p, _int, _i64, _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
     "smm_group_apply_host": [_p, _p, _int, _p, _int, _i64, _i64, _i64, _int, _p, _p, _dbl, _uint, _i64],
     "smm_debug_fail_at_chunk": [_i64],
+    "smm_debug_set_grid_limit": [_i64],
+    "smm_set_host_threads": [_int, ctypes.POINTER(_int)],
     "smm_comm_unique_id": [_p],
     "smm_comm_create": [_p, _int, _int, _pp],
     "smm_comm_destroy": [_p],

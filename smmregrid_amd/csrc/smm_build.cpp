@@ -7,9 +7,80 @@
 #include "smm_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 namespace smm {
+
+static std::atomic<int> g_host_threads{0};      // 0 = automatic
+static std::atomic<int> g_active_builders{0};   // builders inside a parallel section right now
+
+int set_host_threads(int n) { return g_host_threads.exchange(n < 0 ? 0 : n); }
+
+int host_threads(int64_t work_items, int64_t min_items_per_thread) {
+  const int fixed = g_host_threads.load();
+  if (fixed > 0) return fixed;   // the caller's count, whatever the work (tests force small inputs through every path)
+  const int hw = (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+  const int share = std::max(1, hw / std::max(1, g_active_builders.load()));
+  const int64_t by_work = std::max<int64_t>(1, work_items / std::max<int64_t>(1, min_items_per_thread));
+  return (int)std::min<int64_t>(share, by_work);
+}
+
+namespace {
+
+struct BuilderScope {   // counts this builder among the active ones for the automatic thread share
+  BuilderScope() { g_active_builders.fetch_add(1); }
+  ~BuilderScope() { g_active_builders.fetch_sub(1); }
+};
+
+// fn(t, lo, hi) over [0, n) cut into `nt` contiguous ranges; the calling thread takes range 0.
+template <typename F>
+void parallel_ranges(int64_t n, int nt, F fn) {
+  nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, n));
+  if (nt == 1) {
+    fn(0, (int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve((size_t)nt - 1);
+  for (int t = 1; t < nt; ++t) pool.emplace_back([=, &fn] { fn(t, n * t / nt, n * (t + 1) / nt); });
+  fn(0, (int64_t)0, n / nt);
+  for (auto& th : pool) th.join();
+}
+
+}  // namespace
+
+namespace {
+
+inline void mark_byte(uint8_t* p) { __atomic_store_n(p, (uint8_t)1, __ATOMIC_RELAXED); }
+
+// n_used_src and max_row_nnz of a finished CSR (parallel over links / rows).
+void finish_csr_stats(HostCsr& out, int nt) {
+  std::vector<uint8_t> used((size_t)out.n_src, 0);
+  parallel_ranges(out.nnz, nt, [&](int, int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; ++i) mark_byte(&used[(size_t)out.col[(size_t)i]]);
+  });
+  std::vector<int64_t> part_u((size_t)nt, 0), part_m((size_t)nt, 0);
+  parallel_ranges(out.n_src, nt, [&](int t, int64_t lo, int64_t hi) {
+    int64_t u = 0;
+    for (int64_t s = lo; s < hi; ++s) u += used[(size_t)s];
+    part_u[(size_t)t] = u;
+  });
+  parallel_ranges(out.n_dst, nt, [&](int t, int64_t lo, int64_t hi) {
+    int64_t m = 0;
+    for (int64_t d = lo; d < hi; ++d) m = std::max(m, out.rowptr[(size_t)d + 1] - out.rowptr[(size_t)d]);
+    part_m[(size_t)t] = m;
+  });
+  out.n_used_src = 0;
+  out.max_row_nnz = 0;
+  for (int t = 0; t < nt; ++t) {
+    out.n_used_src += part_u[(size_t)t];
+    out.max_row_nnz = std::max(out.max_row_nnz, part_m[(size_t)t]);
+  }
+}
+
+}  // namespace
 
 bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
                const int32_t* dst1, const double* w, HostCsr& out, std::string& err) {
@@ -25,71 +96,203 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
     err = "null link array";
     return false;
   }
-  for (int64_t k = 0; k < nnz; ++k) {
-    const int64_t s = (int64_t)src1[k] - 1, d = (int64_t)dst1[k] - 1;
-    if (s < 0 || s >= n_src) {
-      err = "src_address[" + std::to_string(k) + "]=" + std::to_string(src1[k]) +
-            " outside 1.." + std::to_string(n_src);
-      return false;
-    }
-    if (d < 0 || d >= n_dst) {
-      err = "dst_address[" + std::to_string(k) + "]=" + std::to_string(dst1[k]) +
-            " outside 1.." + std::to_string(n_dst);
-      return false;
-    }
-  }
+  BuilderScope scope;
+  const int nt = host_threads(nnz, (int64_t)1 << 17);
 
-  // Two stable counting sorts (LSD): by src, then by dst -> order (dst, src, original k).
-  std::vector<int32_t> by_src((size_t)nnz), order((size_t)nnz);
+  // pass 1: addresses in range (the lowest bad index is reported, src before dst) and, on the way,
+  // whether the links already come ordered by (dst, src) -- what `cdo gen*` writes
+  std::vector<int64_t> first_bad((size_t)nt, nnz);
+  std::vector<uint8_t> unsorted((size_t)nt, 0);
+  parallel_ranges(nnz, nt, [&](int t, int64_t lo, int64_t hi) {
+    uint8_t uns = 0;
+    for (int64_t k = lo; k < hi; ++k) {
+      const int64_t s = (int64_t)src1[k] - 1, d = (int64_t)dst1[k] - 1;
+      if (s < 0 || s >= n_src || d < 0 || d >= n_dst) {
+        first_bad[(size_t)t] = k;
+        break;
+      }
+      if (k > 0 && (dst1[k - 1] > dst1[k] || (dst1[k - 1] == dst1[k] && src1[k - 1] > src1[k]))) uns = 1;
+    }
+    unsorted[(size_t)t] = uns;
+  });
   {
-    std::vector<int64_t> pos((size_t)n_src + 1, 0);
-    for (int64_t k = 0; k < nnz; ++k) pos[(size_t)src1[k]]++;  // src1-1+1
-    for (int64_t s = 0; s < n_src; ++s) pos[(size_t)s + 1] += pos[(size_t)s];
-    for (int64_t k = 0; k < nnz; ++k) by_src[(size_t)pos[(size_t)src1[k] - 1]++] = (int32_t)k;
-  }
-  std::vector<int64_t> rawptr((size_t)n_dst + 1, 0);
-  {
-    for (int64_t k = 0; k < nnz; ++k) rawptr[(size_t)dst1[k]]++;
-    for (int64_t d = 0; d < n_dst; ++d) rawptr[(size_t)d + 1] += rawptr[(size_t)d];
-    std::vector<int64_t> pos(rawptr.begin(), rawptr.end() - 1);
-    for (int64_t i = 0; i < nnz; ++i) {
-      const int32_t k = by_src[(size_t)i];
-      order[(size_t)pos[(size_t)dst1[k] - 1]++] = k;
+    const int64_t k = *std::min_element(first_bad.begin(), first_bad.end());
+    if (k < nnz) {
+      const int64_t s = (int64_t)src1[k] - 1;
+      if (s < 0 || s >= n_src)
+        err = "src_address[" + std::to_string(k) + "]=" + std::to_string(src1[k]) + " outside 1.." + std::to_string(n_src);
+      else
+        err = "dst_address[" + std::to_string(k) + "]=" + std::to_string(dst1[k]) + " outside 1.." + std::to_string(n_dst);
+      return false;
     }
   }
-  by_src.clear();
-  by_src.shrink_to_fit();
+  const bool sorted = std::none_of(unsorted.begin(), unsorted.end(), [](uint8_t u) { return u != 0; });
 
   out.n_src = n_src;
   out.n_dst = n_dst;
   out.rowptr.assign((size_t)n_dst + 1, 0);
   out.col.clear();
   out.val.clear();
-  out.col.reserve((size_t)nnz);
-  out.val.reserve((size_t)nnz);
-  out.max_row_nnz = 0;
-  for (int64_t d = 0; d < n_dst; ++d) {
-    const int64_t row_start = (int64_t)out.col.size();
-    for (int64_t i = rawptr[(size_t)d]; i < rawptr[(size_t)d + 1]; ++i) {
-      const int32_t k = order[(size_t)i];
-      const int32_t s = src1[k] - 1;
-      if ((int64_t)out.col.size() > row_start && out.col.back() == s) {
-        out.val.back() += w[k];  // duplicate coordinate: summed in original link order
-      } else {
-        out.col.push_back(s);
-        out.val.push_back(w[k]);
-      }
-    }
-    out.rowptr[(size_t)d + 1] = (int64_t)out.col.size();
-    out.max_row_nnz = std::max(out.max_row_nnz, (int64_t)out.col.size() - row_start);
-  }
-  out.nnz = (int64_t)out.col.size();
 
-  std::vector<uint8_t> used((size_t)n_src, 0);
-  for (int32_t c : out.col) used[(size_t)c] = 1;
-  int64_t u = 0;
-  for (uint8_t b : used) u += b;
-  out.n_used_src = u;
+  auto same = [&](int64_t a, int64_t b) { return dst1[a] == dst1[b] && src1[a] == src1[b]; };
+
+  if (sorted) {
+    // Ordered input: a coordinate is a run of equal (dst, src); a run is summed in link order by the
+    // thread its first link belongs to (range starts are moved to run starts).
+    std::vector<int64_t> lo_of((size_t)nt + 1, nnz), kept((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; ++t) {
+      int64_t lo = nnz * t / nt;
+      while (lo > 0 && lo < nnz && same(lo, lo - 1)) ++lo;
+      lo_of[(size_t)t] = lo;
+    }
+    for (int t = nt - 1; t > 0; --t) lo_of[(size_t)t] = std::max(lo_of[(size_t)t], lo_of[(size_t)t - 1]);
+    lo_of[0] = 0;
+    std::vector<std::thread> pool;
+    auto count = [&](int t) {
+      int64_t n = 0;
+      for (int64_t k = lo_of[(size_t)t]; k < lo_of[(size_t)t + 1]; ++k) n += (k == lo_of[(size_t)t] || !same(k, k - 1));
+      kept[(size_t)t + 1] = n;
+    };
+    for (int t = 1; t < nt; ++t) pool.emplace_back(count, t);
+    count(0);
+    for (auto& th : pool) th.join();
+    pool.clear();
+    for (int t = 0; t < nt; ++t) kept[(size_t)t + 1] += kept[(size_t)t];
+    const int64_t total = kept[(size_t)nt];
+    out.col.resize((size_t)total);
+    out.val.resize((size_t)total);
+    auto fill = [&](int t) {
+      const int64_t lo = lo_of[(size_t)t], hi = lo_of[(size_t)t + 1];
+      int64_t p = kept[(size_t)t] - 1;
+      // rowptr[r] = kept entries of rows < r: written where the row index steps up
+      int64_t prev_row = lo > 0 ? (int64_t)dst1[lo - 1] - 1 : -1;
+      for (int64_t k = lo; k < hi; ++k) {
+        if (k == lo || !same(k, k - 1)) {
+          ++p;
+          out.col[(size_t)p] = src1[k] - 1;
+          out.val[(size_t)p] = w[k];
+          const int64_t row = (int64_t)dst1[k] - 1;
+          for (int64_t r = prev_row + 1; r <= row; ++r) out.rowptr[(size_t)r] = p;
+          prev_row = row;
+        } else {
+          out.val[(size_t)p] += w[k];   // duplicate coordinate: summed in original link order
+        }
+      }
+    };
+    for (int t = 1; t < nt; ++t) pool.emplace_back(fill, t);
+    fill(0);
+    for (auto& th : pool) th.join();
+    for (int64_t r = (nnz > 0 ? (int64_t)dst1[nnz - 1] : 0); r <= n_dst; ++r) out.rowptr[(size_t)r] = total;  // rows after the last link
+    out.nnz = total;
+    finish_csr_stats(out, nt);
+    return true;
+  }
+
+  // General input.  Links are dealt into `nb` buckets of consecutive destination rows (stable: thread
+  // ranges in order, links of a range in order); every bucket is then ordered by (dst, src, link index)
+  // by its own thread -- a stable counting sort by row, a stable sort by source cell inside each row --
+  // and its duplicate coordinates are summed in that order.
+  const int nb = nt;
+  auto bucket_of = [&](int32_t d1) { return (int)(((int64_t)d1 - 1) * nb / std::max<int64_t>(n_dst, 1)); };
+  std::vector<int64_t> cnt((size_t)nt * nb, 0);
+  parallel_ranges(nnz, nt, [&](int t, int64_t lo, int64_t hi) {
+    int64_t* c = &cnt[(size_t)t * nb];
+    for (int64_t k = lo; k < hi; ++k) ++c[bucket_of(dst1[k])];
+  });
+  std::vector<int64_t> bstart((size_t)nb + 1, 0), off((size_t)nt * nb, 0);
+  for (int b = 0; b < nb; ++b) {
+    int64_t run = bstart[(size_t)b];
+    for (int t = 0; t < nt; ++t) {
+      off[(size_t)t * nb + b] = run;
+      run += cnt[(size_t)t * nb + b];
+    }
+    bstart[(size_t)b + 1] = run;
+  }
+  std::vector<int32_t> idx((size_t)nnz), order((size_t)nnz);
+  parallel_ranges(nnz, nt, [&](int t, int64_t lo, int64_t hi) {
+    int64_t* o = &off[(size_t)t * nb];
+    for (int64_t k = lo; k < hi; ++k) idx[(size_t)o[bucket_of(dst1[k])]++] = (int32_t)k;
+  });
+  std::vector<std::vector<int32_t>> loc_col((size_t)nb);
+  std::vector<std::vector<double>> loc_val((size_t)nb);
+  {
+    std::vector<std::thread> pool;
+    auto work = [&](int b) {
+      // rows of this bucket: floor(d * nb / n_dst) == b  <=>  ceil(b * n_dst / nb) <= d < ceil((b + 1) * n_dst / nb)
+      const int64_t r0 = (n_dst * b + nb - 1) / nb, r1 = (n_dst * (b + 1) + nb - 1) / nb;
+      const int64_t i0 = bstart[(size_t)b], i1 = bstart[(size_t)b + 1];
+      std::vector<int64_t> pos((size_t)(r1 - r0) + 1, 0);
+      for (int64_t i = i0; i < i1; ++i) ++pos[(size_t)(dst1[idx[(size_t)i]] - 1 - r0) + 1];
+      for (int64_t r = 0; r < r1 - r0; ++r) pos[(size_t)r + 1] += pos[(size_t)r];
+      std::vector<int64_t> row_end(pos.begin() + 1, pos.end());
+      {
+        std::vector<int64_t> cur(pos.begin(), pos.end() - 1);
+        for (int64_t i = i0; i < i1; ++i) {
+          const int32_t k = idx[(size_t)i];
+          order[(size_t)(i0 + cur[(size_t)(dst1[k] - 1 - r0)]++)] = k;
+        }
+      }
+      std::vector<int32_t>& lc = loc_col[(size_t)b];
+      std::vector<double>& lv = loc_val[(size_t)b];
+      lc.reserve((size_t)(i1 - i0));
+      lv.reserve((size_t)(i1 - i0));
+      for (int64_t r = 0; r < r1 - r0; ++r) {
+        int32_t* a = &order[(size_t)(i0 + (r ? row_end[(size_t)r - 1] : 0))];
+        const int64_t len = row_end[(size_t)r] - (r ? row_end[(size_t)r - 1] : 0);
+        if (len <= 32) {   // stable insertion sort by source cell
+          for (int64_t i = 1; i < len; ++i) {
+            const int32_t k = a[i];
+            const int32_t s = src1[k];
+            int64_t j = i;
+            while (j > 0 && src1[a[j - 1]] > s) {
+              a[j] = a[j - 1];
+              --j;
+            }
+            a[j] = k;
+          }
+        } else {
+          std::stable_sort(a, a + len, [&](int32_t x, int32_t y) { return src1[x] < src1[y]; });
+        }
+        const size_t row_start = lc.size();
+        for (int64_t i = 0; i < len; ++i) {
+          const int32_t k = a[i];
+          const int32_t s = src1[k] - 1;
+          if (lc.size() > row_start && lc.back() == s) {
+            lv.back() += w[k];  // duplicate coordinate: summed in original link order
+          } else {
+            lc.push_back(s);
+            lv.push_back(w[k]);
+          }
+        }
+        out.rowptr[(size_t)(r0 + r) + 1] = (int64_t)(lc.size() - row_start);   // row length for now
+      }
+    };
+    for (int b = 1; b < nb; ++b) pool.emplace_back(work, b);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  idx.clear();
+  idx.shrink_to_fit();
+  order.clear();
+  order.shrink_to_fit();
+  for (int64_t d = 0; d < n_dst; ++d) out.rowptr[(size_t)d + 1] += out.rowptr[(size_t)d];
+  out.nnz = out.rowptr[(size_t)n_dst];
+  out.col.resize((size_t)out.nnz);
+  out.val.resize((size_t)out.nnz);
+  {
+    std::vector<int64_t> at((size_t)nb + 1, 0);
+    for (int b = 0; b < nb; ++b) at[(size_t)b + 1] = at[(size_t)b] + (int64_t)loc_col[(size_t)b].size();
+    std::vector<std::thread> pool;
+    auto copy = [&](int b) {
+      if (loc_col[(size_t)b].empty()) return;
+      memcpy(&out.col[(size_t)at[(size_t)b]], loc_col[(size_t)b].data(), loc_col[(size_t)b].size() * sizeof(int32_t));
+      memcpy(&out.val[(size_t)at[(size_t)b]], loc_val[(size_t)b].data(), loc_val[(size_t)b].size() * sizeof(double));
+    };
+    for (int b = 1; b < nb; ++b) pool.emplace_back(copy, b);
+    copy(0);
+    for (auto& th : pool) th.join();
+  }
+  finish_csr_stats(out, nt);
   return true;
 }
 
@@ -230,34 +433,48 @@ HostChunk host_chunk_units(int64_t n_units, size_t x_unit, size_t y_unit, size_t
 }
 
 void build_sell(const HostCsr& csr, HostSell& out) {
+  BuilderScope scope;
+  const int nt = host_threads(csr.nnz + csr.n_dst, (int64_t)1 << 17);
   const int64_t n_slices = (csr.n_dst + 63) / 64;
   out.n_slices = n_slices;
   out.slice_off.assign((size_t)n_slices + 1, 0);
   out.rowlen.assign((size_t)n_slices * 64, 0);
-  for (int64_t d = 0; d < csr.n_dst; ++d)
-    out.rowlen[(size_t)d] = (int32_t)(csr.rowptr[(size_t)d + 1] - csr.rowptr[(size_t)d]);
-  for (int64_t s = 0; s < n_slices; ++s) {
-    int32_t m = 0;
-    for (int r = 0; r < 64; ++r) m = std::max(m, out.rowlen[(size_t)s * 64 + r]);
-    out.slice_off[(size_t)s + 1] = out.slice_off[(size_t)s] + (int64_t)m * 64;
-  }
-  out.n_slots = out.slice_off[(size_t)n_slices];
-  out.col.assign((size_t)out.n_slots, 0);
-  out.val.assign((size_t)out.n_slots, 0.0);
-  for (int64_t d = 0; d < csr.n_dst; ++d) {
-    const int64_t s = d >> 6, r = d & 63;
-    const int64_t base = out.slice_off[(size_t)s] + r;
-    const int64_t p0 = csr.rowptr[(size_t)d];
-    const int32_t len = out.rowlen[(size_t)d];
-    for (int32_t k = 0; k < len; ++k) {
-      out.col[(size_t)(base + (int64_t)k * 64)] = csr.col[(size_t)(p0 + k)];
-      out.val[(size_t)(base + (int64_t)k * 64)] = csr.val[(size_t)(p0 + k)];
+  parallel_ranges(n_slices, nt, [&](int, int64_t lo, int64_t hi) {
+    for (int64_t s = lo; s < hi; ++s) {
+      int32_t m = 0;
+      for (int64_t d = s * 64; d < std::min(csr.n_dst, s * 64 + 64); ++d) {
+        const int32_t len = (int32_t)(csr.rowptr[(size_t)d + 1] - csr.rowptr[(size_t)d]);
+        out.rowlen[(size_t)d] = len;
+        m = std::max(m, len);
+      }
+      out.slice_off[(size_t)s + 1] = (int64_t)m * 64;   // slots of the slice for now
     }
-    // padding slots of the slice repeat the row's last column (a cached, valid address)
-    const int64_t nslots = (out.slice_off[(size_t)s + 1] - out.slice_off[(size_t)s]) / 64;
-    const int32_t padcol = len > 0 ? csr.col[(size_t)(p0 + len - 1)] : 0;
-    for (int64_t k = len; k < nslots; ++k) out.col[(size_t)(base + k * 64)] = padcol;
-  }
+  });
+  for (int64_t s = 0; s < n_slices; ++s) out.slice_off[(size_t)s + 1] += out.slice_off[(size_t)s];
+  out.n_slots = out.slice_off[(size_t)n_slices];
+  out.col.resize((size_t)out.n_slots);
+  out.val.resize((size_t)out.n_slots);
+  parallel_ranges(n_slices, nt, [&](int, int64_t lo, int64_t hi) {
+    for (int64_t s = lo; s < hi; ++s) {
+      const int64_t nslots = (out.slice_off[(size_t)s + 1] - out.slice_off[(size_t)s]) / 64;
+      for (int64_t r = 0; r < 64; ++r) {
+        const int64_t d = s * 64 + r;
+        const int64_t base = out.slice_off[(size_t)s] + r;
+        const int32_t len = out.rowlen[(size_t)d];
+        const int64_t p0 = d < csr.n_dst ? csr.rowptr[(size_t)d] : 0;
+        for (int32_t k = 0; k < len; ++k) {
+          out.col[(size_t)(base + (int64_t)k * 64)] = csr.col[(size_t)(p0 + k)];
+          out.val[(size_t)(base + (int64_t)k * 64)] = csr.val[(size_t)(p0 + k)];
+        }
+        // padding slots of the slice repeat the row's last column (a cached, valid address), weight 0
+        const int32_t padcol = len > 0 ? csr.col[(size_t)(p0 + len - 1)] : 0;
+        for (int64_t k = len; k < nslots; ++k) {
+          out.col[(size_t)(base + k * 64)] = padcol;
+          out.val[(size_t)(base + k * 64)] = 0.0;
+        }
+      }
+    }
+  });
 }
 
 void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_block_,
@@ -266,72 +483,119 @@ void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_
   plan.rows_per_block = rows_per_block_;
   plan.chunk_elems = chunk_elems;
   if (csr.n_dst == 0 || rows_per_block_ <= 0 || chunk_elems <= 0) return;
+  BuilderScope scope;
   const int64_t rows_per_block = rows_per_block_;
   const int64_t n_blocks = (csr.n_dst + rows_per_block - 1) / rows_per_block;
+  const int nt = host_threads(csr.nnz + csr.n_dst, (int64_t)1 << 16);
   plan.n_blocks = n_blocks;
   plan.blk_chunk_off.assign((size_t)n_blocks + 1, 0);
   plan.blk_direct.assign((size_t)n_blocks, 0);
   plan.blk_lines.assign((size_t)n_blocks, 0);
-  plan.lcol.assign((size_t)sell.n_slots, 0);
+  plan.lcol.resize((size_t)sell.n_slots);
   constexpr int32_t kLineElems = 16;   // a 128-B line of f64
 
-  std::vector<int32_t> chunks, cols;
-  for (int64_t b = 0; b < n_blocks; ++b) {
-    const int64_t d0 = b * rows_per_block;
-    const int64_t d1 = std::min(csr.n_dst, d0 + rows_per_block);
-    cols.assign(csr.col.begin() + csr.rowptr[(size_t)d0], csr.col.begin() + csr.rowptr[(size_t)d1]);
-    std::sort(cols.begin(), cols.end());
-    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-    plan.total_distinct += (int64_t)cols.size();
-    chunks.clear();
-    for (int32_t c : cols) {
-      const int32_t ch = c / chunk_elems;
-      if (chunks.empty() || chunks.back() != ch) chunks.push_back(ch);
-    }
-    if ((int64_t)chunks.size() > max_chunks_per_block) {
-      // too wide for LDS (polar caps of HEALPix targets, folds of tripolar grids ...): the kernel
-      // gathers this block's links straight from X
-      plan.blk_direct[(size_t)b] = 1;
-      plan.direct_links += csr.rowptr[(size_t)d1] - csr.rowptr[(size_t)d0];
-      plan.blk_chunk_off[(size_t)b + 1] = (int64_t)plan.chunk_src.size();
-      continue;
-    }
-    plan.max_block_chunks = std::max(plan.max_block_chunks, (int64_t)chunks.size());
-    {
-      int32_t lines = 0, last = -1;
+  // Blocks are independent: thread t plans a contiguous range of them into its own chunk list (the lists
+  // are concatenated in block order afterwards) and writes the LDS-local columns of its blocks' links.
+  struct Part {
+    std::vector<int32_t> chunk_src;
+    int64_t total_distinct = 0, direct_links = 0, max_block_chunks = 0, total_lines = 0;
+  };
+  std::vector<Part> parts((size_t)nt);
+  std::vector<uint8_t> chunk_seen((size_t)(csr.n_src / chunk_elems) + 1, 0);   // distinct chunks over the operator
+  parallel_ranges(n_blocks, nt, [&](int t, int64_t b_lo, int64_t b_hi) {
+    Part& me = parts[(size_t)t];
+    std::vector<int32_t> chunks, cols;
+    for (int64_t b = b_lo; b < b_hi; ++b) {
+      const int64_t d0 = b * rows_per_block;
+      const int64_t d1 = std::min(csr.n_dst, d0 + rows_per_block);
+      cols.assign(csr.col.begin() + csr.rowptr[(size_t)d0], csr.col.begin() + csr.rowptr[(size_t)d1]);
+      std::sort(cols.begin(), cols.end());
+      cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+      me.total_distinct += (int64_t)cols.size();
+      chunks.clear();
       for (int32_t c : cols) {
-        if (c / kLineElems != last) {
-          last = c / kLineElems;
-          ++lines;
+        const int32_t ch = c / chunk_elems;
+        if (chunks.empty() || chunks.back() != ch) chunks.push_back(ch);
+      }
+      // lcol slots of rows past a row's length (SELL padding) stay 0 as before
+      for (int64_t d = d0; d < d1; ++d) {
+        const int64_t s = d >> 6, r = d & 63;
+        const int64_t sbase = sell.slice_off[(size_t)s] + r;
+        const int64_t nslots = (sell.slice_off[(size_t)s + 1] - sell.slice_off[(size_t)s]) / 64;
+        for (int64_t k = 0; k < nslots; ++k) plan.lcol[(size_t)(sbase + k * 64)] = 0;
+      }
+      if ((int64_t)chunks.size() > max_chunks_per_block) {
+        // too wide for LDS (polar caps of HEALPix targets, folds of tripolar grids ...): the kernel
+        // gathers this block's links straight from X
+        plan.blk_direct[(size_t)b] = 1;
+        me.direct_links += csr.rowptr[(size_t)d1] - csr.rowptr[(size_t)d0];
+        continue;   // blk_chunk_off[b + 1] holds the block's chunk count (0) until the prefix sum
+      }
+      me.max_block_chunks = std::max(me.max_block_chunks, (int64_t)chunks.size());
+      {
+        int32_t lines = 0, last = -1;
+        for (int32_t c : cols) {
+          if (c / kLineElems != last) {
+            last = c / kLineElems;
+            ++lines;
+          }
+        }
+        plan.blk_lines[(size_t)b] = lines;
+        me.total_lines += lines;
+      }
+      me.chunk_src.insert(me.chunk_src.end(), chunks.begin(), chunks.end());
+      plan.blk_chunk_off[(size_t)b + 1] = (int64_t)chunks.size();
+      for (int32_t ch : chunks) mark_byte(&chunk_seen[(size_t)ch]);
+      // LDS-local column of every link of the block
+      for (int64_t d = d0; d < d1; ++d) {
+        const int64_t s = d >> 6, r = d & 63;
+        const int64_t sbase = sell.slice_off[(size_t)s] + r;
+        const int64_t p0 = csr.rowptr[(size_t)d];
+        const int32_t len = sell.rowlen[(size_t)d];
+        for (int32_t k = 0; k < len; ++k) {
+          const int32_t c = csr.col[(size_t)(p0 + k)];
+          const int32_t ch = c / chunk_elems;
+          const int64_t li =
+              std::lower_bound(chunks.begin(), chunks.end(), ch) - chunks.begin();
+          plan.lcol[(size_t)(sbase + (int64_t)k * 64)] =
+              (int32_t)(li * chunk_elems + (c - ch * chunk_elems));
         }
       }
-      plan.blk_lines[(size_t)b] = lines;
-      plan.total_lines += lines;
     }
-    const int64_t base = (int64_t)plan.chunk_src.size();
-    plan.chunk_src.insert(plan.chunk_src.end(), chunks.begin(), chunks.end());
-    plan.blk_chunk_off[(size_t)b + 1] = base + (int64_t)chunks.size();
-    // LDS-local column of every link of the block
-    for (int64_t d = d0; d < d1; ++d) {
-      const int64_t s = d >> 6, r = d & 63;
-      const int64_t sbase = sell.slice_off[(size_t)s] + r;
-      const int64_t p0 = csr.rowptr[(size_t)d];
-      const int32_t len = sell.rowlen[(size_t)d];
-      for (int32_t k = 0; k < len; ++k) {
-        const int32_t c = csr.col[(size_t)(p0 + k)];
-        const int32_t ch = c / chunk_elems;
-        const int64_t li =
-            std::lower_bound(chunks.begin(), chunks.end(), ch) - chunks.begin();
-        plan.lcol[(size_t)(sbase + (int64_t)k * 64)] =
-            (int32_t)(li * chunk_elems + (c - ch * chunk_elems));
-      }
-    }
+  });
+  // rows of the last slice past n_dst belong to no block: their slots stay 0 too
+  for (int64_t d = csr.n_dst; d < sell.n_slices * 64; ++d) {
+    const int64_t s = d >> 6, r = d & 63;
+    const int64_t nslots = (sell.slice_off[(size_t)s + 1] - sell.slice_off[(size_t)s]) / 64;
+    for (int64_t k = 0; k < nslots; ++k) plan.lcol[(size_t)(sell.slice_off[(size_t)s] + r + k * 64)] = 0;
   }
-  plan.total_chunks = (int64_t)plan.chunk_src.size();
+  for (int64_t b = 0; b < n_blocks; ++b) plan.blk_chunk_off[(size_t)b + 1] += plan.blk_chunk_off[(size_t)b];
+  plan.total_chunks = plan.blk_chunk_off[(size_t)n_blocks];
+  plan.chunk_src.resize((size_t)plan.total_chunks);
   {
-    std::vector<int32_t> all(plan.chunk_src);
-    std::sort(all.begin(), all.end());
-    plan.distinct_chunks = (int64_t)(std::unique(all.begin(), all.end()) - all.begin());
+    std::vector<int64_t> at((size_t)nt + 1, 0);
+    for (int t = 0; t < nt; ++t) {
+      at[(size_t)t + 1] = at[(size_t)t] + (int64_t)parts[(size_t)t].chunk_src.size();
+      plan.total_distinct += parts[(size_t)t].total_distinct;
+      plan.direct_links += parts[(size_t)t].direct_links;
+      plan.total_lines += parts[(size_t)t].total_lines;
+      plan.max_block_chunks = std::max(plan.max_block_chunks, parts[(size_t)t].max_block_chunks);
+    }
+    parallel_ranges(nt, nt, [&](int, int64_t lo, int64_t hi) {
+      for (int64_t t = lo; t < hi; ++t)
+        if (!parts[(size_t)t].chunk_src.empty())
+          memcpy(&plan.chunk_src[(size_t)at[(size_t)t]], parts[(size_t)t].chunk_src.data(),
+                 parts[(size_t)t].chunk_src.size() * sizeof(int32_t));
+    });
+  }
+  {
+    std::vector<int64_t> part((size_t)nt, 0);
+    parallel_ranges((int64_t)chunk_seen.size(), nt, [&](int t, int64_t lo, int64_t hi) {
+      int64_t n = 0;
+      for (int64_t i = lo; i < hi; ++i) n += chunk_seen[(size_t)i];
+      part[(size_t)t] = n;
+    });
+    for (int64_t n : part) plan.distinct_chunks += n;
   }
   plan.valid = plan.direct_links * 4 <= csr.nnz;
 }

@@ -343,6 +343,10 @@ int ensure_sb(smm_operator* op) {
   return SMM_OK;
 }
 
+// largest 1-D launch grid (workgroups); smm_debug_set_grid_limit lowers it so that tests reach the split path
+std::atomic<int64_t> g_grid_limit{0x7fffffffLL};
+inline int64_t grid_limit() { return g_grid_limit.load(); }
+
 struct LaunchInfo {
   bool tile = false, big_operator = false, dma = false;
   int j_per_block = 0, rows_per_step = 1, rows_per_block = 0;
@@ -434,9 +438,34 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
     }
     return SMM_OK;
   }
-  if (use_tile)
-    return SMM_DISPATCH(launch_tile, a, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_flags, fill, flags, s);
-  return SMM_DISPATCH(launch_sell, a, n_lev, fill, flags, s);
+  // One launch when the grid fits (always, short of ~2^31 workgroups); else the batch is cut into parts
+  // (smm::split_batch) that are launched one after the other on the same stream.
+  auto blocks_for = [&](int64_t n_o, int64_t n_i) -> int64_t {
+    ApplyArgs t = a;
+    t.n_j = n_o * n_i;
+    t.n_inner = n_i;
+    if (use_tile)
+      return smm_launch::tile_launch_cfg(t, n_lev, tile_which, tile_max_chunks, max_row_nnz, flags, xsz).total;
+    const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
+    const int bt = (t.n_j >= 8 && variant == 1) ? 8 : ((t.n_j >= 4 && variant <= 1) ? 4 : (t.n_j >= 2 ? 2 : 1));
+    return t.n_dblocks * ((t.n_j + bt - 1) / bt) * n_lev;
+  };
+  const size_t ysz = y_dtype == SMM_F64 ? 8 : 4;
+  auto launch_part = [&](int64_t o0, int64_t n_o, int64_t i0, int64_t n_i) -> int {
+    ApplyArgs p = a;
+    p.x = (const char*)x + (o0 * xs_o + i0 * xs_i) * (int64_t)xsz;
+    p.y = (char*)y + (o0 * ys_o + i0 * ys_i) * (int64_t)ysz;
+    p.n_j = n_o * n_i;
+    p.n_inner = n_i;
+    if (use_tile)
+      return SMM_DISPATCH(launch_tile, p, n_lev, tile_which, tile_max_chunks, max_row_nnz, tile_flags, fill, flags, s);
+    return SMM_DISPATCH(launch_sell, p, n_lev, fill, flags, s);
+  };
+  const int rc = smm::split_batch(0, n_outer, 0, n_inner, grid_limit(), blocks_for, launch_part);
+  if (rc == -1)
+    return fail(SMM_ERR_INVALID, "one batch row alone needs a launch grid beyond " + std::to_string(grid_limit()) +
+                                     " workgroups (destination blocks x levels)");
+  return rc;
 #undef SMM_DISPATCH
 }
 
@@ -635,6 +664,19 @@ int smm_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, s
     SMM_HIP(hipMemcpy2D(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost));
   return SMM_OK;
 }
+int smm_debug_set_grid_limit(int64_t max_blocks) {
+  if (max_blocks < 0) return fail(SMM_ERR_INVALID, "negative grid limit");
+  g_grid_limit.store(max_blocks == 0 || max_blocks > 0x7fffffffLL ? 0x7fffffffLL : max_blocks);
+  return SMM_OK;
+}
+
+int smm_set_host_threads(int n, int* previous) {
+  if (n < 0) return fail(SMM_ERR_INVALID, "negative thread count");
+  const int prev = smm::set_host_threads(n);
+  if (previous) *previous = prev;
+  return SMM_OK;
+}
+
 int smm_debug_fail_at_chunk(int64_t chunk) {
   g_fail_at_chunk.store(chunk < 0 ? -1 : chunk, std::memory_order_relaxed);
   return SMM_OK;
@@ -995,9 +1037,23 @@ int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, voi
   a.masked = (flags & SMM_APPLY_MASKED) ? 1 : 0;
   const bool fill = !(flags & SMM_APPLY_NO_FILL);
   hipStream_t s = (hipStream_t)stream;
-  if (x_dtype == SMM_F64)
-    return y_dtype == SMM_F64 ? launch_sb<double, double>(a, fill, flags, s) : launch_sb<double, float>(a, fill, flags, s);
-  return y_dtype == SMM_F64 ? launch_sb<float, double>(a, fill, flags, s) : launch_sb<float, float>(a, fill, flags, s);
+  // grid = destination tiles x batch tiles of 128 entries: beyond the limit the batch is cut into runs of
+  // whole batch tiles, launched one after the other
+  const int64_t n_dtiles = (a.n_dst + (ysz == 8 ? 16 : 32) - 1) / (ysz == 8 ? 16 : 32);
+  const int64_t limit = grid_limit();
+  if (n_dtiles > limit)
+    return fail(SMM_ERR_INVALID, "one batch tile alone needs a launch grid beyond " + std::to_string(limit) + " workgroups");
+  const int64_t part = std::max<int64_t>(1, limit / n_dtiles) * 128;
+  for (int64_t b0 = 0; b0 < n_batch; b0 += part) {
+    a.x = (const char*)x + b0 * (int64_t)xsz;
+    a.y = (char*)y + ((flags & SMM_APPLY_SB_Y_SB) ? b0 : b0 * ldy) * (int64_t)ysz;
+    a.n_batch = std::min(part, n_batch - b0);
+    rc = x_dtype == SMM_F64
+             ? (y_dtype == SMM_F64 ? launch_sb<double, double>(a, fill, flags, s) : launch_sb<double, float>(a, fill, flags, s))
+             : (y_dtype == SMM_F64 ? launch_sb<float, double>(a, fill, flags, s) : launch_sb<float, float>(a, fill, flags, s));
+    if (rc) return rc;
+  }
+  return SMM_OK;
 }
 
 // ---- host-buffer path: chunked, double-buffered H2D -> kernel -> D2H pipeline

@@ -35,6 +35,12 @@ struct HostSell {
   std::vector<double> val;          // n_slots (padding: 0.0)
 };
 
+// Threads of the host-side builders below.  set_host_threads(n): n > 0 fixes the count, 0 = automatic
+// (hardware threads, at most 16, shared between the builders running at that moment, and never more
+// than the work is worth); returns the previous setting.  The results do not depend on the count.
+int set_host_threads(int n);
+int host_threads(int64_t work_items, int64_t min_items_per_thread);
+
 // Returns false and fills err on invalid input.
 bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
                const int32_t* dst1, const double* w, HostCsr& out, std::string& err);
@@ -87,6 +93,29 @@ struct HostTilePlan {
 int64_t tighten_tile_plan(const HostCsr& csr, HostTilePlan& plan, int64_t full_budget);
 void build_tile_plan(const HostCsr& csr, const HostSell& sell, int32_t rows_per_block,
                      int32_t chunk_elems, int64_t max_chunks_per_block, HostTilePlan& plan);
+
+// Launch grids are 1-D and hold at most 2^31 - 1 workgroups.  A batch of (n_outer x n_inner) rows whose
+// grid would be larger is cut into parts -- halves of the outer range first, then of the inner range --
+// until every part fits; `blocks(n_o, n_i)` is the grid a part of that shape needs (it depends on the
+// part: short batches walk fewer rows per workgroup), `emit(o0, n_o, i0, n_i)` launches one part and
+// returns 0 on success.  Returns 0, emit's first non-zero status, or -1 when a single batch row alone
+// exceeds the limit (nothing is launched for that part; earlier parts have been).
+template <typename Blocks, typename Emit>
+int split_batch(int64_t o0, int64_t n_o, int64_t i0, int64_t n_i, int64_t limit, Blocks&& blocks, Emit&& emit) {
+  if (n_o <= 0 || n_i <= 0) return 0;
+  if (blocks(n_o, n_i) <= limit) return emit(o0, n_o, i0, n_i);
+  if (n_o > 1) {
+    const int64_t h = (n_o + 1) / 2;
+    if (int rc = split_batch(o0, h, i0, n_i, limit, blocks, emit)) return rc;
+    return split_batch(o0 + h, n_o - h, i0, n_i, limit, blocks, emit);
+  }
+  if (n_i > 1) {
+    const int64_t h = (n_i + 1) / 2;
+    if (int rc = split_batch(o0, n_o, i0, h, limit, blocks, emit)) return rc;
+    return split_batch(o0, n_o, i0 + h, n_i - h, limit, blocks, emit);
+  }
+  return -1;
+}
 
 // Chunk sizing of the host-buffer pipelines (smm_apply_host / smm_group_apply_host).  A chunk's X
 // AND Y staging are each allocated twice on the device and twice as pinned host memory, so a chunk

@@ -9,8 +9,8 @@ One process per GPU.  This module is sharding arithmetic plus the gather
 schedules over an INJECTED communicator object; it imports neither torch nor
 the HIP library.  The product communicator is `smmregrid_amd.comm.Comm` (RCCL
 over xGMI behind the C ABI: shards are `DeviceArray`s and never leave HBM
-before the collective); tests inject a gloo adapter (`tests/gloo_comm.py`) and
-the CPU oracle as the per-rank compute.
+before the collective); tests inject a gloo adapter (`tools/torch_comm.py`, also behind
+`bench.py --comm torch`) and the CPU oracle as the per-rank compute.
 
 Communicator interface (duck-typed):
 
@@ -64,20 +64,30 @@ def regrid_sharded(x_rows, apply_fn, n_dst, comm, gather="root", root=0, dtype=n
     if hi > lo:
         apply_fn(x_rows[lo:hi], comm.rows(pad, 0, hi - lo))
     if gather == "none":
-        return comm.rows(pad, 0, hi - lo)
+        return comm.rows(pad, 0, hi - lo)      # a view: the caller owns its base (`.base.free()` for a DeviceArray)
     if gather == "all":
         parts = comm.allgather(pad)
     else:
         parts = comm.gather(pad, root)
-        if rank != root:
-            return None
+    _release(pad)                               # device buffers are returned now, not at garbage collection
+    if parts is None:
+        return None
     host = comm.to_host(parts).reshape(world, max(per, 1), n_dst)
+    _release(parts)
     out = np.empty((n_rows, n_dst), dtype=dtype)
     for r in range(world):
         a, b = shard_bounds(n_rows, world, r)
         if b > a:
             out[a:b] = host[r, :b - a]
     return out
+
+
+def _release(arr):
+    """Free a buffer of the communicator's kind if it has an explicit free (DeviceArray); numpy arrays and
+    torch tensors are left to their own memory management."""
+    free = getattr(arr, "free", None)
+    if callable(free):
+        free()
 
 
 def tile_bounds(n_rows, tiles):

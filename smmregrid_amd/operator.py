@@ -6,6 +6,7 @@
 (weights.py:18-23).
 """
 import ctypes
+import time
 
 import numpy as np
 
@@ -49,8 +50,10 @@ class SparseOperator:
             device = current_device()
         self.device = int(device)
         h = ctypes.c_void_p()
+        t0 = time.perf_counter()
         _lib.call("smm_operator_create_opt", int(n_src), int(n_dst), int(src.size), _cptr(src),
                   _cptr(dst), _cptr(w), _lib.CREATE_PRUNE_ZEROS if prune_zeros else 0, self.device, ctypes.byref(h))
+        self.create_ms = (time.perf_counter() - t0) * 1e3     # sort + duplicate sum + layouts + upload
         self.dst_dims = None if dst_dims is None else tuple(int(v) for v in np.asarray(dst_dims).ravel())
         self._adopt(h)
 
@@ -77,6 +80,7 @@ class SparseOperator:
         self.device = int(current_device() if device is None else device)
         h = ctypes.c_void_p()
         self.dst_dims = None if dst_dims is None else tuple(int(v) for v in np.asarray(dst_dims).ravel())
+        t0 = time.perf_counter()
         try:
             _lib.call("smm_operator_create_csr", int(n_src), int(n_dst), _cptr(rowptr), _cptr(col),
                       _cptr(val), self.device, ctypes.byref(h))
@@ -84,6 +88,7 @@ class SparseOperator:
             if e.code == _lib.SMM_ERR_INVALID:
                 raise ValueError(str(e)) from None
             raise
+        self.create_ms = (time.perf_counter() - t0) * 1e3
         self._adopt(h)
         return self
 

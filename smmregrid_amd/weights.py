@@ -41,23 +41,46 @@ def compute_weights_matrix(weights, device=None, prune_zeros=False):
                           dst_dims=_dst_dims(weights), prune_zeros=prune_zeros)
 
 
-def compute_weights_matrix3d(weights, mask_dim="lev", device=None, prune_zeros=False):
-    """Per-level operators; links truncated to link_length[level]   (weights.py:7-23)."""
+def compute_weights_matrix3d(weights, mask_dim="lev", device=None, prune_zeros=False, workers=None):
+    """Per-level operators; links truncated to link_length[level]   (weights.py:7-23).
+    The levels are independent: they are created by up to `workers` host threads at a time (default:
+    min(8, levels); the library shares its builder threads between the creations in flight), in level
+    order in the returned list."""
     weights = from_xarray(weights)
     link_length = np.asarray(weights["link_length"].values).astype(np.int64)
     n_src = weights.sizes["src_grid_size"]
     n_dst = weights.sizes["dst_grid_size"]
     dims = _dst_dims(weights)
-    sparse_weights = []
-    for i, nl in enumerate(link_length):
+    if device is None:
+        from .device import current_device
+        device = current_device()          # resolved here: worker threads start on device 0
+
+    def one(i):
+        nl = int(link_length[i])
         src = _level_slice(weights["src_address"], mask_dim, i)[:nl]
         dst = _level_slice(weights["dst_address"], mask_dim, i)[:nl]
         rm = _level_slice(weights["remap_matrix"], mask_dim, i)[:nl]
         if rm.ndim == 2:
             rm = rm[:, 0]
-        sparse_weights.append(SparseOperator(n_src, n_dst, src, dst, rm, device=device, dst_dims=dims,
-                                             prune_zeros=prune_zeros))
-    return sparse_weights
+        return SparseOperator(n_src, n_dst, src, dst, rm, device=device, dst_dims=dims, prune_zeros=prune_zeros)
+
+    n_lev = len(link_length)
+    workers = min(8, n_lev) if workers is None else max(1, min(int(workers), n_lev))
+    if workers <= 1:
+        return [one(i) for i in range(n_lev)]
+    from concurrent.futures import ThreadPoolExecutor
+    done = []
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            futures = [pool.submit(one, i) for i in range(n_lev)]
+            for f in futures:
+                done.append(f.result())
+    except BaseException:
+        for f in futures:                   # a failing level: release the operators the others made
+            if f.done() and not f.cancelled() and f.exception() is None:
+                f.result().close()
+        raise
+    return done
 
 
 def mask_tensordot(src_mask, weights_matrix):

@@ -1,5 +1,6 @@
 // Host-only harness around smm_build.cpp (COO -> CSR -> SELL-64 -> LDS tile plans), compiled
 // with g++ -fsanitize=address,undefined by tests/test_build_sanitized.py.
+// argv[1]: host threads of the builders (0 / absent = automatic)
 // stdin : n_src n_dst nnz, then nnz lines "src1 dst1 w"
 // stdout: the canonical CSR and invariants of the SELL / tile-plan structures.
 #include <cinttypes>
@@ -10,7 +11,8 @@
 
 #include "../../smmregrid_amd/csrc/smm_internal.h"
 
-int main() {
+int main(int argc, char** argv) {
+  if (argc > 1) smm::set_host_threads(atoi(argv[1]));
   long long n_src, n_dst, nnz;
   if (scanf("%lld %lld %lld", &n_src, &n_dst, &nnz) != 3) return 2;
   std::vector<int32_t> src((size_t)nnz), dst((size_t)nnz);
@@ -182,6 +184,45 @@ int main() {
     }
     if (max_row != pr.max_row_nnz) ++pbad;
     printf("PRUNEBAD %lld %lld\n", pbad, (long long)dropped);
+  }
+  // launch grids beyond the limit: smm::split_batch cuts the (outer x inner) batch into parts that fit, every
+  // batch row in exactly one part; a single row that cannot fit is reported, not launched
+  {
+    long long sbad = 0;
+    struct Case { int64_t n_o, n_i, n_dblocks, n_lev, limit; };
+    const Case cases[] = {{3600, 1, 254, 1, 0x7fffffffLL}, {3600, 1, 254, 1, 5000}, {120, 7, 1013, 75, 100000},
+                          {1, 1000, 64, 3, 999}, {5, 5, 10, 1, 10}, {1, 1, 10, 1, 10}, {17, 3, 49152, 1, 49152}};
+    for (const Case& c : cases) {
+      // the tile kernel's rule (smm_launch.hpp): walks of 64 rows, halved while the grid stays below 4096
+      auto blocks = [&](int64_t n_o, int64_t n_i) {
+        const int64_t n_j = n_o * n_i;
+        int64_t walk = 64;
+        while (walk > 1 && c.n_dblocks * ((n_j + walk - 1) / walk) * c.n_lev < 4096) walk /= 2;
+        walk = std::min(walk, n_j);
+        return c.n_dblocks * ((n_j + walk - 1) / walk) * c.n_lev;
+      };
+      std::vector<int> seen((size_t)(c.n_o * c.n_i), 0);
+      int64_t parts = 0;
+      auto emit = [&](int64_t o0, int64_t n_o, int64_t i0, int64_t n_i) {
+        if (blocks(n_o, n_i) > c.limit) ++sbad;
+        for (int64_t o = o0; o < o0 + n_o; ++o)
+          for (int64_t i = i0; i < i0 + n_i; ++i) ++seen[(size_t)(o * c.n_i + i)];
+        ++parts;
+        return 0;
+      };
+      const int rc = smm::split_batch(0, c.n_o, 0, c.n_i, c.limit, blocks, emit);
+      const bool one_row_fits = blocks(1, 1) <= c.limit;
+      if (rc != (one_row_fits ? 0 : -1)) ++sbad;
+      if (one_row_fits)
+        for (int v : seen) sbad += v != 1;
+      if (c.limit == 0x7fffffffLL && parts != 1) ++sbad;
+    }
+    // an error of one part stops the walk and is passed on
+    int calls = 0;
+    if (smm::split_batch(0, 8, 0, 1, 1, [](int64_t a, int64_t b) { return a * b; },
+                         [&](int64_t, int64_t, int64_t, int64_t) { return ++calls == 3 ? 7 : 0; }) != 7 || calls != 3)
+      ++sbad;
+    printf("SPLITBAD %lld\n", sbad);
   }
   printf("SELLBAD %lld\n", bad);
   return 0;

@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.smm_abi_version() == 3
+    assert lib.smm_abi_version() == 4
     assert isinstance(lib.smm_last_error(), (bytes, type(None)))
 
 

@@ -48,6 +48,70 @@ def test_gather_phase_on_two_gloo_ranks():
     assert g["ms_per_step"] > 0
 
 
+def test_n_rank_line_carries_baseline_configs_4_and_5():
+    """At N > 1 every rank also runs its share of BASELINE configs 4 and 5 (dry run: stand-in steps), compute
+    only and with the tiled gather; rank 0 reports cells/s, the spread of the per-rank kernel times, the ranks
+    the communicator saw and the gathered bytes.  The last line is the compact one; the bulky details come
+    first on a line that does not start with '{'."""
+    out = run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--comm", "torch",
+               "--config-steps", "3"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json_line(out)
+    assert len(json.dumps(line)) < 4096 and out.stdout.rstrip().splitlines()[-1].startswith("{")
+    assert max(len(v) for v in _strings(line)) <= 100
+    for name in ("cfg4", "cfg5"):
+        blk = line["baseline_configs"][name]
+        assert blk["n_gpus"] == 2 and blk["value"] > 0 and blk["rows_per_gpu"] == 64
+        assert 0 < blk["kernel_ms_min"] <= blk["kernel_ms_max"]
+        g = blk["with_gather"]
+        assert g["ranks"] == 2 and g["gathered_bytes_per_step"] == 64 * 96 * 8 and g["ms_per_step"] > 0
+    r = line["roofline"]
+    assert 0 < r["kernel_ms_min_rank"] <= r["kernel_ms_max_rank"]
+    details = [ln for ln in out.stdout.splitlines() if ln.startswith("details: ")]
+    assert len(details) == 1 and "baseline_configs" in json.loads(details[0][len("details: "):])
+
+
+def _strings(obj):
+    if isinstance(obj, str):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _strings(v)
+    elif isinstance(obj, list):
+        for v in obj:
+            yield from _strings(v)
+
+
+def test_a_hanging_gather_ends_non_zero_with_the_line_still_printed():
+    """The gather watchdog: a rank that never reaches the collective costs the gather figures and the exit
+    status (a hung RCCL must not look like a clean run), never the compute value."""
+    out = run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--comm", "torch",
+               "--gather-timeout", "4"], env={"SMM_BENCH_TEST_HANG_GATHER": "1"}, timeout=120)
+    assert out.returncode != 0
+    line = json_line(out)
+    assert line["value"] > 0 and "error" in line["with_gather"]
+
+
+def test_secondary_entries_keep_their_units():
+    """the roofline block of a secondary workload is nested, it no longer overwrites the
+    entry's cells/s unit with GB/s; the layout summary of the final line is built from it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    entry = {"value": 1.4e11, "unit": "cells/s", "create_ms": 12.34,
+             "roofline": {"kernel_ms": 1.7, "frac": 0.68, "traffic": 9.35e9, "algorithmic_bytes": 9.33e9, "unit": "GB/s"},
+             "spot_check": {"bit_equal_to_oracle": True}}
+    assert entry["unit"] == "cells/s"
+    lay = bench.layout_summary(entry)
+    assert lay == {"ms": 1.7, "frac": 0.68, "traffic": 9.35e9, "traffic_ratio": 1.002, "spot_check": True, "create_ms": 12.3}
+    out = {"roofline": {"kernel_ms": 2.75, "frac": 0.42, "traffic": 17.05e9, "algorithmic_bytes": 9.33e9},
+           "spot_check": {"bit_equal_to_oracle": True}, "config": {"workload": "x" * 300, "plan": {"a": 1}}}
+    line = bench.final_line(out, {"others": {"cfg2sb": entry, "cfg3": {"error": "boom"}}})
+    r = line["roofline"]
+    assert r["layouts"]["batch_fastest"]["frac"] == 0.68 and r["batch_fastest_frac"] == 0.68
+    assert r["layouts"]["native"]["traffic_ratio"] == 1.827 and r["configs"]["cfg3"] == {"error": "boom"}
+    assert len(line["config"]["workload"]) <= 100 and "plan" not in line["config"]
+
+
 def test_world_size_must_match_gpus():
     out = run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0"})
     assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr

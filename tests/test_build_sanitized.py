@@ -17,22 +17,27 @@ EXE = os.path.join(ROOT, "tests", "cpp", "build_harness_asan")
 def harness():
     src = [os.path.join(ROOT, "tests", "cpp", "build_harness.cpp"),
            os.path.join(ROOT, "smmregrid_amd", "csrc", "smm_build.cpp")]
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=address,undefined",
                            "-fno-sanitize-recover=all", "-o", EXE] + src)
     yield EXE
     os.remove(EXE)
 
 
-def run(exe, n_src, n_dst, src, dst, w):
+def run(exe, n_src, n_dst, src, dst, w, threads=1):
     text = f"{n_src} {n_dst} {len(src)}\n" + "".join(f"{int(s)} {int(d)} {float(v)!r}\n" for s, d, v in zip(src, dst, w))
-    out = subprocess.run([exe], input=text, capture_output=True, text=True, timeout=120,
+    out = subprocess.run([exe, str(threads)], input=text, capture_output=True, text=True, timeout=120,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stderr[-3000:]
     return out.stdout.splitlines()
 
 
-@pytest.mark.parametrize("case", ["random", "ragged", "dups", "empty", "one_long_row", "tail_cols", "few_wide_blocks"])
-def test_builder_under_sanitizers(harness, rng, case):
+@pytest.mark.parametrize("threads", [1, 3])
+@pytest.mark.parametrize("case", ["random", "ragged", "dups", "cdo_order", "empty", "one_long_row", "tail_cols",
+                                  "few_wide_blocks"])
+def test_builder_under_sanitizers(harness, rng, case, threads):
+    """`threads` = host threads of the builders (smm_set_host_threads): the threaded sort / duplicate sum, SELL
+    fill and tile-plan construction give the same bits as one thread; "cdo_order" = links already ordered by
+    (dst, src) with their duplicates adjacent (what `cdo gen*` writes: the builder's sort-free path)."""
     if case == "random":
         n_src, n_dst = 5000, 1300
         src, dst, w = random_links(rng, n_src, n_dst, 9000)
@@ -42,6 +47,11 @@ def test_builder_under_sanitizers(harness, rng, case):
     elif case == "dups":
         n_src, n_dst = 40, 130
         src, dst, w = random_links(rng, n_src, n_dst, 4000, dup_frac=0.5)
+    elif case == "cdo_order":
+        n_src, n_dst = 700, 400
+        src, dst, w = random_links(rng, n_src, n_dst, 6000, dup_frac=0.3)
+        order = np.lexsort((src, dst))
+        src, dst, w = src[order], dst[order], w[order]
     elif case == "empty":
         n_src, n_dst = 10, 5
         src, dst, w = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0)
@@ -63,7 +73,7 @@ def test_builder_under_sanitizers(harness, rng, case):
         src = np.concatenate([np.full(64, 1006), np.full(64, 1005), np.arange(1, 65)]).astype(np.int32)
         dst = np.tile(np.arange(1, 65), 3).astype(np.int32)
         w = rng.random(src.size)
-    lines = run(harness, n_src, n_dst, src, dst, w)
+    lines = run(harness, n_src, n_dst, src, dst, w, threads)
     assert lines[0].startswith("CSR")
     nnz, n_used, max_row, n_slots = (int(v) for v in lines[0].split()[1:])
     rowptr, col, val = oracle.coo_to_csr(n_src, n_dst, src, dst, w)
@@ -83,6 +93,7 @@ def test_builder_under_sanitizers(harness, rng, case):
         t4 = [t for t in tight if t[1] == "4"][0]
         assert int(t4[2]) == 64 and int(t4[3]) <= 34 and 1000 <= int(t4[4]) <= 1024   # budget 512 -> 64, one block direct
     assert "ADOPTBAD 0" in lines            # smm_operator_create_csr's validator (adopt_csr)
+    assert "SPLITBAD 0" in lines            # launch grids beyond the limit are cut into parts (smm::split_batch)
     assert "CHUNKBAD 0" in lines            # host pipelines size their chunks from X AND Y bytes (U << D)
     prune = [ln.split() for ln in lines if ln.startswith("PRUNEBAD")][0]
     assert prune[1] == "0" and int(prune[2]) == int((val == 0.0).sum())     # exact-zero links dropped, rest intact

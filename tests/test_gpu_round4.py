@@ -1,0 +1,179 @@
+"""Round 4: launch grids beyond the limit are split (smm_debug_set_grid_limit forces the path on small
+inputs), operator creation is threaded (smm_set_host_threads: same operator whatever the count), and the
+LDS-DMA staging falls back to register staging for fields that are not 16-B aligned."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from smmregrid_amd import OperatorGroup, SparseOperator, _lib, gridgen, to_device
+from smmregrid_amd.device import DeviceArray
+from smmregrid_amd.weights import compute_weights_matrix3d
+from tests.helpers import assert_same, field, ragged_links, random_links
+
+pytestmark = pytest.mark.gpu
+T, S_ = _lib.APPLY_KERNEL_TILE, _lib.APPLY_KERNEL_SELL
+
+
+@pytest.fixture
+def grid_limit():
+    """Lowers the launch-grid limit for one test (explicit debug setter, no environment variable)."""
+    def setter(n):
+        _lib.call("smm_debug_set_grid_limit", int(n))
+    yield setter
+    _lib.call("smm_debug_set_grid_limit", 0)
+
+
+def _operator(w, device=0):
+    op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                        w["dst_address"].values, w["remap_matrix"].values, device=device)
+    return op
+
+
+@pytest.mark.parametrize("method,src,dst", [("bil", "r360x180", "r90x45"), ("con", "r360x180", "r120x60")])
+def test_grids_beyond_the_limit_are_launched_in_parts(hip, rng, grid_limit, method, src, dst):
+    """smm_apply (tile and SELL kernels) and smm_apply_sb with the limit forced far below the grid the batch
+    needs: the parts together give the bits of the single launch and of the oracle; a limit no single batch
+    row fits is an error, not a partial result."""
+    w = gridgen.generate_weights(src, dst, method=method)
+    op = _operator(w)
+    imask = (rng.random(op.n_dst) > 0.1).astype(np.int32)
+    op.set_epilogue(imask, w["dst_grid_frac"].values)
+    x = field(rng, 37, op.n_src, nan_frac=0.02)
+    ref = oracle.apply_c(op.export_csr(), x, True, imask, w["dst_grid_frac"].values, 0.5)
+    xd = to_device(x)
+    xsb = to_device(np.ascontiguousarray(x.T))
+    whole = {fl: op.apply(xd, masked=True, remap_area_min=0.5, flags=fl).to_host() for fl in (T, S_)}
+    for fl in (T, S_):
+        info = op.launch_info(37, np.float64, flags=fl)
+        assert_same(whole[fl], ref, exact=True)
+        for limit in (info["n_blocks"] - 1, max(info["n_blocks"] // 7, 64), 64):
+            grid_limit(limit)
+            y = op.apply(xd, masked=True, remap_area_min=0.5, flags=fl).to_host()
+            assert_same(y, ref, exact=True)
+        grid_limit(1)
+        with pytest.raises(_lib.SmmError):
+            op.apply(xd, masked=True, remap_area_min=0.5, flags=fl)
+        grid_limit(0)
+    n_dtiles = -(-op.n_dst // 16)
+    for keep in (False, True):
+        for limit in (n_dtiles, 3 * n_dtiles + 5):     # one batch tile of 128 entries per launch / three
+            grid_limit(limit)
+            xl = DeviceArray((op.n_src, 300), np.float64)
+            big = field(rng, 300, op.n_src, nan_frac=0.01)
+            xl.copy_from_host(np.ascontiguousarray(big.T))
+            y = op.apply_sb(xl, masked=True, remap_area_min=0.5, keep_batch_fastest=keep).to_host()
+            r2 = oracle.apply_c(op.export_csr(), big, True, imask, w["dst_grid_frac"].values, 0.5)
+            assert_same(y.T if keep else y, r2, exact=True)
+        grid_limit(n_dtiles - 1)
+        with pytest.raises(_lib.SmmError):
+            op.apply_sb(xsb, masked=True, remap_area_min=0.5, keep_batch_fastest=keep)
+        grid_limit(0)
+
+
+def test_group_launch_is_split_over_outer_and_inner_ranges(hip, rng, grid_limit):
+    """smm_group_apply over (outer, level, inner) batches: the split walks halves of the outer range, then
+    of the inner range (strides carry the offsets), both output orders."""
+    nx, ny, n_lev = 96, 48, 5
+    masks = gridgen.synthetic_ocean_masks(nx, ny, n_lev)
+    w3 = gridgen.ConservativeLevels(gridgen.regular_grid(nx, ny), "r24x12").stack(masks, np.arange(n_lev, dtype=float))
+    ops = compute_weights_matrix3d(w3, "lev", device=0)
+    dmask = np.stack([op.mask_apply(masks[i]) for i, op in enumerate(ops)])
+    for i, op in enumerate(ops):
+        op.set_epilogue(dmask[i], w3["dst_grid_frac"].values[i])
+    group = OperatorGroup(ops)
+    n_outer, n_inner, S, D = 6, 5, nx * ny, 24 * 12
+    x = 10.0 + rng.standard_normal((n_outer, n_lev, n_inner, S))
+    x[rng.random(x.shape) < 0.01] = np.nan
+    lev = np.arange(n_lev, dtype=np.int32)
+    ml = (~(dmask == 1).all(axis=1)).astype(np.uint8)
+    xd = to_device(x)
+    csrs = [op.export_csr() for op in ops]
+    for transpose in (True, False):
+        ref = oracle.apply_levels(csrs, x, 1, lev, ml, dmask, w3["dst_grid_frac"].values, 0.5, transpose)
+        whole = group.apply(xd, lev, ml, masked=True, remap_area_min=0.5, transpose=transpose).to_host()
+        assert_same(whole, ref, exact=True)
+        n_blocks = group.launch_info(n_outer, n_lev, n_inner)["n_blocks"]
+        for limit in (n_blocks - 1, n_blocks // 3, max(n_blocks // 11, 16)):
+            grid_limit(limit)
+            y = group.apply(xd, lev, ml, masked=True, remap_area_min=0.5, transpose=transpose).to_host()
+            assert_same(y, ref, exact=True)
+            grid_limit(0)
+    group.close()
+    for op in ops:
+        op.close()
+
+
+@pytest.mark.parametrize("kind", ["random", "ragged", "cdo_order"])
+def test_operator_does_not_depend_on_the_builder_threads(hip, rng, kind):
+    """smm_set_host_threads(1) and (5): identical CSR, identical kernel plan, identical results -- for link
+    lists in random order and in CDO's (dst, src) order (the builder's sort-free path)."""
+    n_src, n_dst = 9000, 2100
+    if kind == "ragged":
+        src, dst, w = ragged_links(rng, n_src, n_dst, max_len=45)
+    else:
+        src, dst, w = random_links(rng, n_src, n_dst, 30000, dup_frac=0.2)
+        if kind == "cdo_order":
+            o = np.lexsort((src, dst))
+            src, dst, w = src[o], dst[o], w[o]
+    x = to_device(field(rng, 9, n_src, nan_frac=0.01))
+    prev = ctypes.c_int(-1)
+    got = []
+    try:
+        for nt in (1, 5):
+            _lib.call("smm_set_host_threads", nt, ctypes.byref(prev))
+            op = SparseOperator(n_src, n_dst, src, dst, w, device=0)
+            got.append((op.export_csr(), op.plan_info(), op.apply(x).to_host(), op.apply(x, flags=S_).to_host()))
+            assert op.create_ms > 0
+            op.close()
+    finally:
+        _lib.call("smm_set_host_threads", 0, None)
+    (c1, p1, y1, s1), (c5, p5, y5, s5) = got
+    assert all(np.array_equal(a, b) for a, b in zip(c1, c5)) and p1 == p5
+    assert_same(y5, y1, exact=True)
+    assert_same(s5, s1, exact=True)
+    rowptr, col, val = oracle.coo_to_csr_c(n_src, n_dst, src, dst, w)
+    assert np.array_equal(c5[0], rowptr) and np.array_equal(c5[1], col)
+    assert np.array_equal(c5[2].view(np.uint64), val.view(np.uint64))
+
+
+def test_levels_created_by_worker_threads_match_serial_creation(hip, rng):
+    """compute_weights_matrix3d creates the levels on a pool of host threads: same operators, in level order."""
+    nx, ny, n_lev = 120, 60, 9
+    masks = gridgen.synthetic_ocean_masks(nx, ny, n_lev)
+    w3 = gridgen.ConservativeLevels(gridgen.regular_grid(nx, ny), "r36x18").stack(masks, np.arange(n_lev, dtype=float))
+    serial = compute_weights_matrix3d(w3, "lev", device=0, workers=1)
+    pooled = compute_weights_matrix3d(w3, "lev", device=0)
+    for a, b in zip(serial, pooled):
+        assert all(np.array_equal(u, v) for u, v in zip(a.export_csr(), b.export_csr()))
+        assert a.plan_info() == b.plan_info()
+    for op in serial + pooled:
+        op.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dma_request_on_unaligned_fields_falls_back_bit_equal(hip, rng, dtype):
+    """Variant 10 asks for LDS-DMA staging, which moves aligned 16-B pieces.  A field whose base or row pitch
+    is not a multiple of 16 B must take the register-staged kernel (the DMA kernel skips the piece rotation
+    such rows need): launch_info -- which assumes an aligned field -- says tile-dma, the results of the odd
+    base / odd pitch fields equal the oracle bit for bit."""
+    w = gridgen.generate_weights("r360x180", "r90x45", method="bil")
+    op = _operator(w)
+    op.set_epilogue(None, w["dst_grid_frac"].values)
+    assert op.launch_info(12, dtype, flags=T | (10 << 16))["kernel"] == "tile-dma"
+    S = op.n_src
+    n_batch = 12
+    for pitch, offset in ((S + 1, 0), (S, 1), (S + 3, 1), (S + (16 // np.dtype(dtype).itemsize), 0)):
+        buf = DeviceArray((n_batch * pitch + 4,), dtype)
+        host = np.zeros(n_batch * pitch + 4, dtype=dtype)
+        x = field(rng, n_batch, S, dtype=dtype, nan_frac=0.02)
+        view = host[offset:offset + n_batch * pitch].reshape(n_batch, pitch)
+        view[:, :S] = x
+        buf.copy_from_host(host)
+        xv = DeviceArray((n_batch, pitch), dtype, ptr=buf.ptr + offset * np.dtype(dtype).itemsize, base=buf)
+        ref = oracle.apply_c(op.export_csr(), x, False, None, w["dst_grid_frac"].values, 0.5)
+        for fl in (T | (10 << 16), T | (9 << 16), T):
+            y = op.apply(xv, remap_area_min=0.5, flags=fl).to_host()
+            assert_same(y, ref, exact=True)
+        buf.free()

@@ -7,7 +7,7 @@ for rep in 1 2 3; do
   for wl in ${1:-cfg2}; do
     for lib in ${2:-old new}; do
       if [ $lib = new ]; then unset SMM_LIB_PATH; else export SMM_LIB_PATH=$PWD/tools/exp/libsmm_$lib.so; fi
-      python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python tools/short.py $wl $lib >> gpurun_out/ab.log
+      python bench.py --workload $wl --steps 30 --warmup 3 --no-cpu-baseline --others none --configs none 2>/dev/null | python tools/short.py $wl $lib >> gpurun_out/ab.log
     done
   done
 done

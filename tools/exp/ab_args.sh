@@ -8,7 +8,7 @@ for rep in 1 2 3; do
   i=0
   for set in "$@"; do
     i=$((i+1))
-    python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline $set > $out/s${i}_$rep.json 2> $out/s${i}_$rep.err
+    python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline --others none --configs none $set > $out/s${i}_$rep.json 2> $out/s${i}_$rep.err
   done
 done
 i=0

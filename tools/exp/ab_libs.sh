@@ -11,7 +11,7 @@ for rep in 1 2 3; do
   for wl in $wls; do
     for lib in "${libs[@]}"; do
       tag=$(basename $lib .so)
-      SMM_LIB_ALLOW_MISSING=1 SMM_LIB_PATH=$PWD/$lib python bench.py --workload $wl --steps 10 --warmup 3 --others none \
+      SMM_LIB_ALLOW_MISSING=1 SMM_LIB_PATH=$PWD/$lib python bench.py --workload $wl --steps 10 --warmup 3 --others none --configs none \
           --no-cpu-baseline > $out/${wl}_${tag}_$rep.json 2> $out/${wl}_${tag}_$rep.err
     done
   done

@@ -5,7 +5,7 @@ out=gpurun_out/ab_var_$wl
 rm -rf $out; mkdir -p $out
 for rep in 1 2 3; do
   for v in $vars; do
-    python bench.py --workload $wl --variant $v --steps 20 --warmup 5 --no-cpu-baseline "$@" > $out/v${v}_$rep.json 2> $out/v${v}_$rep.err
+    python bench.py --workload $wl --variant $v --steps 20 --warmup 5 --no-cpu-baseline --others none --configs none "$@" > $out/v${v}_$rep.json 2> $out/v${v}_$rep.err
   done
 done
 python - <<PY

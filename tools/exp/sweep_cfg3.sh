@@ -2,7 +2,7 @@
 # cfg3 knob sweep in one box: ablations + walk length + XCD run length + cache policy
 out=gpurun_out/sweep3
 rm -rf $out; mkdir -p $out
-run() { tag=$1; shift; python bench.py --workload cfg3 --steps 8 --warmup 2 --no-cpu-baseline "$@" > $out/$tag.json 2> $out/$tag.err; }
+run() { tag=$1; shift; python bench.py --workload cfg3 --steps 8 --warmup 2 --no-cpu-baseline --others none --configs none "$@" > $out/$tag.json 2> $out/$tag.err; }
 run base
 SMM_LIB_PATH=$PWD/tools/exp/libsmm_skipcompute.so run skipcompute
 SMM_LIB_PATH=$PWD/tools/exp/libsmm_skipstage.so run skipstage
