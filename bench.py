@@ -95,7 +95,7 @@ WORKLOADS = {
     "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "pad"),
     "cfg3c": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
     # config 3 with the field kept batch-fastest per level, X (L, S, T) (smm_group_apply_sb)
-    # (kernel D stages every cell's 16-entry run: cells start on 128-B lines with the pitch T rounded up to 16;
+    # (cells start on 128-B lines with the pitch T rounded up to 16;
     # "cfg3sbc": pitch T itself -- 120 entries = 960 B, every other run straddles a line)
     "cfg3sb": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "sb"),
     "cfg3sbc": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "sbc"),
@@ -396,6 +396,8 @@ class ProblemLevels:
         if self.x is not None:
             self.x.free()
         self.name, self.padded = name, bool(padded)
+        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] in ("sb", "sbc") else "bs"
+        self.y_shape = (self.n_t, 1, self.n_lev, self.n_dst)
         n_lev, slab = self.n_lev, self.slab
         nx, ny, tgrid = self.nx, self.ny, self.tgrid
         ldx = -(-self.n_src // 16) * 16 if self.padded else self.n_src
@@ -765,7 +767,7 @@ def roofline_block(args, prob, k_avg, workload, batch, with_copy_rate=True):
     return out
 
 
-OTHERS_DEFAULT = ["cfg2sb", "cfg2sbk", "cfg3", "cfg3c", "cfg4s", "cfg5tile"]
+OTHERS_DEFAULT = ["cfg2sb", "cfg2sbk", "cfg3", "cfg3c", "cfg3sb", "cfg4s", "cfg5tile"]
 # BASELINE.json configs 4 and 5: every rank regrids its share of the fixed total batch (8760 / 8 = 1095 rows
 # of f32; 137 x 744 / 8 = 12 741 rows of f64)
 BASELINE_CONFIGS = ["cfg4", "cfg5"]

@@ -303,8 +303,11 @@ int smm_group_apply(smm_group_t g,
  * y + l * ys_lev + b * ys_batch + d.  Y as regrid3d lays it out with transpose (B, L, D):
  * ys_lev = D, ys_batch = L * D; without (L, B, D): ys_lev = B * D, ys_batch = D.  With SMM_APPLY_SB_Y_SB
  * the result stays batch-fastest per level, Y (L, D, ys_batch >= B): ys_lev = D * ys_batch.  Same level_index /
- * masked_levels semantics and the same bits as smm_group_apply (one kernel launch per data level, all
- * on `stream`).  smm_group_prepare_sb uploads the members' CSRs ahead of time (else done by the first call).
+ * masked_levels semantics and the same bits as smm_group_apply.  One kernel launch per data level: the
+ * levels are independent, so they are dealt over a pool of streams owned by the group that is forked from
+ * `stream` and joined back to it by events -- for the caller everything is ordered on `stream` as before,
+ * while the ramp-up and tail of the per-level launches overlap (BASELINE config 3 kept batch-fastest:
+ * 14.4 -> 9.9 ms).  smm_group_prepare_sb uploads the members' CSRs ahead of time (else done by the first call).
  */
 int smm_group_prepare_sb(smm_group_t g);
 int smm_group_apply_sb(smm_group_t g,

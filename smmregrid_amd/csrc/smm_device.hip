@@ -215,6 +215,14 @@ struct smm_group {
   std::map<std::string, void*> cfg_cache;
   std::mutex pipe_mu;  // smm_group_apply_host calls on one group take turns
   HostPipe pipe;
+  // smm_group_apply_sb launches one kernel per data level.  The levels are independent, so they are dealt
+  // over a pool of streams forked from and joined to the caller's stream by events: the ramp-up and the
+  // tail of 75 launches overlap instead of adding up (config 3 batch-fastest: 14.4 -> 9.9 ms).
+  static constexpr int kSbStreams = 16;
+  std::mutex sb_mu;     // enqueueing calls on one group take turns (the fork / join events are shared)
+  bool sb_pool_ready = false;
+  hipStream_t sb_stream[kSbStreams] = {};
+  hipEvent_t sb_fork = nullptr, sb_join[kSbStreams] = {};
 };
 
 namespace {
@@ -1297,6 +1305,11 @@ int smm_group_destroy(smm_group_t g) {
   DeviceGuard guard(g->device);
   for (auto& kv : g->cfg_cache) (void)hipFree(kv.second);
   (void)hipFree(g->d_descs);
+  for (int i = 0; i < smm_group::kSbStreams; ++i) {   // queued work finishes before the runtime lets go of them
+    if (g->sb_stream[i]) (void)hipStreamDestroy(g->sb_stream[i]);
+    if (g->sb_join[i]) (void)hipEventDestroy(g->sb_join[i]);
+  }
+  if (g->sb_fork) (void)hipEventDestroy(g->sb_fork);
   for (smm_operator_t op : g->ops) op->group_refs.fetch_sub(1);
   delete g;
   return SMM_OK;
@@ -1456,16 +1469,43 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
     int vrc = check_sb_levels(g, n_lev, level_index, masked_levels, remap_area_min, flags);
     if (vrc) return vrc;
   }
-  for (int64_t l = 0; l < n_lev; ++l) {
+  // One launch per data level (see smm_group: the stream pool).  Tuning variants: 12 = all levels on the
+  // caller's stream (the round-3 form), 9 / 11 = 4 / 16 pool streams instead of 8.
+  const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
+  const int n_pool = (n_lev < 2 || variant == 12) ? 0 : (int)std::min<int64_t>(n_lev, variant == 9 ? 4 : (variant == 11 ? 16 : 8));
+  hipStream_t caller = (hipStream_t)stream;
+  DeviceGuard guard(g->device);
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
+  std::unique_lock<std::mutex> pool_lock(g->sb_mu, std::defer_lock);
+  if (n_pool > 0) {
+    pool_lock.lock();
+    if (!g->sb_pool_ready) {
+      for (int i = 0; i < smm_group::kSbStreams; ++i) {
+        SMM_HIP(hipStreamCreateWithFlags(&g->sb_stream[i], hipStreamNonBlocking));
+        SMM_HIP(hipEventCreateWithFlags(&g->sb_join[i], hipEventDisableTiming));
+      }
+      SMM_HIP(hipEventCreateWithFlags(&g->sb_fork, hipEventDisableTiming));
+      g->sb_pool_ready = true;
+    }
+    SMM_HIP(hipEventRecord(g->sb_fork, caller));                 // fork: the pool starts after the caller's queue
+    for (int i = 0; i < n_pool; ++i) SMM_HIP(hipStreamWaitEvent(g->sb_stream[i], g->sb_fork, 0));
+  }
+  int status = SMM_OK;
+  for (int64_t l = 0; l < n_lev && status == SMM_OK; ++l) {
     const int w = level_index[l];
     unsigned fl = flags & ~(unsigned)SMM_APPLY_MASKED;
     if ((flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w])) fl |= SMM_APPLY_MASKED;   // regrid.py:405
-    int rc = smm_apply_sb(g->ops[(size_t)w], (const char*)x + (size_t)l * xs_lev * xsz, x_dtype, ldx,
+    if (variant == 9 || variant == 11 || variant == 12) fl &= ~(0xFu << SMM_APPLY_VARIANT_SHIFT);       // knobs of this loop only
+    status = smm_apply_sb(g->ops[(size_t)w], (const char*)x + (size_t)l * xs_lev * xsz, x_dtype, ldx,
                           (char*)y + (size_t)l * ys_lev * ysz, y_dtype, ys_batch, n_batch, remap_area_min, fl,
-                          stream);
-    if (rc) return rc;
+                          n_pool > 0 ? g->sb_stream[l % n_pool] : caller);
   }
-  return SMM_OK;
+  // join: whatever was queued on the pool -- also after a failing level -- is waited for by the caller's stream
+  for (int i = 0; i < n_pool; ++i) {
+    SMM_HIP(hipEventRecord(g->sb_join[i], g->sb_stream[i]));
+    SMM_HIP(hipStreamWaitEvent(caller, g->sb_join[i], 0));
+  }
+  return status;
 }
 
 extern "C++" {

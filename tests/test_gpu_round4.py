@@ -177,3 +177,48 @@ def test_dma_request_on_unaligned_fields_falls_back_bit_equal(hip, rng, dtype):
             y = op.apply(xv, remap_area_min=0.5, flags=fl).to_host()
             assert_same(y, ref, exact=True)
         buf.free()
+
+
+def test_group_sb_levels_over_the_stream_pool(hip, rng):
+    """smm_group_apply_sb deals its per-level launches over a pool of streams forked from / joined to the
+    caller's stream.  Same bits with 4 / 8 / 16 pool streams and with all levels on the caller's stream
+    (tuning variants 9 / default / 11 / 12); on a caller stream of its own the call is ordered between the
+    upload queued before it and the download queued after it; repeated calls reuse the pool."""
+    from smmregrid_amd.device import Stream
+    S, D, n_ops, B = 1100, 260, 7, 50
+    ops, csrs = [], []
+    imask = (rng.random((n_ops, D)) > 0.25).astype(np.int32)
+    frac = rng.random((n_ops, D))
+    for i in range(n_ops):
+        src, dst, w = (random_links(rng, S, D, 2500 + 200 * i) if i % 2 else ragged_links(rng, S, D, max_len=30))
+        op = SparseOperator(S, D, src, dst, w, device=0)
+        op.set_epilogue(imask[i], frac[i])
+        ops.append(op)
+        csrs.append(op.export_csr())
+    grp = OperatorGroup(ops)
+    level_index = np.array([0, 1, 2, 3, 4, 5, 6, 3, 1, 0, 6, 5, 2, 4, 0, 1, 2, 3, 4], dtype=np.int32)   # 19 data levels
+    ml = np.array([1, 0, 1, 1, 0, 1, 1], np.uint8)
+    L = level_index.size
+    x = field(rng, B * L, S, nan_frac=0.02).reshape(B, L, 1, S)
+    ref = oracle.apply_levels(csrs, x, 1, level_index, ml.astype(bool), imask, frac, 0.4, True)   # (B, 1, L, D)
+    x_sb = np.ascontiguousarray(np.transpose(x[:, :, 0, :], (1, 2, 0)))                            # (L, S, B)
+    xd = to_device(x_sb)
+    for variant in (0, 9, 11, 12):
+        for _ in range(2):
+            y = grp.apply_sb(xd, level_index, ml, masked=True, remap_area_min=0.4, flags=variant << 16).to_host()
+            assert_same(y.reshape(ref.shape), ref, exact=True)
+    # a caller stream of its own: H2D, apply, D2H all queued on it, one synchronisation at the end
+    st = Stream()
+    xs = DeviceArray(x_sb.shape, np.float64)
+    ys = DeviceArray((B, L, D), np.float64)
+    for rep in range(3):
+        x2 = field(rng, B * L, S, nan_frac=0.02).reshape(B, L, 1, S)
+        ref2 = oracle.apply_levels(csrs, x2, 1, level_index, ml.astype(bool), imask, frac, 0.4, True)
+        xs.copy_from_host(np.ascontiguousarray(np.transpose(x2[:, :, 0, :], (1, 2, 0))), stream=st)
+        grp.apply_sb(xs, level_index, ml, y=ys, masked=True, remap_area_min=0.4, stream=st)
+        got = ys.to_host(stream=st)
+        assert_same(got.reshape(ref2.shape), ref2, exact=True)
+    st.close()
+    grp.close()
+    for op in ops:
+        op.close()
