@@ -38,12 +38,16 @@ def main():
     ap.add_argument("--key", required=True)
     ap.add_argument("--out", required=True)
     ap.add_argument("--traffic", required=True)
+    ap.add_argument("--launches-per-step", type=int, default=1,
+                    help="kernel launches that make up one bench step (cfg3sb: one per data level): the per-launch "
+                         "means are multiplied by it, so `hbm_bytes_per_launch` stays the bytes of one step")
     ap.add_argument("--git-head", default=os.environ.get("SMM_GIT_HEAD"),
                     help="commit the profiled tree was built from (the GPU box has no .git)")
     a = ap.parse_args()
     fetch, nf = mean_counter(a.fetch, a.kernel)["FETCH_SIZE"]
     write, nw = mean_counter(a.write, a.kernel)["WRITE_SIZE"]
-    out = {"key": a.key, "launches_averaged": {"fetch": nf, "write": nw},
+    fetch, write = fetch * a.launches_per_step, write * a.launches_per_step
+    out = {"key": a.key, "launches_averaged": {"fetch": nf, "write": nw}, "launches_per_step": a.launches_per_step,
            "FETCH_SIZE_KiB_raw": fetch, "WRITE_SIZE_KiB_raw": write,
            "fetch_correction": 2 if a.wide_loads else 1,
            "fetch_bytes": fetch * 1024 * (2 if a.wide_loads else 1), "write_bytes": write * 1024}
@@ -52,6 +56,7 @@ def main():
         out["TCC_EA0_RDREQ_sum"] = rd.get("TCC_EA0_RDREQ_sum", (None,))[0]
         out["TCC_EA0_RDREQ_32B_sum"] = rd.get("TCC_EA0_RDREQ_32B_sum", (None,))[0]
         if out["TCC_EA0_RDREQ_sum"]:
+            out["TCC_EA0_RDREQ_sum"] *= a.launches_per_step
             out["rdreq_x128B_bytes"] = out["TCC_EA0_RDREQ_sum"] * 128
     out["hbm_bytes_per_launch"] = out["fetch_bytes"] + out["write_bytes"]
     json.dump(out, open(a.out, "w"), indent=1)
