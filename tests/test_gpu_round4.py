@@ -222,3 +222,25 @@ def test_group_sb_levels_over_the_stream_pool(hip, rng):
     grp.close()
     for op in ops:
         op.close()
+
+
+def test_a_failing_level_fails_the_pooled_creation_cleanly(hip, rng):
+    """One level with an address outside the source grid: compute_weights_matrix3d raises the library's
+    error (lowest bad link index in the message) whatever worker hits it, and the operators the other
+    workers made are released (creating the same levels again afterwards works)."""
+    nx, ny, n_lev = 60, 30, 6
+    masks = gridgen.synthetic_ocean_masks(nx, ny, n_lev)
+    w3 = gridgen.ConservativeLevels(gridgen.regular_grid(nx, ny), "r20x10").stack(masks, np.arange(n_lev, dtype=float))
+    good = w3["src_address"].values.copy()
+    bad = good.copy()
+    bad[3, 5] = nx * ny + 7
+    bad[3, 9] = 0
+    w3["src_address"].data = bad
+    with pytest.raises(_lib.SmmError) as err:
+        compute_weights_matrix3d(w3, "lev", device=0)
+    assert "src_address[5]" in str(err.value)
+    w3["src_address"].data = good
+    ops = compute_weights_matrix3d(w3, "lev", device=0, workers=3)
+    assert len(ops) == n_lev and all(op.nnz > 0 for op in ops)
+    for op in ops:
+        op.close()

@@ -17,7 +17,17 @@ for seed in range(n):
     if kind == "longband":
         n_src, n_dst = int(rng.integers(5000, 200000)), int(rng.integers(1, 900))
     src, dst, w = make_links(rng, kind, n_src, n_dst)
+    if seed % 3 == 1 and src.size:                 # links in CDO's (dst, src) order: the builder's sort-free path
+        o = np.lexsort((src, dst)); src, dst, w = src[o], dst[o], w[o]
+    # round 4: the builder on 1 .. 6 host threads (0 = automatic), the same operator whatever the count
+    _lib.call("smm_set_host_threads", int(rng.integers(0, 7)), None)
     op = SparseOperator(n_src, n_dst, src, dst, w, device=0, prune_zeros=(seed % 5 == 2))
+    _lib.call("smm_set_host_threads", 0, None)
+    if not (seed % 5 == 2):
+        rp, cc, vv = oracle.coo_to_csr_c(n_src, n_dst, src, dst, w)
+        got = op.export_csr()
+        if not (np.array_equal(got[0], rp) and np.array_equal(got[1], cc) and np.array_equal(got[2].view(np.uint64), vv.view(np.uint64))):
+            bad += 1; print("CSR MISMATCH seed", seed, flush=True)
     csr = op.export_csr()
     imask = (rng.random(n_dst) > 0.3).astype(np.int32); frac = rng.random(n_dst)
     op.set_epilogue(imask, frac)
@@ -35,8 +45,14 @@ for seed in range(n):
     dx = to_device(x)
     for fl in ks:
         for rep in range(3):
+            # round 4: every third repetition with a launch-grid limit a few parts below the grid the batch needs
+            if rep == 2:
+                nb = op.launch_info(x.shape[0], dtype, flags=fl)["n_blocks"]
+                per_row = op.launch_info(1, dtype, flags=fl)["n_blocks"]
+                _lib.call("smm_debug_set_grid_limit", int(max(per_row, nb // int(rng.integers(2, 6)))))
             y = op.apply(dx, masked=masked, remap_area_min=amin, flags=fl).to_host()
             same = np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])
+            _lib.call("smm_debug_set_grid_limit", 0)
             if not same:
                 bad += 1; print("MISMATCH seed", seed, "flags", fl, "rep", rep, flush=True)
     # batch-fastest entry point (full and packed X) and the host pipeline (packing when the operator qualifies)
