@@ -235,11 +235,12 @@ def test_a_failing_level_fails_the_pooled_creation_cleanly(hip, rng):
     bad = good.copy()
     bad[3, 5] = nx * ny + 7
     bad[3, 9] = 0
-    w3["src_address"].data = bad
+    dims = w3["src_address"].dims
+    w3["src_address"] = (dims, bad)
     with pytest.raises(_lib.SmmError) as err:
         compute_weights_matrix3d(w3, "lev", device=0)
     assert "src_address[5]" in str(err.value)
-    w3["src_address"].data = good
+    w3["src_address"] = (dims, good)
     ops = compute_weights_matrix3d(w3, "lev", device=0, workers=3)
     assert len(ops) == n_lev and all(op.nnz > 0 for op in ops)
     for op in ops:
