@@ -121,8 +121,10 @@ def parse_args():
     ap.add_argument("--comm", default="native", choices=["native", "torch"],
                     help="N>1 gather plumbing: the library's smm_comm_* over RCCL (no torch in the process) "
                          "or torch.distributed (nccl == RCCL; gloo with --dry-run)")
-    ap.add_argument("--gather-timeout", type=float, default=180.0,
-                    help="seconds the gather phase may take before the line is printed without it")
+    ap.add_argument("--gather-timeout", type=float, default=300.0,
+                    help="seconds everything after the headline's compute loop may take at N > 1 (communicator set-up, "
+                         "the gather loops, the BASELINE configs) before the line is printed as it stands and the run "
+                         "ends with status 3")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, no kernel: a stand-in step exercises launcher, rendezvous, barriers, "
                          "max over ranks and the JSON line (CPU tests of the N>1 path)")
