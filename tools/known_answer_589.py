@@ -72,6 +72,15 @@ def main():
     add("target longitude cells [0, 4] instead of [-2, 2]", frac(slonb, slatb, dst.lon_b + 2, dst.lat_b, m)[0])
     add("source longitude cells [0, 2.5] instead of [-1.25, 1.25]", frac(slonb + 1.25, slatb, dst.lon_b, dst.lat_b, m)[0])
     add("both longitudes as left edges", frac(slonb + 1.25, slatb, dst.lon_b + 2, dst.lat_b, m)[0])
+    add("target r90x45 as 45 latitude CENTRES -90 .. 90 (not CDO's r-grid: tests/data/r360x180.nc is cell-centred)",
+        frac(slonb, slatb, dst.lon_b, mid_bounds(np.linspace(-90, 90, 45), (-90, 90)), m)[0])
+    add("target latitude cells shifted by half a cell north / south",
+        frac(slonb, slatb, dst.lon_b, np.clip(dst.lat_b + 2, -90, 90), m)[0])
+    add("  (south)", frac(slonb, slatb, dst.lon_b, np.clip(dst.lat_b - 2, -90, 90), m)[0])
+    add("missing-value pattern shifted by one source row north / south", frac(slonb, slatb, dst.lon_b, dst.lat_b, np.roll(m, 1, axis=0))[0])
+    add("  (south)", frac(slonb, slatb, dst.lon_b, dst.lat_b, np.roll(m, -1, axis=0))[0])
+    add("missing-value pattern shifted by one source column east / west", frac(slonb, slatb, dst.lon_b, dst.lat_b, np.roll(m, 1, axis=1))[0])
+    add("  (west)", frac(slonb, slatb, dst.lon_b, dst.lat_b, np.roll(m, -1, axis=1))[0])
     add("frac by NUMBER of overlapping source cells, `<`", frac(slonb, slatb, dst.lon_b, dst.lat_b, m, by_count=True)[0])
     add("frac by number of overlapping source cells, `<=`",
         frac(slonb, slatb, dst.lon_b, dst.lat_b, m, by_count=True)[0], le=True)
