@@ -307,7 +307,9 @@ int smm_group_apply(smm_group_t g,
  * levels are independent, so they are dealt over a pool of streams owned by the group that is forked from
  * `stream` and joined back to it by events -- for the caller everything is ordered on `stream` as before,
  * while the ramp-up and tail of the per-level launches overlap (BASELINE config 3 kept batch-fastest:
- * 14.4 -> 9.9 ms).  smm_group_prepare_sb uploads the members' CSRs ahead of time (else done by the first call).
+ * 14.4 -> 9.9 ms).  Captured into a hipGraph the call is a fork / join sub-graph (after one warm-up call, which
+ * creates the pool and uploads the CSR copies).  smm_group_prepare_sb uploads the members' CSRs ahead of time
+ * (else done by the first call).
  */
 int smm_group_prepare_sb(smm_group_t g);
 int smm_group_apply_sb(smm_group_t g,
