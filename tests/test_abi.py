@@ -102,3 +102,21 @@ def test_product_never_touches_the_oracle():
     lib = ctypes.CDLL(_lib.LIB_PATH) if os.path.exists(_lib.LIB_PATH) else None
     if lib is not None:
         assert not hasattr(lib, "oracle_apply")
+
+
+def test_process_wide_setters_need_no_device():
+    """smm_set_host_threads / smm_debug_set_grid_limit are host-side state: they answer without a GPU, hand back
+    the previous setting, and refuse negative values with SMM_ERR_INVALID (ABI v4)."""
+    prev = ctypes.c_int(-1)
+    _lib.call("smm_set_host_threads", 5, ctypes.byref(prev))
+    first = prev.value
+    _lib.call("smm_set_host_threads", first, ctypes.byref(prev))
+    assert prev.value == 5 and first >= 0
+    _lib.call("smm_set_host_threads", first, None)          # the out pointer may be NULL
+    with pytest.raises(_lib.SmmError) as err:
+        _lib.call("smm_set_host_threads", -1, None)
+    assert err.value.code == _lib.SMM_ERR_INVALID
+    _lib.call("smm_debug_set_grid_limit", 12345)
+    _lib.call("smm_debug_set_grid_limit", 0)
+    with pytest.raises(_lib.SmmError):
+        _lib.call("smm_debug_set_grid_limit", -3)
