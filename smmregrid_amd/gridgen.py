@@ -11,8 +11,8 @@ masks, ``dst_grid_frac``, centre coordinates in radians.
 Supported: global regular lon/lat grids ``r<NX>x<NY>`` / ``global_<res>``, regular
 Gaussian grids ``F<N>`` / ``n<N>`` (CDO naming, cdogrid.py:11-22), explicit regular grids, HEALPix targets ``hp<NSIDE>[_nested|_ring]``
 (cdogrid.py:18-19); methods ``bil`` (4-point bilinear), ``nn`` (nearest
-neighbour) and ``con`` (first-order conservative, `fracarea` normalisation,
-regular -> regular).
+neighbour) and ``con`` (first-order conservative, `fracarea` / `destarea` normalisation: exact overlap
+areas regular <-> regular; regular <-> HEALPix through the pixels' equal-area nested sub-pixels).
 """
 import re
 
@@ -44,6 +44,9 @@ class Grid:
         # regular grids are held south-to-north; a file that stores latitudes north-to-south (ERA5
         # and friends) sets this flag and generate_weights renumbers cells to the file's order
         self.lat_descending = False
+        # HEALPix grids made by parse_grid know their resolution and pixel order (conservative weights need them)
+        self.nside = None
+        self.nested = None
 
     @property
     def dims(self):
@@ -189,11 +192,15 @@ def parse_grid(spec):
     if m:
         nside = int(m.group(1))
         lon, lat = healpix_centers(nside, nested=(m.group(2) != "_ring"))
-        return Grid("points", lon, lat, name=spec, cdo_type="healpix")
+        g = Grid("points", lon, lat, name=spec, cdo_type="healpix")
+        g.nside, g.nested = nside, m.group(2) != "_ring"
+        return g
     m = _HPZ_GRID.match(spec)
     if m:
         lon, lat = healpix_centers(2 ** int(m.group(1)), nested=True)
-        return Grid("points", lon, lat, name=spec, cdo_type="healpix")
+        g = Grid("points", lon, lat, name=spec, cdo_type="healpix")
+        g.nside, g.nested = 2 ** int(m.group(1)), True
+        return g
     m = _GAUSS_GRID.match(spec)
     if m:
         return gaussian_grid(int(m.group(1)), name=spec)
@@ -391,6 +398,178 @@ def conservative_weights(src, dst, src_mask=None, norm="fracarea"):
                           dst_area=dst_area, norm=norm)
 
 
+def healpix_ring_index(nside, lon, lat):
+    """RING-order pixel index of the directions (lon, lat) in degrees (the standard ang2pix_ring)."""
+    z = np.sin(np.radians(np.asarray(lat, dtype=np.float64)))
+    za = np.abs(z)
+    tt = (np.asarray(lon, dtype=np.float64) % 360.0) / 90.0          # in [0, 4)
+    nl4 = 4 * nside
+    pix = np.empty(z.shape, dtype=np.int64)
+    eq = za <= 2.0 / 3.0
+    # equatorial belt
+    t1 = nside * (0.5 + tt[eq])
+    t2 = nside * z[eq] * 0.75
+    jp = np.floor(t1 - t2).astype(np.int64)                            # ascending edge line
+    jm = np.floor(t1 + t2).astype(np.int64)                            # descending edge line
+    ir = nside + 1 + jp - jm                                           # ring counted from z = 2/3, 1 .. 2 nside + 1
+    kshift = 1 - (ir & 1)
+    ip = ((jp + jm - nside + kshift + 1) // 2) % nl4
+    pix[eq] = 2 * nside * (nside - 1) + (ir - 1) * nl4 + ip
+    # polar caps
+    cap = ~eq
+    tp = tt[cap] - np.floor(tt[cap])
+    tmp = nside * np.sqrt(3.0 * (1.0 - za[cap]))
+    jp = np.floor(tp * tmp).astype(np.int64)
+    jm = np.floor((1.0 - tp) * tmp).astype(np.int64)
+    ir = jp + jm + 1                                                   # ring counted from the closest pole
+    ip = np.minimum(np.floor(tt[cap] * ir).astype(np.int64), 4 * ir - 1)
+    north = z[cap] > 0
+    pix[cap] = np.where(north, 2 * ir * (ir - 1) + ip, 12 * nside * nside - 2 * ir * (ir + 1) + ip)
+    return pix
+
+
+def _regular_cell_index(grid, lon, lat):
+    """Address (lon fastest) of the regular grid's cell that holds each direction."""
+    nx, ny = grid.lon.size, grid.lat.size
+    span = grid.lon_b[-1] - grid.lon_b[0]
+    u = (np.asarray(lon) - grid.lon_b[0]) % 360.0
+    if abs(span - 360.0) < 1e-9 and np.allclose(np.diff(grid.lon_b), span / nx):
+        i = np.minimum((u / (span / nx)).astype(np.int64), nx - 1)
+    else:
+        i = np.clip(np.searchsorted(grid.lon_b - grid.lon_b[0], u, side="right") - 1, 0, nx - 1)
+    j = np.clip(np.searchsorted(grid.lat_b, np.asarray(lat), side="right") - 1, 0, ny - 1)
+    return j * nx + i
+
+
+def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", samples=None, chunk=1 << 22):
+    """First-order conservative weights when one side is a HEALPix grid and the other a regular lon/lat grid.
+
+    HEALPix pixels have curved edges but a gift: a pixel at resolution nside is exactly the union of the 4^k
+    EQUAL-AREA pixels of its nested subdivision at nside * 2^k.  The overlap area of a HEALPix pixel with a
+    lon/lat cell is therefore (sub-pixels whose centre falls into the cell) / 4^k of the pixel's area, with an
+    error that shrinks with the sub-pixel size along the cell edges only.  `samples` = 4^k sub-pixels per pixel
+    (default: at least 64, and enough that a sub-pixel is at most a quarter of the other grid's cell width).
+    CDO's own gencon approximates HEALPix pixels too (quadrilaterals with great-circle edges).
+
+    Masked source cells (src_mask == 0) take no part; `dst_grid_frac` = unmasked share of the destination cell,
+    weights normalised per `fracarea` (rows with a link sum to 1) or `destarea`, as conservative_weights does."""
+    src, dst = parse_grid(src), parse_grid(dst)
+    hp_is_dst = dst.cdo_type == "healpix" and dst.nside is not None
+    hp, reg = (dst, src) if hp_is_dst else (src, dst)
+    if hp.cdo_type != "healpix" or hp.nside is None or reg.kind != "regular":
+        raise ValueError("sampled conservative weights need one HEALPix grid (hp<N>[_nested|_ring]) and one regular grid")
+    nside, npix = hp.nside, 12 * hp.nside * hp.nside
+    if samples is None:
+        cell = min(float(np.min(np.diff(reg.lon_b))), float(np.min(np.diff(reg.lat_b)[1:-1])) if reg.lat.size > 2 else 180.0)
+        pix_deg = np.degrees(np.sqrt(4.0 * np.pi / npix))
+        k = 3
+        while pix_deg / 2 ** k > cell / 4.0 and k < 8:
+            k += 1
+    else:
+        k = max(0, int(round(np.log(max(int(samples), 1)) / np.log(4.0))))
+    fine = nside << k
+    per = 4 ** k
+    imask = None
+    if src_mask is not None:
+        imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+        if imask.size != src.size:
+            raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+    # pairs (hp pixel, regular cell) with their sub-pixel counts, accumulated over chunks of fine pixels
+    keys, counts = [], []
+    n_reg = reg.size
+    for lo in range(0, 12 * fine * fine, chunk):
+        hi = min(12 * fine * fine, lo + chunk)
+        flon, flat = _healpix_centers_range(fine, lo, hi)
+        parent = np.arange(lo, hi, dtype=np.int64) >> (2 * k)                   # nested index of the coarse pixel
+        cell_idx = _regular_cell_index(reg, flon, flat)
+        key = parent * n_reg + cell_idx
+        uk, uc = np.unique(key, return_counts=True)
+        keys.append(uk)
+        counts.append(uc)
+    key = np.concatenate(keys)
+    cnt = np.concatenate(counts).astype(np.float64)
+    uk, inv = np.unique(key, return_inverse=True)                               # chunks may split a pixel's sub-pixels
+    cnt = np.bincount(inv, weights=cnt)
+    hp_idx, reg_idx = uk // n_reg, uk % n_reg
+    if not hp_is_dst:
+        # a lon/lat target cell too small to catch a sub-pixel centre (the last rows before a pole) takes the
+        # pixel that holds its own centre
+        empty = np.flatnonzero(np.bincount(reg_idx, minlength=n_reg) == 0)
+        if empty.size:
+            clon, clat = reg.centers()
+            nlon, nlat = healpix_centers(nside, nested=True)
+            ring2nest = np.argsort(healpix_ring_index(nside, nlon, nlat))
+            hp_idx = np.concatenate([hp_idx, ring2nest[healpix_ring_index(nside, clon[empty], clat[empty])]])
+            reg_idx = np.concatenate([reg_idx, empty])
+            cnt = np.concatenate([cnt, np.full(empty.size, 1e-6)])               # a token area: one link, weight 1
+    if not hp.nested:                                                           # ring-ordered grid: renumber the pixels
+        plon, plat = healpix_centers(nside, nested=True)
+        hp_idx = healpix_ring_index(nside, plon, plat)[hp_idx]
+    pix_area = 4.0 * np.pi / npix
+    area = cnt / per * pix_area                                                 # overlap area on the unit sphere
+    if hp_is_dst:
+        dst_addr, src_addr = hp_idx, reg_idx
+        dst_area = np.full(npix, pix_area)
+    else:
+        dst_addr, src_addr = reg_idx, hp_idx
+        dst_area = (np.diff(np.sin(reg.lat_b * DEG))[:, None] * (np.diff(reg.lon_b) * DEG)[None, :]).ravel()
+    if imask is not None:
+        keep = imask[src_addr] != 0
+        dst_addr, src_addr, area = dst_addr[keep], src_addr[keep], area[keep]
+    covered = np.bincount(dst_addr, weights=area, minlength=dst.size)
+    if hp_is_dst:
+        frac = covered / dst_area
+    else:
+        # a lon/lat cell's sampled area (all sub-pixels that fell into it) stands for its area: the fraction is
+        # the unmasked share of the samples, free of the sampling error of the cell's own outline
+        total = np.bincount(reg_idx, weights=cnt / per * pix_area, minlength=dst.size)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            frac = np.where(total > 0, covered / total, 0.0)
+    if norm == "fracarea":
+        w = area / covered[dst_addr]
+    elif norm == "destarea":
+        w = area / (dst_area[dst_addr] if hp_is_dst else np.maximum(np.bincount(reg_idx, weights=cnt / per * pix_area,
+                                                                        minlength=dst.size), 1e-300)[dst_addr])
+    else:
+        raise ValueError("norm must be 'fracarea' or 'destarea'")
+    src_addr, dst_addr, w = _sort_links(src_addr + 1, dst_addr + 1, w)
+    return _scrip_dataset(src, dst, src_addr, dst_addr, w, "con", src_imask=imask, dst_frac=np.clip(frac, 0.0, 1.0),
+                          dst_area=dst_area, norm=norm)
+
+
+def _healpix_centers_range(nside, lo, hi):
+    """Centres of the NESTED pixels lo .. hi - 1 at resolution nside (degrees)."""
+    pix = np.arange(lo, hi, dtype=np.int64)
+    npface = nside * nside
+    face = pix // npface
+    p = pix % npface
+
+    def compact(v):
+        v = v & 0x5555555555555555
+        v = (v | (v >> 1)) & 0x3333333333333333
+        v = (v | (v >> 2)) & 0x0F0F0F0F0F0F0F0F
+        v = (v | (v >> 4)) & 0x00FF00FF00FF00FF
+        v = (v | (v >> 8)) & 0x0000FFFF0000FFFF
+        v = (v | (v >> 16)) & 0x00000000FFFFFFFF
+        return v
+
+    ix = compact(p)
+    iy = compact(p >> 1)
+    jrll = np.array([2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4], dtype=np.int64)
+    jpll = np.array([1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7], dtype=np.int64)
+    jr = jrll[face] * nside - ix - iy - 1
+    nr = np.where(jr < nside, jr, np.where(jr > 3 * nside, 4 * nside - jr, nside))
+    z = np.where(jr < nside, 1.0 - nr * nr / (3.0 * nside * nside),
+                 np.where(jr > 3 * nside, -1.0 + nr * nr / (3.0 * nside * nside),
+                          (2 * nside - jr) * 2.0 / (3.0 * nside)))
+    kshift = np.where((jr < nside) | (jr > 3 * nside), 0, (jr - nside) & 1)
+    jp = (jpll[face] * nr + ix - iy + 1 + kshift) // 2
+    jp = np.where(jp > 4 * nr, jp - 4 * nr, jp)
+    jp = np.where(jp < 1, jp + 4 * nr, jp)
+    phi = (jp - (kshift + 1) * 0.5) * (np.pi / 2.0) / nr
+    return np.degrees(phi) % 360.0, np.degrees(np.arcsin(np.clip(z, -1.0, 1.0)))
+
+
 def _flip_rows(values, nx):
     """Reverse the latitude rows of a per-cell vector stored lon-fastest."""
     v = np.asarray(values)
@@ -412,7 +591,10 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     if flip_s and src_mask is not None:
         src_mask = _flip_rows(np.asarray(src_mask).ravel(), src.lon.size)
     if method in ("con", "ycon"):
-        ds = conservative_weights(src, dst, src_mask=src_mask, norm=norm)
+        if "healpix" in (src.cdo_type, dst.cdo_type) and (src.kind == "regular" or dst.kind == "regular"):
+            ds = sampled_conservative_weights(src, dst, src_mask=src_mask, norm=norm)
+        else:
+            ds = conservative_weights(src, dst, src_mask=src_mask, norm=norm)
     elif method == "bil":
         ds = bilinear_weights(src, dst, src_mask=src_mask)
     elif method == "nn":

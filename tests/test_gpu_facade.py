@@ -338,7 +338,7 @@ def test_era5_style_descending_latitudes(hip, rng):
 
 
 @pytest.mark.parametrize("method,target,shape", [("nn", "r360x180", (12, 180, 360)), ("con", "r180x90", (12, 90, 180)),
-                                                 ("bil", "hp16_nested", (12, 3072))])
+                                                 ("bil", "hp16_nested", (12, 3072)), ("con", "hp16_nested", (12, 3072))])
 def test_reference_test_data_2t_era5(hip, method, target, shape):
     """The reference's tests/data/2t-era5.nc (fixture: tests/golden/2t_era5.npz) with the call
     pattern of basic_test.py:42-79: init from the data itself + a CDO target name, Dataset and
@@ -423,6 +423,31 @@ def test_healpix_source_with_setgrid(hip):
     # every output value is one of the 12 source values of its time step
     for t in range(2):
         assert set(np.unique(rfield["tas"].values[t])) <= set(xfield["tas"].values[t].astype(np.float64))
+
+
+def test_healpix_source_conservative_with_setgrid(hip):
+    """basic_test.py:14-29 with method con: the 12 cells of healpix_0.nc (`-setgrid,hp1_nested`) conservatively onto
+    r360x180 -- native weights from the pixels' nested sub-pixels (round 4).  Every target cell averages the base
+    pixels under it: values between the 12 source values of the step, cells inside one base pixel equal to it, and
+    the area integral kept."""
+    from smmregrid_amd.io import open_dataset
+    golden = os.path.join(os.path.dirname(__file__), "golden", "refdata")
+    tfile = os.path.join(golden, "r360x180.nc")
+    wfield = CdoGenerate(os.path.join(golden, "healpix_0.nc"), tfile, cdo_extra="-setgrid,hp1_nested",
+                         cdo_options=["--force"], loglevel="debug").weights(method="con")
+    assert wfield.sizes["src_grid_size"] == 12 and wfield.sizes["dst_grid_size"] == 360 * 180
+    xfield = open_dataset(os.path.join(golden, "healpix_0.nc"))
+    rfield = Regridder(weights=wfield).regrid(xfield)
+    assert rfield["tas"].shape == (2, 180, 360)
+    src = xfield["tas"].values.astype(np.float64)
+    out = rfield["tas"].values
+    area = (np.diff(np.sin(np.radians(np.linspace(-90, 90, 181))))[:, None] * np.full((1, 360), np.radians(1.0)))
+    for t in range(2):
+        assert src[t].min() - 1e-9 <= out[t].min() and out[t].max() <= src[t].max() + 1e-9
+        assert np.isin(out[t], src[t]).mean() > 0.9              # most cells lie inside one base pixel
+        assert abs((out[t] * area).sum() - src[t].sum() * 4 * np.pi / 12) / abs(src[t].sum() * 4 * np.pi / 12) < 2e-3
+    ref = oracle_2d(wfield, src.reshape(2, -1), masked=False)
+    assert_same(out.reshape(2, -1), ref, exact=True)
 
 
 def test_unstructured_source_file_with_cf_coordinates(hip, rng, tmp_path):

@@ -1,0 +1,100 @@
+"""Native first-order conservative weights where one side is HEALPix (gridgen.sampled_conservative_weights):
+overlap areas from the pixels' equal-area nested sub-pixels.  CPU only (pure numpy)."""
+import numpy as np
+import pytest
+
+from smmregrid_amd import gridgen
+from smmregrid_amd.gridgen import DEG
+
+
+def _dense(w):
+    S, D = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
+    m = np.zeros((D, S))
+    np.add.at(m, (w["dst_address"].values - 1, w["src_address"].values - 1), w["remap_matrix"].values[:, 0])
+    return m
+
+
+def _cell_areas(grid):
+    return (np.diff(np.sin(grid.lat_b * DEG))[:, None] * (np.diff(grid.lon_b) * DEG)[None, :]).ravel()
+
+
+def test_ring_index_inverts_the_ring_centres():
+    for nside in (1, 2, 8, 32):
+        lon, lat = gridgen.healpix_centers(nside, nested=False)
+        assert np.array_equal(gridgen.healpix_ring_index(nside, lon, lat), np.arange(12 * nside * nside))
+        nlon, nlat = gridgen.healpix_centers(nside, nested=True)
+        perm = gridgen.healpix_ring_index(nside, nlon, nlat)
+        assert np.array_equal(np.sort(perm), np.arange(12 * nside * nside))
+        assert np.allclose(lon[perm], nlon) and np.allclose(lat[perm], nlat)
+
+
+@pytest.mark.parametrize("src,dst", [("r96x48", "hp8_nested"), ("r180x90", "hp16"), ("F32", "hp8_ring")])
+def test_regular_to_healpix_conserves(src, dst):
+    """Rows sum to 1 (a constant stays a constant), dst_grid_frac is 1 without a mask, and the area integral of a
+    smooth field is kept to the accuracy of the sampled overlap areas."""
+    w = gridgen.generate_weights(src, dst, method="con")
+    g = gridgen.parse_grid(src)
+    m = _dense(w)
+    assert np.allclose(m.sum(axis=1), 1.0, rtol=0, atol=1e-12) and (m >= 0).all()
+    assert np.allclose(w["dst_grid_frac"].values, 1.0, atol=1e-12)
+    lon2, lat2 = g.centers()
+    x = 280.0 + 30.0 * np.cos(lat2 * DEG) * np.sin(2 * lon2 * DEG) + 10.0 * np.sin(lat2 * DEG)
+    y = m @ x
+    pix = 4 * np.pi / y.size
+    assert abs((y * pix).sum() - (x * _cell_areas(g)).sum()) / abs((x * _cell_areas(g)).sum()) < 2e-3
+    assert x.min() - 1e-9 <= y.min() and y.max() <= x.max() + 1e-9          # convex combinations
+    # links are stored sorted by (dst, src), 1-based
+    d, s = w["dst_address"].values, w["src_address"].values
+    assert d.min() >= 1 and s.min() >= 1 and (np.diff(d.astype(np.int64) * (g.size + 1) + s) > 0).all()
+
+
+def test_ring_and_nested_targets_hold_the_same_weights():
+    a = _dense(gridgen.generate_weights("r72x36", "hp4_nested", method="con"))
+    b = _dense(gridgen.generate_weights("r72x36", "hp4_ring", method="con"))
+    nlon, nlat = gridgen.healpix_centers(4, nested=True)
+    perm = gridgen.healpix_ring_index(4, nlon, nlat)          # nested pixel i is ring pixel perm[i]
+    assert np.array_equal(b[perm], a)
+
+
+def test_healpix_to_regular_conserves_and_converges():
+    """HEALPix source: every target cell averages the pixels under it.  The sampled area of a lon/lat cell approaches
+    its true area as the sub-pixels get finer."""
+    errs = []
+    for samples in (16, 256):
+        w = gridgen.sampled_conservative_weights("hp16_nested", "r72x36", samples=samples)
+        m = _dense(w)
+        assert np.allclose(m.sum(axis=1), 1.0, atol=1e-12)
+        # column sums x destination areas = the source pixel's area (conservation), to sampling accuracy
+        dst = gridgen.parse_grid("r72x36")
+        col = (m * _cell_areas(dst)[:, None]).sum(axis=0)
+        errs.append(np.abs(col / (4 * np.pi / col.size) - 1.0).max())
+    assert errs[1] < errs[0] and errs[1] < 0.08
+    lon, lat = gridgen.healpix_centers(16, nested=True)
+    x = 5.0 + np.sin(lat * DEG) + 0.5 * np.cos(lon * DEG) * np.cos(lat * DEG)
+    y = m @ x
+    assert abs((y * _cell_areas(dst)).sum() - (x * 4 * np.pi / x.size).sum()) / (x * 4 * np.pi / x.size).sum() < 2e-3
+
+
+def test_masked_source_cells_give_fractions_and_no_links():
+    """A masked band of the source: destination pixels wholly inside it get no link and frac 0, pixels across its
+    edge a fraction in (0, 1) and rows that still sum to 1 (fracarea) or to the fraction (destarea)."""
+    g = gridgen.parse_grid("r96x48")
+    mask = np.ones((48, 96), np.int32)
+    mask[18:30, 10:50] = 0
+    w = gridgen.generate_weights(g, "hp8_nested", method="con", src_mask=mask.ravel())
+    frac = w["dst_grid_frac"].values
+    rows = np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0], minlength=frac.size)
+    assert (frac == 0).any() and ((frac > 0) & (frac < 1)).any() and (frac <= 1).all()
+    assert np.allclose(rows[frac > 0], 1.0, atol=1e-12) and (rows[frac == 0] == 0).all()
+    assert (mask.ravel()[w["src_address"].values - 1] == 1).all()
+    wd = gridgen.generate_weights(g, "hp8_nested", method="con", src_mask=mask.ravel(), norm="destarea")
+    rows_d = np.bincount(wd["dst_address"].values - 1, weights=wd["remap_matrix"].values[:, 0], minlength=frac.size)
+    assert np.allclose(rows_d, frac, atol=1e-12)
+    # the unmasked share of pixel area: band area / sphere within the sampling error
+    band = (np.sin(g.lat_b[30] * DEG) - np.sin(g.lat_b[18] * DEG)) * (g.lon_b[50] - g.lon_b[10]) * DEG
+    assert abs((1 - frac).sum() * (4 * np.pi / frac.size) - band) / band < 0.02
+
+
+def test_unsupported_pairs_still_say_so():
+    with pytest.raises(ValueError):
+        gridgen.generate_weights("hp8", "hp4", method="con")              # HEALPix on both sides: not built
