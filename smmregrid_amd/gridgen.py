@@ -10,7 +10,7 @@ masks, ``dst_grid_frac``, centre coordinates in radians.
 
 Supported: global regular lon/lat grids ``r<NX>x<NY>`` / ``global_<res>``, regular
 Gaussian grids ``F<N>`` / ``n<N>`` (CDO naming, cdogrid.py:11-22), explicit regular grids, HEALPix targets ``hp<NSIDE>[_nested|_ring]``
-(cdogrid.py:18-19); methods ``bil`` (4-point bilinear), ``nn`` (nearest
+(cdogrid.py:18-19); methods ``bil`` (4-point bilinear from a regular or a HEALPix source), ``nn`` (nearest
 neighbour) and ``con`` (first-order conservative, `fracarea` / `destarea` normalisation: exact overlap
 areas regular <-> regular; regular <-> HEALPix through the pixels' equal-area nested sub-pixels).
 """
@@ -269,8 +269,10 @@ def bilinear_weights(src, dst, src_mask=None):
     corners are all masked gets no link (the apply path then yields NaN for it through
     ``dst_grid_imask``, weights.py:47-52).  CDO's genbil likewise never links a masked source cell."""
     src, dst = parse_grid(src), parse_grid(dst)
+    if src.cdo_type == "healpix" and src.nside is not None:
+        return _healpix_bilinear(src, dst, src_mask)
     if src.kind != "regular":
-        raise ValueError("bilinear generation needs a regular source grid")
+        raise ValueError("bilinear generation needs a regular or HEALPix (hp<N>) source grid")
     nx, ny = src.lon.size, src.lat.size
     lon, lat = dst.centers()
     dlon = 360.0 / nx if nx > 1 else 360.0
@@ -304,6 +306,101 @@ def bilinear_weights(src, dst, src_mask=None):
         wv = wv / tot[:, None]
     return _scrip_dataset(src, dst, (src4[valid] + 1).astype(np.int32), dst4[valid], wv[valid], "bil",
                           src_imask=imask)
+
+
+def _healpix_bilinear(src, dst, src_mask=None):
+    """4-point interpolation from a HEALPix source: the two pixels either side of the point on the ring above and
+    on the ring below it, linear in longitude along each ring and in colatitude between the rings (the standard
+    HEALPix interpolation scheme); beyond the first / last ring the four pixels of that ring share the polar part.
+    Weights are >= 0 and sum to 1.  With `src_mask`, masked pixels are dropped and the rest renormalised."""
+    nside = src.nside
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    lon, lat = dst.centers()
+    n = lon.size
+    theta = np.radians(90.0 - np.asarray(lat, dtype=np.float64))
+    phi = np.radians(np.asarray(lon, dtype=np.float64) % 360.0)
+    z = np.cos(theta)
+    az = np.abs(z)
+    ir_cap = np.floor(nside * np.sqrt(3.0 * (1.0 - az))).astype(np.int64)
+    ir1 = np.where(az <= 2.0 / 3.0, np.floor(nside * (2.0 - 1.5 * z)).astype(np.int64),
+                   np.where(z > 0, ir_cap, 4 * nside - ir_cap - 1))            # ring above the point (0 = none)
+    ir2 = ir1 + 1
+
+    def ring_info(ir):
+        """(first pixel, pixels, colatitude, shifted) of ring ir (1 .. 4 nside - 1), RING order."""
+        ir = np.clip(ir, 1, 4 * nside - 1)
+        north = ir < nside
+        south = ir > 3 * nside
+        irs = 4 * nside - ir
+        nr = np.where(north, 4 * ir, np.where(south, 4 * irs, 4 * nside))
+        sp = np.where(north, 2 * ir * (ir - 1), np.where(south, npix - 2 * irs * (irs + 1), ncap + (ir - nside) * 4 * nside))
+        zz = np.where(north, 1.0 - ir * ir / (3.0 * nside * nside),
+                      np.where(south, -(1.0 - irs * irs / (3.0 * nside * nside)), (2 * nside - ir) * 2.0 / (3.0 * nside)))
+        shifted = np.where(north | south, 1, 1 - ((ir - nside) & 1))
+        return sp, nr, np.arccos(np.clip(zz, -1.0, 1.0)), shifted
+
+    def along(ir):
+        sp, nr, th, sh = ring_info(ir)
+        dphi = 2.0 * np.pi / nr
+        tmp = phi / dphi - 0.5 * sh
+        i1 = np.floor(tmp).astype(np.int64)
+        w1 = tmp - i1
+        i1 = np.where(i1 < 0, i1 + nr, i1)
+        i2 = np.where(i1 + 1 >= nr, 0, i1 + 1)
+        return sp + i1, sp + i2, 1.0 - w1, w1, th
+
+    a1, a2, wa1, wa2, th1 = along(ir1)
+    b1, b2, wb1, wb2, th2 = along(ir2)
+    pix = np.stack([a1, a2, b1, b2], axis=1)
+    wgt = np.stack([wa1, wa2, wb1, wb2], axis=1)
+    north = ir1 == 0
+    south = ir2 == 4 * nside
+    mid = ~(north | south)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        wt = np.where(mid, (theta - th1) / np.where(th2 != th1, th2 - th1, 1.0), 0.0)
+    wgt[mid, 0:2] *= (1.0 - wt[mid])[:, None]
+    wgt[mid, 2:4] *= wt[mid][:, None]
+    if north.any():                        # above the first ring: its four pixels
+        wn = theta[north] / th2[north]
+        fac = (1.0 - wn) * 0.25
+        pix[north, 0] = (pix[north, 2] + 2) & 3
+        pix[north, 1] = (pix[north, 3] + 2) & 3
+        wgt[north, 0] = fac
+        wgt[north, 1] = fac
+        wgt[north, 2] = wgt[north, 2] * wn + fac
+        wgt[north, 3] = wgt[north, 3] * wn + fac
+    if south.any():                        # below the last ring
+        ws = (theta[south] - th1[south]) / (np.pi - th1[south])
+        fac = ws * 0.25
+        wgt[south, 0] = wgt[south, 0] * (1.0 - ws) + fac
+        wgt[south, 1] = wgt[south, 1] * (1.0 - ws) + fac
+        pix[south, 2] = ((pix[south, 0] + 2) & 3) + npix - 4
+        pix[south, 3] = ((pix[south, 1] + 2) & 3) + npix - 4
+        wgt[south, 2] = fac
+        wgt[south, 3] = fac
+    if src.nested:                          # the source field is stored in nested order
+        nlon, nlat = healpix_centers(nside, nested=True)
+        ring2nest = np.argsort(healpix_ring_index(nside, nlon, nlat))
+        pix = ring2nest[pix]
+    order = np.argsort(pix, axis=1, kind="stable")
+    pix = np.take_along_axis(pix, order, axis=1)
+    wgt = np.take_along_axis(wgt, order, axis=1)
+    dst4 = np.repeat(np.arange(1, n + 1, dtype=np.int32)[:, None], 4, axis=1)
+    if src_mask is None:
+        return _scrip_dataset(src, dst, (pix.ravel() + 1).astype(np.int32), dst4.ravel(), wgt.ravel(), "bil")
+    imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+    if imask.size != src.size:
+        raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+    valid = imask[pix] != 0
+    wv = np.where(valid, wgt, 0.0)
+    tot = wv.sum(axis=1)
+    flat = (tot == 0.0) & valid.any(axis=1)
+    wv[flat] = valid[flat] / valid[flat].sum(axis=1, keepdims=True)
+    tot[flat] = 1.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        wv = wv / tot[:, None]
+    return _scrip_dataset(src, dst, (pix[valid] + 1).astype(np.int32), dst4[valid], wv[valid], "bil", src_imask=imask)
 
 
 def nearest_weights(src, dst, src_mask=None):

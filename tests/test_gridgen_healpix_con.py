@@ -98,3 +98,47 @@ def test_masked_source_cells_give_fractions_and_no_links():
 def test_unsupported_pairs_still_say_so():
     with pytest.raises(ValueError):
         gridgen.generate_weights("hp8", "hp4", method="con")              # HEALPix on both sides: not built
+
+
+@pytest.mark.parametrize("spec", ["hp8_nested", "hp8_ring"])
+def test_bilinear_from_a_healpix_source(spec):
+    """basic_test.py:82-93 ('hp32' -> r360x180, bil) and :14-29 (hp1 source, bil): the ring-wise 4-point scheme.
+    Weights are >= 0 and sum to 1, a point on a pixel centre takes that pixel's value, a smooth field is reproduced
+    with an error that falls with the resolution, ring and nested order agree."""
+    src = gridgen.parse_grid(spec)
+    w = gridgen.generate_weights(spec, "r72x36", method="bil")
+    assert w.sizes["src_grid_size"] == 768 and w.sizes["dst_grid_size"] == 72 * 36 and w.sizes["num_links"] == 4 * 72 * 36
+    m = _dense(w)
+    assert np.allclose(m.sum(axis=1), 1.0, atol=1e-13) and m.min() >= 0.0
+    ident = _dense(gridgen.generate_weights(spec, gridgen.Grid("points", src.lon, src.lat, cdo_type="unstructured"), method="bil"))
+    assert np.allclose(ident, np.eye(768), atol=1e-9)
+
+    def f(lo, la):
+        return 3.0 + np.sin(la * DEG) + 0.5 * np.cos(lo * DEG) * np.cos(la * DEG)
+    dl, dla = gridgen.parse_grid("r72x36").centers()
+    err8 = np.abs(m @ f(src.lon, src.lat) - f(dl, dla)).max()
+    fine = gridgen.parse_grid("hp32" + spec[3:])
+    err32 = np.abs(_dense(gridgen.generate_weights(fine, "r72x36", method="bil")) @ f(fine.lon, fine.lat) - f(dl, dla)).max()
+    assert err32 < err8 / 4 and err32 < 3e-3
+    other = gridgen.parse_grid("hp8_ring" if spec.endswith("nested") else "hp8_nested")
+    y_other = _dense(gridgen.generate_weights(other, "r72x36", method="bil")) @ f(other.lon, other.lat)
+    assert np.allclose(m @ f(src.lon, src.lat), y_other, atol=1e-12)
+
+
+def test_bilinear_from_healpix_drops_masked_pixels():
+    src = gridgen.parse_grid("hp8_nested")
+    mask = np.ones(768, np.int32)
+    mask[src.lat > 60.0] = 0
+    w = gridgen.generate_weights(src, "r36x18", method="bil", src_mask=mask)
+    assert (mask[w["src_address"].values - 1] == 1).all()
+    rows = np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0], minlength=36 * 18)
+    assert set(np.round(rows, 12)) <= {0.0, 1.0} and (rows == 0).any() and (rows == 1).any()
+
+
+def test_reference_generation_sizes_from_grid_names():
+    """basic_test.py:82-93: weights between CDO grid names carry the grid sizes (the hp32 source case needs the
+    HEALPix bilinear scheme)."""
+    for s, t, ns, nd in (("r180x90", "r360x180", 180 * 90, 360 * 180), ("F128", "r180x90", 256 * 512, 180 * 90),
+                         ("hp32", "r360x180", 12288, 360 * 180)):
+        w = gridgen.generate_weights(s, t, method="bil")
+        assert w.sizes["src_grid_size"] == ns and w.sizes["dst_grid_size"] == nd
