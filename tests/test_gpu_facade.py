@@ -425,6 +425,25 @@ def test_healpix_source_with_setgrid(hip):
         assert set(np.unique(rfield["tas"].values[t])) <= set(xfield["tas"].values[t].astype(np.float64))
 
 
+def test_healpix_source_bilinear_with_setgrid(hip):
+    """basic_test.py:14-29 with method bil: the ring-wise 4-point scheme from the 12 base pixels; results stay inside
+    the range of the step's source values and equal the oracle bit for bit."""
+    from smmregrid_amd.io import open_dataset
+    golden = os.path.join(os.path.dirname(__file__), "golden", "refdata")
+    tfile = os.path.join(golden, "r360x180.nc")
+    wfield = CdoGenerate(os.path.join(golden, "healpix_0.nc"), tfile, cdo_extra="-setgrid,hp1_nested",
+                         cdo_options=["--force", "-f", "nc"]).weights(method="bil")
+    assert wfield.sizes["src_grid_size"] == 12 and wfield.sizes["num_links"] == 4 * 360 * 180
+    xfield = open_dataset(os.path.join(golden, "healpix_0.nc"))
+    rfield = Regridder(weights=wfield).regrid(xfield)
+    assert rfield["tas"].shape == (2, 180, 360) and rfield["ta"].shape == (2, 90, 180, 360)
+    src = xfield["tas"].values.astype(np.float64)
+    out = rfield["tas"].values
+    for t in range(2):
+        assert src[t].min() - 1e-9 <= out[t].min() and out[t].max() <= src[t].max() + 1e-9
+    assert_same(out.reshape(2, -1), oracle_2d(wfield, src.reshape(2, -1)), exact=True)
+
+
 def test_healpix_source_conservative_with_setgrid(hip):
     """basic_test.py:14-29 with method con: the 12 cells of healpix_0.nc (`-setgrid,hp1_nested`) conservatively onto
     r360x180 -- native weights from the pixels' nested sub-pixels (round 4).  Every target cell averages the base
