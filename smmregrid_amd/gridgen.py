@@ -634,6 +634,59 @@ def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", sampl
                           dst_area=dst_area, norm=norm)
 
 
+def healpix_hierarchy_weights(src, dst, src_mask=None, norm="fracarea"):
+    """First-order conservative weights between two HEALPix grids: exact, because a coarse pixel is the union of
+    the 4^k pixels below it in the nested hierarchy.  Coarsening averages the (unmasked) children, refining copies
+    the parent.  Either grid may be in ring order."""
+    src, dst = parse_grid(src), parse_grid(dst)
+
+    def nest_of(g):       # nested index of every pixel in the grid's own order
+        if g.nested:
+            return np.arange(g.size, dtype=np.int64)
+        nlon, nlat = healpix_centers(g.nside, nested=True)
+        ring_of_nest = healpix_ring_index(g.nside, nlon, nlat)
+        out = np.empty(g.size, dtype=np.int64)
+        out[ring_of_nest] = np.arange(g.size, dtype=np.int64)
+        return out
+
+    def order_of(g):      # the grid's own index of every nested pixel
+        inv = np.empty(g.size, dtype=np.int64)
+        inv[nest_of(g)] = np.arange(g.size, dtype=np.int64)
+        return inv
+
+    ks, kd = int(round(np.log2(src.nside))), int(round(np.log2(dst.nside)))
+    if 2 ** ks != src.nside or 2 ** kd != dst.nside:
+        raise ValueError("HEALPix hierarchy weights need nside to be powers of two")
+    if ks >= kd:          # coarsening (or the same resolution): every source pixel has one parent
+        parent_nest = nest_of(src) >> (2 * (ks - kd))
+        dst_addr = order_of(dst)[parent_nest]
+        src_addr = np.arange(src.size, dtype=np.int64)
+    else:                 # refining: every destination pixel has one parent
+        parent_nest = nest_of(dst) >> (2 * (kd - ks))
+        src_addr = order_of(src)[parent_nest]
+        dst_addr = np.arange(dst.size, dtype=np.int64)
+    area = np.full(src_addr.size, 4.0 * np.pi / max(src.size, dst.size))      # the finer pixel's area per link
+    dst_area = np.full(dst.size, 4.0 * np.pi / dst.size)
+    imask = None
+    if src_mask is not None:
+        imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+        if imask.size != src.size:
+            raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+        keep = imask[src_addr] != 0
+        dst_addr, src_addr, area = dst_addr[keep], src_addr[keep], area[keep]
+    covered = np.bincount(dst_addr, weights=area, minlength=dst.size)
+    frac = covered / dst_area
+    if norm == "fracarea":
+        w = area / covered[dst_addr]
+    elif norm == "destarea":
+        w = area / dst_area[dst_addr]
+    else:
+        raise ValueError("norm must be 'fracarea' or 'destarea'")
+    src_addr, dst_addr, w = _sort_links(src_addr + 1, dst_addr + 1, w)
+    return _scrip_dataset(src, dst, src_addr, dst_addr, w, "con", src_imask=imask, dst_frac=np.clip(frac, 0.0, 1.0),
+                          dst_area=dst_area, norm=norm)
+
+
 def _healpix_centers_range(nside, lo, hi):
     """Centres of the NESTED pixels lo .. hi - 1 at resolution nside (degrees)."""
     pix = np.arange(lo, hi, dtype=np.int64)
@@ -688,7 +741,9 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     if flip_s and src_mask is not None:
         src_mask = _flip_rows(np.asarray(src_mask).ravel(), src.lon.size)
     if method in ("con", "ycon"):
-        if "healpix" in (src.cdo_type, dst.cdo_type) and (src.kind == "regular" or dst.kind == "regular"):
+        if src.cdo_type == "healpix" and dst.cdo_type == "healpix" and src.nside and dst.nside:
+            ds = healpix_hierarchy_weights(src, dst, src_mask=src_mask, norm=norm)
+        elif "healpix" in (src.cdo_type, dst.cdo_type) and (src.kind == "regular" or dst.kind == "regular"):
             ds = sampled_conservative_weights(src, dst, src_mask=src_mask, norm=norm)
         else:
             ds = conservative_weights(src, dst, src_mask=src_mask, norm=norm)

@@ -95,9 +95,30 @@ def test_masked_source_cells_give_fractions_and_no_links():
     assert abs((1 - frac).sum() * (4 * np.pi / frac.size) - band) / band < 0.02
 
 
-def test_unsupported_pairs_still_say_so():
+def test_healpix_to_healpix_uses_the_nested_hierarchy():
+    """Coarsening averages the 4^k children exactly, refining copies the parent; ring order on either side; a masked
+    child lowers dst_grid_frac by 1 / 4^k."""
+    fine = gridgen.parse_grid("hp8_nested")
+    x = 2.0 + np.sin(fine.lat * DEG) * np.cos(fine.lon * DEG)
+    m = _dense(gridgen.generate_weights("hp8_nested", "hp2_nested", method="con"))
+    assert np.allclose(m @ x, x.reshape(48, 16).mean(axis=1), atol=1e-14)
+    up = _dense(gridgen.generate_weights("hp2_nested", "hp8_nested", method="con"))
+    assert np.array_equal(up, np.kron(np.eye(48), np.ones((16, 1))))
+    # ring order on both sides: the same averages, renumbered
+    ring_f, ring_c = gridgen.parse_grid("hp8_ring"), gridgen.parse_grid("hp2_ring")
+    mr = _dense(gridgen.generate_weights(ring_f, ring_c, method="con"))
+    pf = gridgen.healpix_ring_index(8, fine.lon, fine.lat)                 # nested pixel i is ring pixel pf[i]
+    coarse = gridgen.parse_grid("hp2_nested")
+    pc = gridgen.healpix_ring_index(2, coarse.lon, coarse.lat)
+    xr = np.empty_like(x)
+    xr[pf] = x
+    assert np.allclose((mr @ xr)[pc], m @ x, atol=1e-14)
+    mask = np.ones(768, np.int32)
+    mask[:4] = 0                                                           # four children of coarse pixel 0
+    w = gridgen.generate_weights("hp8_nested", "hp2_nested", method="con", src_mask=mask)
+    assert np.isclose(w["dst_grid_frac"].values[0], 12 / 16) and np.allclose(w["dst_grid_frac"].values[1:], 1.0)
     with pytest.raises(ValueError):
-        gridgen.generate_weights("hp8", "hp4", method="con")              # HEALPix on both sides: not built
+        gridgen.generate_weights("r36x18", gridgen.Grid("points", fine.lon, fine.lat, cdo_type="unstructured"), method="con")
 
 
 @pytest.mark.parametrize("spec", ["hp8_nested", "hp8_ring"])
