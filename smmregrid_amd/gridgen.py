@@ -225,7 +225,7 @@ def _scrip_dataset(src, dst, src_addr, dst_addr, w, method, src_imask=None, dst_
         "title": "smmregrid_amd native weights",
         "normalization": norm,
         "map_method": {"bil": "Bilinear remapping", "nn": "Nearest neighbor remapping",
-                       "con": "Conservative remapping"}[method],
+                       "con": "Conservative remapping", "dis": "Distance weighted avg of nearest neighbors"}[method],
         "conventions": "SCRIP",
         "source_grid": src.cdo_type,
         "dest_grid": dst.cdo_type,
@@ -432,6 +432,38 @@ def nearest_weights(src, dst, src_mask=None):
     jb = np.clip(np.searchsorted(src.lat_b, lat, side="right") - 1, 0, ny - 1)
     d = np.arange(lon.size, dtype=np.int64)
     return _scrip_dataset(src, dst, jb * nx + i + 1, d + 1, np.ones(lon.size), "nn")
+
+
+def distance_weights(src, dst, src_mask=None, neighbours=4):
+    """Inverse-distance weighted average of the `neighbours` nearest (unmasked) source cell centres (CDO's
+    gendis: four neighbours, weights 1 / great-circle distance, normalised; a coinciding centre takes it all)."""
+    from scipy.spatial import cKDTree
+    src, dst = parse_grid(src), parse_grid(dst)
+    imask = None
+    if src_mask is not None:
+        imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+        if imask.size != src.size:
+            raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+    slon, slat = src.centers()
+    lon, lat = dst.centers()
+    cells = np.arange(src.size, dtype=np.int64) if imask is None else np.flatnonzero(imask)
+    n = lon.size
+    if cells.size == 0:
+        return _scrip_dataset(src, dst, np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0), "dis", src_imask=imask)
+    k = int(min(neighbours, cells.size))
+    chord, idx = cKDTree(_unit_vectors(slon[cells], slat[cells])).query(_unit_vectors(lon, lat), k=k)
+    chord, idx = chord.reshape(n, k), idx.reshape(n, k)
+    ang = 2.0 * np.arcsin(np.clip(chord / 2.0, 0.0, 1.0))                 # great-circle angle
+    hit = ang <= 1e-14
+    with np.errstate(divide="ignore"):
+        w = np.where(hit.any(axis=1, keepdims=True), hit.astype(np.float64), 1.0 / np.where(hit, 1.0, ang))
+    w = w / w.sum(axis=1, keepdims=True)
+    src_idx = cells[idx]
+    order = np.argsort(src_idx, axis=1, kind="stable")
+    src_idx = np.take_along_axis(src_idx, order, axis=1)
+    w = np.take_along_axis(w, order, axis=1)
+    dst_idx = np.repeat(np.arange(1, n + 1, dtype=np.int64)[:, None], k, axis=1)
+    return _scrip_dataset(src, dst, src_idx.ravel() + 1, dst_idx.ravel(), w.ravel(), "dis", src_imask=imask)
 
 
 def _overlap_1d(sb, db, periodic=None):
@@ -733,7 +765,7 @@ def _flip_address(addr, nx, ny):
 
 def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     """Dispatch on CDO method names (cdogenerate.py:73): con/ycon -> conservative,
-    bil -> bilinear, nn -> nearest.  Grids whose latitude axis runs north-to-south are
+    bil -> bilinear, nn -> nearest, dis -> inverse-distance average of four neighbours.  Grids whose latitude axis runs north-to-south are
     computed south-to-north and renumbered to the file's cell order afterwards."""
     src, dst = parse_grid(src), parse_grid(dst)
     flip_s = src.kind == "regular" and src.lat_descending
@@ -751,9 +783,11 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
         ds = bilinear_weights(src, dst, src_mask=src_mask)
     elif method == "nn":
         ds = nearest_weights(src, dst, src_mask=src_mask)
+    elif method == "dis":
+        ds = distance_weights(src, dst, src_mask=src_mask)
     else:
         raise ValueError(f"method '{method}' is not available without the cdo binary "
-                         "(native generator: con, ycon, bil, nn)")
+                         "(native generator: con, ycon, bil, nn, dis)")
     if not (flip_s or flip_d):
         return ds
     src_addr, dst_addr = ds["src_address"].values, ds["dst_address"].values

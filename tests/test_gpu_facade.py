@@ -385,7 +385,7 @@ def test_netcdf4_files_of_the_reference_through_the_builtin_reader(hip):
     assert outr.shape == (1, 45, 90) and np.isfinite(outr.values).all()
 
 
-@pytest.mark.parametrize("method", ["nn", "con"])
+@pytest.mark.parametrize("method", ["nn", "con", "dis"])
 def test_target_grid_given_as_a_data_file(hip, method):
     """basic_test.py:42-70 with the reference's own files: the target grid is the grid of the fields in
     tests/data/r360x180.nc (a path), the source a DataArray of 2t-era5.nc; Dataset and DataArray in."""

@@ -163,3 +163,33 @@ def test_reference_generation_sizes_from_grid_names():
                          ("hp32", "r360x180", 12288, 360 * 180)):
         w = gridgen.generate_weights(s, t, method="bil")
         assert w.sizes["src_grid_size"] == ns and w.sizes["dst_grid_size"] == nd
+
+
+def test_distance_weighted_average_of_four_neighbours():
+    """`dis` (basic_test.py:61-68 uses it): four nearest source centres, weights 1 / great-circle distance normalised,
+    a coinciding centre takes all; masked cells are not candidates; north-to-south files keep their cell order."""
+    w = gridgen.generate_weights("r96x48", "r36x18", method="dis")
+    assert w.sizes["num_links"] == 4 * 36 * 18 and w.attrs["map_method"].startswith("Distance")
+    m = _dense(w)
+    assert np.allclose(m.sum(axis=1), 1.0, atol=1e-13) and m.min() >= 0 and ((m > 0).sum(axis=1) == 4).all()
+    g = gridgen.parse_grid("r96x48")
+    lon2, lat2 = g.centers()
+    same = _dense(gridgen.generate_weights(g, gridgen.Grid("points", lon2[100:160], lat2[100:160], cdo_type="unstructured"), method="dis"))
+    assert np.array_equal(same, np.eye(96 * 48)[100:160])
+    # the weights of one target point against the definition
+    d = gridgen.parse_grid("r36x18")
+    dl, dla = d.centers()
+    k = 300
+    v = lambda lo, la: np.stack([np.cos(la * DEG) * np.cos(lo * DEG), np.cos(la * DEG) * np.sin(lo * DEG), np.sin(la * DEG)], -1)
+    ang = np.arccos(np.clip(v(lon2, lat2) @ v(dl[k], dla[k]), -1, 1))
+    near = np.argsort(ang)[:4]
+    ref = (1 / ang[near]) / (1 / ang[near]).sum()
+    assert np.allclose(np.sort(m[k][m[k] > 0]), np.sort(ref), rtol=1e-9)
+    mask = np.ones(96 * 48, np.int32)
+    mask[near] = 0
+    wm = gridgen.generate_weights(g, d, method="dis", src_mask=mask)
+    assert (mask[wm["src_address"].values - 1] == 1).all()
+    # a source stored north to south: the same numbers, cells renumbered
+    desc = gridgen.regular_grid_from_centers(g.lon, g.lat[::-1])
+    md = _dense(gridgen.generate_weights(desc, d, method="dis"))
+    assert np.allclose(md.reshape(-1, 48, 96)[:, ::-1].reshape(-1, 96 * 48), m, atol=1e-14)
