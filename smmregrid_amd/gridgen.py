@@ -225,7 +225,8 @@ def _scrip_dataset(src, dst, src_addr, dst_addr, w, method, src_imask=None, dst_
         "title": "smmregrid_amd native weights",
         "normalization": norm,
         "map_method": {"bil": "Bilinear remapping", "nn": "Nearest neighbor remapping",
-                       "con": "Conservative remapping", "dis": "Distance weighted avg of nearest neighbors"}[method],
+                       "con": "Conservative remapping", "dis": "Distance weighted avg of nearest neighbors",
+                       "laf": "Largest area fraction"}[method],
         "conventions": "SCRIP",
         "source_grid": src.cdo_type,
         "dest_grid": dst.cdo_type,
@@ -752,6 +753,14 @@ def _healpix_centers_range(nside, lo, hi):
     return np.degrees(phi) % 360.0, np.degrees(np.arcsin(np.clip(z, -1.0, 1.0)))
 
 
+def _unflipped(grid):
+    """The same grid without the north-to-south flag (weights in its internal south-to-north order)."""
+    if grid.kind != "regular" or not grid.lat_descending:
+        return grid
+    g = Grid("regular", grid.lon, grid.lat, grid.lon_b, grid.lat_b, name=grid.name, cdo_type=grid.cdo_type)
+    return g
+
+
 def _flip_rows(values, nx):
     """Reverse the latitude rows of a per-cell vector stored lon-fastest."""
     v = np.asarray(values)
@@ -785,9 +794,21 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
         ds = nearest_weights(src, dst, src_mask=src_mask)
     elif method == "dis":
         ds = distance_weights(src, dst, src_mask=src_mask)
+    elif method == "laf":
+        # largest area fraction: the (unmasked) source cell with the largest overlap, weight 1 -- read off the
+        # conservative weights of the same pair (ties: the lowest source address, the order links are stored in)
+        con = generate_weights(_unflipped(src), _unflipped(dst), method="con",
+                               src_mask=None if src_mask is None else np.asarray(src_mask).ravel(), norm="fracarea")
+        d_all, s_all, w_all = con["dst_address"].values, con["src_address"].values, con["remap_matrix"].values[:, 0]
+        order = np.lexsort((s_all, -w_all, d_all))                       # per destination: heaviest link first
+        first = np.concatenate(([True], d_all[order][1:] != d_all[order][:-1]))
+        pick = order[first]
+        ds = _scrip_dataset(src, dst, s_all[pick], d_all[pick], np.ones(pick.size), "laf",
+                            src_imask=None if src_mask is None else (np.asarray(src_mask).ravel() != 0).astype(np.int32),
+                            dst_frac=con["dst_grid_frac"].values)
     else:
         raise ValueError(f"method '{method}' is not available without the cdo binary "
-                         "(native generator: con, ycon, bil, nn, dis)")
+                         "(native generator: con, ycon, bil, nn, dis, laf)")
     if not (flip_s or flip_d):
         return ds
     src_addr, dst_addr = ds["src_address"].values, ds["dst_address"].values

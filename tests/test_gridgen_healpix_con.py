@@ -193,3 +193,23 @@ def test_distance_weighted_average_of_four_neighbours():
     desc = gridgen.regular_grid_from_centers(g.lon, g.lat[::-1])
     md = _dense(gridgen.generate_weights(desc, d, method="dis"))
     assert np.allclose(md.reshape(-1, 48, 96)[:, ::-1].reshape(-1, 96 * 48), m, atol=1e-14)
+
+
+def test_largest_area_fraction_takes_the_heaviest_conservative_link():
+    """`laf`: one link of weight 1 per destination cell, to the unmasked source cell with the largest overlap
+    (the heaviest link of the conservative weights of the same pair; the lowest address among equals)."""
+    w = gridgen.generate_weights("r96x48", "r36x18", method="laf")
+    con = _dense(gridgen.generate_weights("r96x48", "r36x18", method="con"))
+    assert w.sizes["num_links"] == 36 * 18 and set(w["remap_matrix"].values[:, 0]) == {1.0}
+    assert np.array_equal(w["src_address"].values - 1, con.argmax(axis=1))
+    g = gridgen.parse_grid("r96x48")
+    a = w["src_address"].values - 1
+    desc = gridgen.regular_grid_from_centers(g.lon, g.lat[::-1])           # the same grid stored north to south
+    b = gridgen.generate_weights(desc, "r36x18", method="laf")["src_address"].values - 1
+    assert np.array_equal((47 - b // 96) * 96 + b % 96, a)
+    mask = np.ones(96 * 48, np.int32)
+    mask[a[:100]] = 0
+    wm = gridgen.generate_weights("r96x48", "r36x18", method="laf", src_mask=mask)
+    assert (mask[wm["src_address"].values - 1] == 1).all() and wm.sizes["num_links"] == 36 * 18
+    hp = gridgen.generate_weights("r96x48", "hp4_nested", method="laf")    # through the sampled overlaps
+    assert hp.sizes["num_links"] == 192 and set(hp["remap_matrix"].values[:, 0]) == {1.0}
