@@ -226,7 +226,7 @@ def _scrip_dataset(src, dst, src_addr, dst_addr, w, method, src_imask=None, dst_
         "normalization": norm,
         "map_method": {"bil": "Bilinear remapping", "nn": "Nearest neighbor remapping",
                        "con": "Conservative remapping", "dis": "Distance weighted avg of nearest neighbors",
-                       "laf": "Largest area fraction"}[method],
+                       "laf": "Largest area fraction", "bic": "Bicubic remapping"}[method],
         "conventions": "SCRIP",
         "source_grid": src.cdo_type,
         "dest_grid": dst.cdo_type,
@@ -247,7 +247,8 @@ def _scrip_dataset(src, dst, src_addr, dst_addr, w, method, src_imask=None, dst_
                            np.ones(dst.size) if dst_frac is None else np.asarray(dst_frac, np.float64))
     ds["src_address"] = (("num_links",), np.asarray(src_addr, np.int32))
     ds["dst_address"] = (("num_links",), np.asarray(dst_addr, np.int32))
-    ds["remap_matrix"] = (("num_links", "num_wgts"), np.asarray(w, np.float64).reshape(n_links, 1))
+    w = np.asarray(w, np.float64)
+    ds["remap_matrix"] = (("num_links", "num_wgts"), w.reshape(n_links, -1) if w.ndim == 2 else w.reshape(n_links, 1))
     return ds
 
 
@@ -307,6 +308,58 @@ def bilinear_weights(src, dst, src_mask=None):
         wv = wv / tot[:, None]
     return _scrip_dataset(src, dst, (src4[valid] + 1).astype(np.int32), dst4[valid], wv[valid], "bil",
                           src_imask=imask)
+
+
+def bicubic_weights(src, dst, src_mask=None):
+    """SCRIP bicubic from a regular lon/lat source: per corner of the enclosing source box four weights -- for the
+    value and for its derivatives along i, along j and the cross derivative (cubic Hermite basis), `num_wgts` = 4 as
+    CDO's genbic writes them.  The reference applies column 0 only (weights.py:33: `remap_matrix[:, 0]`), i.e. the
+    value basis h00(x) h00(y) with h00(t) = 1 - 3 t^2 + 2 t^3; columns 1 - 3 are there for the file's sake.
+    Masked corners (src_mask == 0) drop out and column 0 is renormalised, as for bilinear weights."""
+    src, dst = parse_grid(src), parse_grid(dst)
+    if src.kind != "regular":
+        raise ValueError("bicubic generation needs a regular source grid")
+    nx, ny = src.lon.size, src.lat.size
+    lon, lat = dst.centers()
+    dlon = 360.0 / nx if nx > 1 else 360.0
+    u = ((lon - src.lon[0]) % 360.0) / dlon
+    i0 = np.floor(u).astype(np.int64)
+    fx = u - i0
+    i0 = i0 % nx
+    i1 = (i0 + 1) % nx
+    j1 = np.clip(np.searchsorted(src.lat, lat, side="right"), 1, ny - 1)
+    j0 = j1 - 1
+    fy = np.clip((lat - src.lat[j0]) / (src.lat[j1] - src.lat[j0]), 0.0, 1.0)
+
+    def basis(t):       # value and slope basis of the cubic Hermite interpolant at the near / far end
+        return (1 - 3 * t ** 2 + 2 * t ** 3, 3 * t ** 2 - 2 * t ** 3, t - 2 * t ** 2 + t ** 3, t ** 3 - t ** 2)
+
+    ax0, ax1, bx0, bx1 = basis(fx)
+    ay0, ay1, by0, by1 = basis(fy)
+    src4 = np.stack([j0 * nx + i0, j0 * nx + i1, j1 * nx + i0, j1 * nx + i1], axis=1)
+    vx = np.stack([ax0, ax1, ax0, ax1], axis=1)
+    vy = np.stack([ay0, ay0, ay1, ay1], axis=1)
+    sx = np.stack([bx0, bx1, bx0, bx1], axis=1)
+    sy = np.stack([by0, by0, by1, by1], axis=1)
+    w4 = np.stack([vx * vy, sx * vy, vx * sy, sx * sy], axis=2)           # (n, corner, 4 weights)
+    order = np.argsort(src4, axis=1, kind="stable")
+    src4 = np.take_along_axis(src4, order, axis=1)
+    w4 = np.take_along_axis(w4, order[:, :, None], axis=1)
+    dst4 = np.repeat(np.arange(1, lon.size + 1, dtype=np.int32)[:, None], 4, axis=1)
+    if src_mask is None:
+        return _scrip_dataset(src, dst, (src4.ravel() + 1).astype(np.int32), dst4.ravel(), w4.reshape(-1, 4), "bic")
+    imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+    if imask.size != src.size:
+        raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+    valid = imask[src4] != 0
+    w0 = np.where(valid, w4[:, :, 0], 0.0)
+    tot = w0.sum(axis=1)
+    flat = (tot == 0.0) & valid.any(axis=1)
+    w0[flat] = valid[flat] / valid[flat].sum(axis=1, keepdims=True)
+    tot[flat] = 1.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        w4[:, :, 0] = w0 / tot[:, None]
+    return _scrip_dataset(src, dst, (src4[valid] + 1).astype(np.int32), dst4[valid], w4[valid], "bic", src_imask=imask)
 
 
 def _healpix_bilinear(src, dst, src_mask=None):
@@ -794,6 +847,8 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
         ds = nearest_weights(src, dst, src_mask=src_mask)
     elif method == "dis":
         ds = distance_weights(src, dst, src_mask=src_mask)
+    elif method == "bic":
+        ds = bicubic_weights(src, dst, src_mask=src_mask)
     elif method == "laf":
         # largest area fraction: the (unmasked) source cell with the largest overlap, weight 1 -- read off the
         # conservative weights of the same pair (ties: the lowest source address, the order links are stored in)
@@ -808,7 +863,7 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
                             dst_frac=con["dst_grid_frac"].values)
     else:
         raise ValueError(f"method '{method}' is not available without the cdo binary "
-                         "(native generator: con, ycon, bil, nn, dis, laf)")
+                         "(native generator: con, ycon, bil, bic, nn, dis, laf)")
     if not (flip_s or flip_d):
         return ds
     src_addr, dst_addr = ds["src_address"].values, ds["dst_address"].values

@@ -51,13 +51,19 @@ def test_regrid_dataarray_and_dataset(hip, rng, method):
     assert outds["time_bnds"].shape == (4, 2)                   # time bounds are passed through
 
 
-def test_nan_timestep_preserved(hip, rng):
-    # basic_test.py:31-39
+@pytest.mark.parametrize("method", ["con", "nn", "bic"])
+def test_nan_timestep_preserved(hip, rng, method):
+    # basic_test.py:31-39 (same methods; weights through the deprecated cdo_generate_weights wrapper, as there)
+    from smmregrid_amd import cdo_generate_weights
     field = tas_field(rng, nt=3, dtype=np.float64)
     field.data[1, :, :] = np.nan
-    rg = Regridder(weights=CdoGenerate("r96x48", "r36x18").weights(method="con"), horizontal_dims="pippo")
+    with pytest.warns(DeprecationWarning):
+        wfield = cdo_generate_weights("r96x48", "r36x18", method=method)
+    rg = Regridder(weights=wfield, horizontal_dims="pippo")
     out = rg.regrid(field)
     assert np.isnan(out.values[1]).all() and np.isfinite(out.values[0]).all()
+    if method == "bic":
+        assert wfield.sizes["num_wgts"] == 4       # only column 0 is applied (weights.py:33)
 
 
 def test_init_from_grids_and_healpix_target(hip, rng):

@@ -213,3 +213,35 @@ def test_largest_area_fraction_takes_the_heaviest_conservative_link():
     assert (mask[wm["src_address"].values - 1] == 1).all() and wm.sizes["num_links"] == 36 * 18
     hp = gridgen.generate_weights("r96x48", "hp4_nested", method="laf")    # through the sampled overlaps
     assert hp.sizes["num_links"] == 192 and set(hp["remap_matrix"].values[:, 0]) == {1.0}
+
+
+def test_bicubic_weights_carry_four_columns_and_column_zero_is_the_value_basis():
+    """`bic` (basic_test.py:31-39 uses it): SCRIP's four weights per corner; the reference applies column 0 only, the
+    cubic Hermite value basis -- a partition of unity that reproduces the nodes and, between them, the smoothstep of
+    the bilinear fractions."""
+    w = gridgen.generate_weights("r96x48", "r36x18", method="bic")
+    rm = w["remap_matrix"].values
+    assert rm.shape == (4 * 36 * 18, 4) and w.sizes["num_wgts"] == 4
+    rows = np.bincount(w["dst_address"].values - 1, weights=rm[:, 0], minlength=36 * 18)
+    assert np.allclose(rows, 1.0, atol=1e-13) and rm[:, 0].min() >= 0.0
+    bil = gridgen.generate_weights("r96x48", "r36x18", method="bil")
+    assert np.array_equal(bil["src_address"].values, w["src_address"].values)
+    # per destination the bicubic value weights are the products of the smoothstepped 1-D fractions of the bilinear ones
+    wb = bil["remap_matrix"].values[:, 0].reshape(-1, 4)
+    fx = wb[:, 1] + wb[:, 3]          # links sorted by source address: (j0,i0), (j0,i1), (j1,i0), (j1,i1) unless the row wraps
+    fy = wb[:, 2] + wb[:, 3]
+    sm = lambda t: 3 * t ** 2 - 2 * t ** 3
+    ref = np.stack([(1 - sm(fx)) * (1 - sm(fy)), sm(fx) * (1 - sm(fy)), (1 - sm(fx)) * sm(fy), sm(fx) * sm(fy)], axis=1)
+    inner = (w["src_address"].values.reshape(-1, 4)[:, 1] - w["src_address"].values.reshape(-1, 4)[:, 0]) == 1
+    assert inner.sum() > 500 and np.allclose(rm[:, 0].reshape(-1, 4)[inner], ref[inner], atol=1e-12)
+    g = gridgen.parse_grid("r96x48")
+    lon2, lat2 = g.centers()
+    node = gridgen.generate_weights(g, gridgen.Grid("points", lon2[200:260], lat2[200:260], cdo_type="unstructured"), method="bic")
+    m = _dense(node)
+    assert np.allclose(m, np.eye(96 * 48)[200:260], atol=1e-12)
+    mask = np.ones(96 * 48, np.int32)
+    mask[1000:1200] = 0
+    wm = gridgen.generate_weights("r96x48", "r36x18", method="bic", src_mask=mask)
+    assert (mask[wm["src_address"].values - 1] == 1).all()
+    rows = np.bincount(wm["dst_address"].values - 1, weights=wm["remap_matrix"].values[:, 0], minlength=36 * 18)
+    assert np.allclose(rows[rows > 0], 1.0, atol=1e-13)
