@@ -100,7 +100,7 @@ def test_without_cdo_the_native_generator_says_so(monkeypatch, caplog):
     with pytest.raises(ValueError):
         gen.weights(method="con", remap_norm="bogus")
     with pytest.raises(NotImplementedError, match="needs the cdo binary"):
-        gen.weights(method="bic")
+        gen.weights(method="con2")
     with pytest.raises(NotImplementedError, match="extrapolate=False"):
         gen.weights(method="bil", extrapolate=False)
 
