@@ -24,7 +24,7 @@ from .gridmeta import CdoGrid
 from .gridtype import GridType, tolist
 from .xrlite import DataArray, Dataset, from_xarray, is_xarray
 
-NATIVE_METHODS = ("con", "ycon", "bil", "bic", "nn", "dis", "laf")
+NATIVE_METHODS = ("con", "ycon", "con2", "bil", "bic", "nn", "dis", "laf")
 
 
 class CdoGenerate:

@@ -806,6 +806,64 @@ def _healpix_centers_range(nside, lo, hi):
     return np.degrees(phi) % 360.0, np.degrees(np.arcsin(np.clip(z, -1.0, 1.0)))
 
 
+def conservative2_weights(src, dst, src_mask=None, norm="fracarea"):
+    """SCRIP second-order conservative weights between regular lon/lat grids (Jones 1999, eqs. 4 - 6), `num_wgts` = 3:
+    per overlap A_nk of source cell n with destination cell k
+
+        w1 = |A_nk|,   w2 = int_A (lat - lat_n) dA,   w3 = int_A cos(lat) (lon - lon_n) dA
+
+    with (lat_n, lon_n) the area centroid of the source cell, all three normalised like the first-order weight.
+    A destination value is then sum_n f_n w1 + (df/dlat)_n w2 + (1/cos(lat) df/dlon)_n w3.  The reference applies
+    column 0 only (weights.py:33), which is the first-order weight.  Exact for lon/lat boxes."""
+    src, dst = parse_grid(src), parse_grid(dst)
+    if src.kind != "regular" or dst.kind != "regular":
+        raise ValueError("second-order conservative generation needs regular source and destination grids")
+    first = conservative_weights(src, dst, src_mask=src_mask, norm=norm)
+    s_addr = first["src_address"].values.astype(np.int64) - 1
+    d_addr = first["dst_address"].values.astype(np.int64) - 1
+    nx, mx = src.lon.size, dst.lon.size
+    js, is_ = s_addr // nx, s_addr % nx
+    jd, id_ = d_addr // mx, d_addr % mx
+    sb, db = src.lat_b * DEG, dst.lat_b * DEG
+    t1 = np.maximum(sb[js], db[jd])                       # latitude range of the overlap
+    t2 = np.minimum(sb[js + 1], db[jd + 1])
+    # longitude range of the overlap, measured from the source cell's centre (periodic)
+    sl1, sl2 = src.lon_b[is_], src.lon_b[is_ + 1]
+    mid = 0.5 * (sl1 + sl2)
+    dl1 = ((dst.lon_b[id_] - mid + 180.0) % 360.0) - 180.0
+    dl2 = dl1 + (dst.lon_b[id_ + 1] - dst.lon_b[id_])
+    half = 0.5 * (sl2 - sl1)
+    # a destination cell wider than 360 - source width could meet the source cell twice; the first-order pass
+    # merged those pieces, here the piece around the source centre is the one integrated (global grids of
+    # ordinary resolution have a single piece)
+    p1 = np.maximum(dl1, -half) * DEG
+    p2 = np.minimum(dl2, half) * DEG
+    wrap = p2 <= p1                                        # the overlap lies on the other side of the date line
+    p1 = np.where(wrap, np.maximum(dl1 + 360.0, -half) * DEG, p1)
+    p2 = np.where(wrap, np.minimum(dl2 + 360.0, half) * DEG, p2)
+
+    def i_cos(a, b):          # int cos(t) dt
+        return np.sin(b) - np.sin(a)
+
+    def i_tcos(a, b):         # int t cos(t) dt
+        return (b * np.sin(b) + np.cos(b)) - (a * np.sin(a) + np.cos(a))
+
+    def i_cos2(a, b):         # int cos^2(t) dt
+        return 0.5 * (b - a) + 0.25 * (np.sin(2 * b) - np.sin(2 * a))
+
+    lat_c = i_tcos(sb[:-1], sb[1:]) / i_cos(sb[:-1], sb[1:])             # area centroid latitude of every source row
+    dphi = p2 - p1
+    w1 = i_cos(t1, t2) * dphi
+    w2 = (i_tcos(t1, t2) - lat_c[js] * i_cos(t1, t2)) * dphi
+    w3 = i_cos2(t1, t2) * 0.5 * (p2 * p2 - p1 * p1)                       # lon measured from the source centre
+    scale = first["remap_matrix"].values[:, 0] / np.where(w1 != 0.0, w1, 1.0)   # the first-order normalisation
+    w = np.stack([first["remap_matrix"].values[:, 0], w2 * scale, w3 * scale], axis=1)
+    ds = first
+    ds["remap_matrix"] = (("num_links", "num_wgts"), w)
+    ds.attrs["map_method"] = "Conservative remapping, second order"
+    return ds
+
+
 def _unflipped(grid):
     """The same grid without the north-to-south flag (weights in its internal south-to-north order)."""
     if grid.kind != "regular" or not grid.lat_descending:
@@ -847,6 +905,8 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
         ds = nearest_weights(src, dst, src_mask=src_mask)
     elif method == "dis":
         ds = distance_weights(src, dst, src_mask=src_mask)
+    elif method == "con2":
+        ds = conservative2_weights(src, dst, src_mask=src_mask, norm=norm)
     elif method == "bic":
         ds = bicubic_weights(src, dst, src_mask=src_mask)
     elif method == "laf":
@@ -863,7 +923,7 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
                             dst_frac=con["dst_grid_frac"].values)
     else:
         raise ValueError(f"method '{method}' is not available without the cdo binary "
-                         "(native generator: con, ycon, bil, bic, nn, dis, laf)")
+                         "(native generator: con, ycon, con2, bil, bic, nn, dis, laf)")
     if not (flip_s or flip_d):
         return ds
     src_addr, dst_addr = ds["src_address"].values, ds["dst_address"].values

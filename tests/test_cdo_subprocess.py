@@ -99,8 +99,15 @@ def test_without_cdo_the_native_generator_says_so(monkeypatch, caplog):
         gen.weights(method="bogus")
     with pytest.raises(ValueError):
         gen.weights(method="con", remap_norm="bogus")
-    with pytest.raises(NotImplementedError, match="needs the cdo binary"):
-        gen.weights(method="con2")
+    # every method the reference lists has a native form for lon/lat grids (round 4); a pair the native generator
+    # cannot do still says so instead of guessing
+    from smmregrid_amd.cdogenerate import NATIVE_METHODS
+    assert set(NATIVE_METHODS) == {"bic", "bil", "con", "con2", "dis", "laf", "nn", "ycon"}     # cdogenerate.py:73
+    for method in NATIVE_METHODS:
+        w = gridgen.generate_weights("r32x16", "r16x8", method=method)          # (gen.weights adds the GPU mask pass)
+        assert w.sizes["dst_grid_size"] == 16 * 8 and w.sizes["num_wgts"] == {"bic": 4, "con2": 3}.get(method, 1)
+    with pytest.raises(ValueError, match="regular"):
+        gridgen.generate_weights("r32x16", "hp4", method="con2")
     with pytest.raises(NotImplementedError, match="extrapolate=False"):
         gen.weights(method="bil", extrapolate=False)
 

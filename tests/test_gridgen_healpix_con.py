@@ -245,3 +245,48 @@ def test_bicubic_weights_carry_four_columns_and_column_zero_is_the_value_basis()
     assert (mask[wm["src_address"].values - 1] == 1).all()
     rows = np.bincount(wm["dst_address"].values - 1, weights=wm["remap_matrix"].values[:, 0], minlength=36 * 18)
     assert np.allclose(rows[rows > 0], 1.0, atol=1e-13)
+
+
+def test_second_order_conservative_weights_follow_their_definition():
+    """`con2` (SCRIP, Jones 1999 eqs. 4 - 6), three columns: column 0 is the first-order weight (what the reference
+    applies); with the latitude gradient column a field linear in latitude is remapped exactly; columns 1 and 2 equal
+    a brute-force quadrature of int (lat - lat_n) dA and int cos(lat) (lon - lon_n) dA over the overlap -- also for
+    the source cells that straddle longitude 0."""
+    src, dst = gridgen.parse_grid("r96x48"), gridgen.parse_grid("r36x18")
+    w = gridgen.generate_weights(src, dst, method="con2")
+    first = gridgen.generate_weights(src, dst, method="con")
+    rm = w["remap_matrix"].values
+    assert rm.shape[1] == 3 and np.array_equal(rm[:, 0], first["remap_matrix"].values[:, 0])
+    assert np.array_equal(w["src_address"].values, first["src_address"].values)
+    s, d = w["src_address"].values - 1, w["dst_address"].values - 1
+    sb, db = src.lat_b * DEG, dst.lat_b * DEG
+    cen = lambda b: ((b[1:] * np.sin(b[1:]) + np.cos(b[1:])) - (b[:-1] * np.sin(b[:-1]) + np.cos(b[:-1]))) / (np.sin(b[1:]) - np.sin(b[:-1]))
+    f = 2.0 + 3.0 * np.repeat(cen(sb), 96)                     # cell means of 2 + 3 lat
+    y2 = np.bincount(d, weights=rm[:, 0] * f[s] + rm[:, 1] * 3.0, minlength=648)
+    y1 = np.bincount(d, weights=rm[:, 0] * f[s], minlength=648)
+    exact = 2.0 + 3.0 * np.repeat(cen(db), 36)
+    assert np.abs(y2 - exact).max() < 1e-13 < 1e-3 < np.abs(y1 - exact).max()
+    # brute force of the definition on a sample of links (incl. source column 0, centred on longitude 0)
+    rng = np.random.default_rng(5)
+    pick = np.concatenate([rng.choice(s.size, 40, replace=False), np.flatnonzero(s % 96 == 0)[:10]])
+    covered = np.bincount(d, weights=0 * rm[:, 0] + 1, minlength=648)         # every cell is covered (no mask)
+    assert covered.min() > 0
+    dst_area = np.repeat(np.diff(np.sin(db)), 36) * (10.0 * DEG)
+    for k in pick:
+        js, i_s, jd, i_d = s[k] // 96, s[k] % 96, d[k] // 36, d[k] % 36
+        lat_n, lon_n = cen(sb)[js], src.lon[i_s]
+        t = np.linspace(max(sb[js], db[jd]), min(sb[js + 1], db[jd + 1]), 2001)
+        lo1 = ((dst.lon_b[i_d] - lon_n + 180) % 360) - 180
+        lo2 = lo1 + 10.0
+        a, b = max(lo1, -1.875), min(lo2, 1.875)
+        if b <= a:
+            a, b = max(lo1 + 360, -1.875), min(lo2 + 360, 1.875)
+        p = np.linspace(a, b, 401) * DEG
+        tm, pm = 0.5 * (t[1:] + t[:-1]), 0.5 * (p[1:] + p[:-1])
+        dA = np.outer(np.cos(tm) * np.diff(t), np.diff(p))
+        w1 = dA.sum()
+        w2 = ((tm - lat_n)[:, None] * dA).sum()
+        w3 = (np.cos(tm)[:, None] * pm[None, :] * dA).sum()
+        assert np.isclose(w1 / dst_area[d[k]], rm[k, 0], rtol=1e-6)
+        assert np.isclose(w2 / dst_area[d[k]], rm[k, 1], rtol=1e-4, atol=1e-8)
+        assert np.isclose(w3 / dst_area[d[k]], rm[k, 2], rtol=1e-4, atol=1e-8)
