@@ -25,13 +25,15 @@ reported as `with_gather` beside it (xGMI-link bound; --gather none skips it).  
 gather is the library's own RCCL communicator (--comm native, default: no torch in the process) or
 torch.distributed (--comm torch).  `n_gpus` is the number of ranks that really joined.
 
-Rank 0 prints ONE JSON line: the driver's contract plus `roofline` (HBM bound;
-algorithmic bytes of SURVEY 8d over the live HIP-event kernel time), `cpu_baseline`
-(the CPU oracle -- a port of the reference's step sequence -- timed on this host's cores
-over a bounded sample of the same workload) and, for the default workload at N = 1,
-`others`: the secondary workloads (config 2 with the field kept batch-fastest, BASELINE config 3
-packed and on 128-B lines, config-4 geometry) timed in the same run, each with kernel time,
-algorithmic bytes, roofline fraction, replayed PMC traffic and a bit-equality spot check
+Rank 0 prints TWO stdout lines.  The LAST one is the compact JSON line (< 4 kB, every string < 100 characters):
+the driver's contract plus `roofline` (HBM bound; algorithmic bytes of SURVEY 8d over the live HIP-event kernel time;
+`roofline.layouts` = config 2 in the native and the batch-fastest layout, `roofline.configs` = the secondary
+workloads' fractions and traffic ratios), `cpu_baseline` (the CPU oracle -- a port of the reference's step sequence --
+timed on this host's cores over a bounded sample of the same workload) and `baseline_configs` (one rank's share of
+BASELINE configs 4 and 5 per GPU; at N > 1 with the per-rank kernel times and the gather figures).  The line before it,
+prefixed `details: `, holds the bulky per-workload entries (`others`: config 2 with the field kept batch-fastest,
+BASELINE config 3 packed / on 128-B lines / batch-fastest, config-4 geometry, config-5 geometry), each timed in the
+same run with kernel time, algorithmic bytes, roofline fraction, replayed PMC traffic and a bit-equality spot check
 of its timed output against the CPU oracle.
 """
 import argparse
