@@ -66,16 +66,26 @@ class CdoGenerate:
                        if GridType(v.dims).horizontal_dims)
         if isinstance(obj, DataArray):
             lon = lat = None
+
+            def degrees(coord):
+                """Coordinate values in degrees: files written by CDO for unstructured grids carry radians
+                (tests/data/tas-healpix2.nc of the reference: `units = "radian"`)."""
+                v = np.asarray(coord.values, dtype=np.float64)
+                return np.degrees(v) if str(coord.attrs.get("units", "")).lower().startswith("rad") else v
+
             for k in ("lon", "longitude"):
                 if k in obj.coords:
-                    lon = obj.coords[k].values
+                    lon = degrees(obj.coords[k])
             for k in ("lat", "latitude"):
                 if k in obj.coords:
-                    lat = obj.coords[k].values
+                    lat = degrees(obj.coords[k])
             if lon is not None and lat is not None and lon.ndim == 1 and lat.ndim == 1:
                 if obj.coords[[k for k in ("lon", "longitude") if k in obj.coords][0]].dims == \
                         obj.coords[[k for k in ("lat", "latitude") if k in obj.coords][0]].dims:
                     # lon(cell), lat(cell): a list of cell centres (unstructured, HEALPix with coordinates)
+                    hp = gridgen.healpix_grid_of_centers(lon, lat)
+                    if hp is not None:       # HEALPix pixel centres: con / bil know the pixels, not just the centres
+                        return hp
                     return gridgen.Grid("points", lon, lat, name="cell centres", cdo_type="unstructured")
                 return gridgen.regular_grid_from_centers(lon, lat)   # either latitude direction
         raise NotImplementedError("native weight generation supports CDO grid names "

@@ -162,6 +162,29 @@ def healpix_centers(nside, nested=True):
     return lon, lat
 
 
+def healpix_grid_of_centers(lon, lat, tol=1e-6):
+    """The HEALPix grid (nested or ring) whose pixel centres the given cell-centre list is, or None.  A file that
+    holds a HEALPix field with explicit coordinates (cdo setgrid,hp<N>; tests/data/tas-healpix2.nc of the
+    reference) is recognised by them, which opens the methods that need the pixels themselves (con, bil)."""
+    lon = np.asarray(lon, dtype=np.float64).ravel()
+    lat = np.asarray(lat, dtype=np.float64).ravel()
+    n = lon.size
+    if n < 12 or n % 12 or lat.size != n:
+        return None
+    nside = int(round(np.sqrt(n / 12.0)))
+    if 12 * nside * nside != n or nside & (nside - 1):
+        return None
+    for nested in (True, False):
+        hlon, hlat = healpix_centers(nside, nested=nested)
+        dlon = np.abs(((hlon - lon + 180.0) % 360.0) - 180.0)
+        pole = np.abs(np.abs(hlat) - 90.0) < 1e-9
+        if np.all(np.abs(hlat - lat) <= tol) and np.all((dlon <= tol) | pole):
+            g = Grid("points", hlon, hlat, name=f"hp{nside}_{'nested' if nested else 'ring'}", cdo_type="healpix")
+            g.nside, g.nested = nside, nested
+            return g
+    return None
+
+
 def gaussian_grid(n, name=None):
     """Regular Gaussian grid F<N> / n<N>: 4N longitudes from 0, 2N Gauss-Legendre latitudes
     (south to north here; cell bounds at mid-points, clipped at the poles)."""

@@ -27,4 +27,12 @@ with h5py.File("/root/reference/tests/data/2t-era5.nc", "r") as f:
     np.savez_compressed(os.path.join(HERE, "2t_era5.npz"), t2m=f["2t"][...].astype(np.float32),
                         lat=f["lat"][:].astype(np.float64), lon=f["lon"][:].astype(np.float64),
                         time=f["time"][:].astype(np.float64))
+from scipy.io import netcdf_file   # tas-healpix2.nc is classic NetCDF-3
+with netcdf_file("/root/reference/tests/data/tas-healpix2.nc", "r", mmap=False) as f:
+    # tests/data/tas-healpix2.nc (identity2d_test.py:14-18): a HEALPix field (nside 32, nested) with explicit cell
+    # coordinates in RADIANS; first two time steps + the coordinates as written
+    units = f.variables["lat"].units
+    np.savez_compressed(os.path.join(HERE, "tas_healpix2.npz"), tas=f.variables["tas"][:2].astype(np.float32),
+                        lat=f.variables["lat"][:].astype(np.float64), lon=f.variables["lon"][:].astype(np.float64),
+                        units=np.array(units.decode() if isinstance(units, bytes) else str(units)))
 print("missing per level:", np.isnan(ua).reshape(19, -1).sum(axis=1))

@@ -431,6 +431,29 @@ def test_healpix_source_with_setgrid(hip):
         assert set(np.unique(rfield["tas"].values[t])) <= set(xfield["tas"].values[t].astype(np.float64))
 
 
+@pytest.mark.parametrize("method", ["nn", "con", "bil"])
+def test_reference_test_data_tas_healpix2(hip, method):
+    """identity2d_test.py:14-18 (`tas-healpix2.nc` -> r360x180, nn and con; bil added): a nested HEALPix field with
+    explicit coordinates in radians, init from the data itself.  The grid is recognised from the pixel centres; values
+    against the oracle, temperatures stay temperatures, con keeps the global mean."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tas_healpix2.npz"))
+    coords = {"time": np.arange(2), "lat": DataArray(z["lat"], dims=("pix",), attrs={"units": "radian"}),
+              "lon": DataArray(z["lon"], dims=("pix",), attrs={"units": "radian"})}
+    field = DataArray(z["tas"], dims=("time", "pix"), coords=coords, name="tas", attrs={"CDI_grid_type": "unstructured"})
+    rg = Regridder(source_grid=field, target_grid="r360x180", method=method)
+    out = rg.regrid(field)
+    assert out.shape == (2, 180, 360) and out.values.dtype == np.float64 and "CDI_grid_type" not in out.attrs
+    w = rg.grids[0].weights
+    assert w.sizes["src_grid_size"] == 12288
+    ref = oracle_2d(w, z["tas"].reshape(2, -1))
+    assert_same(out.values.reshape(2, -1), ref, exact=True)
+    assert 190.0 < np.nanmin(out.values) and np.nanmax(out.values) < 330.0
+    if method == "con":
+        area = np.diff(np.sin(np.radians(np.linspace(-90, 90, 181))))[:, None] * np.full((1, 360), np.radians(1.0))
+        for t in range(2):
+            assert abs((out.values[t] * area).sum() / (4 * np.pi) - z["tas"][t].astype(np.float64).mean()) < 0.02
+
+
 def test_healpix_source_bilinear_with_setgrid(hip):
     """basic_test.py:14-29 with method bil: the ring-wise 4-point scheme from the 12 base pixels; results stay inside
     the range of the step's source values and equal the oracle bit for bit."""

@@ -290,3 +290,37 @@ def test_second_order_conservative_weights_follow_their_definition():
         assert np.isclose(w1 / dst_area[d[k]], rm[k, 0], rtol=1e-6)
         assert np.isclose(w2 / dst_area[d[k]], rm[k, 1], rtol=1e-4, atol=1e-8)
         assert np.isclose(w3 / dst_area[d[k]], rm[k, 2], rtol=1e-4, atol=1e-8)
+
+
+def test_healpix_field_with_coordinates_in_radians_is_recognised():
+    """tests/data/tas-healpix2.nc of the reference (identity2d_test.py:14-18; fixture tests/golden/tas_healpix2.npz):
+    a nested nside-32 field whose lon(pix) / lat(pix) are in radians.  CdoGenerate converts by the `units` attribute
+    and recognises the pixel centres as a HEALPix grid, so conservative weights are available for it."""
+    import os
+    from smmregrid_amd import CdoGenerate, DataArray
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tas_healpix2.npz"))
+    assert str(z["units"]) == "radian"
+    coords = {"lat": DataArray(z["lat"], dims=("pix",), attrs={"units": "radian"}),
+              "lon": DataArray(z["lon"], dims=("pix",), attrs={"units": "radian"})}
+    field = DataArray(z["tas"], dims=("time", "pix"), coords=coords, name="tas")
+    g = CdoGenerate._grid_of(field)
+    assert g.cdo_type == "healpix" and g.nside == 32 and g.nested is True and g.size == 12288
+    ref = gridgen.parse_grid("hp32_nested")
+    assert np.allclose(g.lon, ref.lon) and np.allclose(g.lat, ref.lat)
+    # ring order and non-HEALPix lists
+    rlon, rlat = gridgen.healpix_centers(8, nested=False)
+    assert gridgen.healpix_grid_of_centers(rlon, rlat).nested is False
+    assert gridgen.healpix_grid_of_centers(rlon[::-1], rlat[::-1]) is None
+    assert gridgen.healpix_grid_of_centers(rlon[:100], rlat[:100]) is None
+    # degrees stay degrees
+    plain = DataArray(z["tas"], dims=("time", "pix"),
+                      coords={"lat": DataArray(np.degrees(z["lat"]), dims=("pix",), attrs={"units": "degrees_north"}),
+                              "lon": DataArray(np.degrees(z["lon"]), dims=("pix",), attrs={"units": "degrees_east"})}, name="tas")
+    assert CdoGenerate._grid_of(plain).nside == 32
+    w = gridgen.generate_weights(g, "r72x36", method="con")
+    m = _dense(w)
+    y = m @ z["tas"][0].astype(np.float64)
+    assert np.allclose(m.sum(axis=1), 1.0) and 200.0 < y.min() and y.max() < 330.0
+    mean_src = z["tas"][0].astype(np.float64).mean()                       # equal-area pixels
+    dst = gridgen.parse_grid("r72x36")
+    assert abs((y * _cell_areas(dst)).sum() / (4 * np.pi) - mean_src) < 0.05
