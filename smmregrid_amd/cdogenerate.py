@@ -61,9 +61,11 @@ class CdoGenerate:
         """CDO grid name, Grid, or a data object with 1-D lon/lat coordinates -> Grid."""
         if isinstance(obj, (str, gridgen.Grid)):
             return gridgen.parse_grid(obj)
+        parent = None
         if isinstance(obj, Dataset):
+            parent = obj
             obj = next(v for v in obj.data_vars.values()
-                       if GridType(v.dims).horizontal_dims)
+                       if GridType(v.dims).horizontal_dims and not any(t in str(v.name) for t in ("bnds", "bounds", "vertices")))
         if isinstance(obj, DataArray):
             lon = lat = None
 
@@ -87,7 +89,30 @@ class CdoGenerate:
                     if hp is not None:       # HEALPix pixel centres: con / bil know the pixels, not just the centres
                         return hp
                     return gridgen.Grid("points", lon, lat, name="cell centres", cdo_type="unstructured")
-                return gridgen.regular_grid_from_centers(lon, lat)   # either latitude direction
+                def edges(coord_name, centres):
+                    """nx + 1 cell edges from the file's (n, 2) bounds variable named by the coordinate's `bounds`
+                    attribute (CF), when the cells are contiguous; None -> mid-points.  CDO uses a file's bounds too."""
+                    if parent is None:
+                        return None
+                    bname = obj.coords[coord_name].attrs.get("bounds")
+                    if not bname or bname not in parent:
+                        return None
+                    b = np.asarray(parent[bname].values, dtype=np.float64)
+                    if str(parent[bname].attrs.get("units", obj.coords[coord_name].attrs.get("units", ""))).lower().startswith("rad"):
+                        b = np.degrees(b)
+                    if b.shape != (centres.size, 2):
+                        return None
+                    lo, hi = b.min(axis=1), b.max(axis=1)
+                    rising = centres.size < 2 or centres[0] < centres[-1]
+                    e = np.concatenate([lo[:1], hi]) if rising else np.concatenate([hi[:1], lo])
+                    inner_ok = np.allclose(lo[1:], hi[:-1], atol=1e-6) if rising else np.allclose(hi[1:], lo[:-1], atol=1e-6)
+                    return e if inner_ok else None
+                lon_name = [k for k in ("lon", "longitude") if k in obj.coords][0]
+                lat_name = [k for k in ("lat", "latitude") if k in obj.coords][0]
+                try:
+                    return gridgen.regular_grid_from_centers(lon, lat, lon_b=edges(lon_name, lon), lat_b=edges(lat_name, lat))
+                except ValueError:
+                    return gridgen.regular_grid_from_centers(lon, lat)   # unusable bounds: mid-points, either direction
         raise NotImplementedError("native weight generation supports CDO grid names "
                                   "(r<NX>x<NY>, hp<N>) and regular lon/lat data only")
 
@@ -95,7 +120,8 @@ class CdoGenerate:
         """Land/sea mask from the NaNs of the source field (CDO's behaviour for data with missing values)."""
         obj = self.source_grid
         if isinstance(obj, Dataset):
-            obj = next(v for v in obj.data_vars.values() if GridType(v.dims).horizontal_dims)
+            obj = next(v for v in obj.data_vars.values() if GridType(v.dims).horizontal_dims
+                       and not any(t in str(v.name) for t in ("bnds", "bounds", "vertices")))
         if not isinstance(obj, DataArray):
             return None
         gt = GridType(obj.dims)

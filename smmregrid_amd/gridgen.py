@@ -78,8 +78,10 @@ def regular_grid(nx, ny, name=None):
     return Grid("regular", lon, lat, lon_b, lat_b, name=name or f"r{nx}x{ny}")
 
 
-def regular_grid_from_centers(lon, lat, name=None):
-    """Regular grid from 1-D centre coordinates (bounds at mid-points, poles clipped)."""
+def regular_grid_from_centers(lon, lat, name=None, lon_b=None, lat_b=None):
+    """Regular grid from 1-D centre coordinates.  Cell bounds: the given edges (`lon_b` nx + 1, `lat_b` ny + 1, in
+    the order of the centres -- what a file's lon_bnds / lat_bnds hold, e.g. the true Gaussian cell edges), else
+    mid-points with the poles clipped (what CDO generates for a file without bounds)."""
     lon = np.asarray(lon, dtype=np.float64)
     lat = np.asarray(lat, dtype=np.float64)
 
@@ -95,7 +97,14 @@ def regular_grid_from_centers(lon, lat, name=None):
     descending = lat.size > 1 and lat[0] > lat[-1]
     if descending:
         lat = lat[::-1]
-    g = Grid("regular", lon, lat, bounds(lon), bounds(lat, -90.0, 90.0), name=name or "lonlat")
+        if lat_b is not None:
+            lat_b = np.asarray(lat_b, dtype=np.float64)[::-1]
+    lon_edges = bounds(lon) if lon_b is None else np.asarray(lon_b, dtype=np.float64)
+    lat_edges = bounds(lat, -90.0, 90.0) if lat_b is None else np.clip(np.asarray(lat_b, dtype=np.float64), -90.0, 90.0)
+    if lon_edges.size != lon.size + 1 or lat_edges.size != lat.size + 1 or np.any(np.diff(lat_edges) <= 0) \
+            or np.any(np.diff(lon_edges) <= 0):
+        raise ValueError("cell bounds must be nx + 1 / ny + 1 strictly increasing edges")
+    g = Grid("regular", lon, lat, lon_edges, lat_edges, name=name or "lonlat")
     g.lat_descending = bool(descending)
     return g
 

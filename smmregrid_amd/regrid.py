@@ -113,6 +113,14 @@ class Regridder(object):
                     self.grids[index] = gridtype
                 # weights are generated from one variable of this gridtype (regrid.py:171-177)
                 sample = next(iter(gridtype.variables.values()), source_grid_array)
+                if isinstance(source_grid_array, Dataset) and isinstance(sample, DataArray) and gridtype.bounds:
+                    # ... together with the grid's bounds variables, as the reference stores them (regrid.py:173-175):
+                    # the native generator takes a lon/lat grid's cell edges from them, as CDO does
+                    picked = Dataset({sample.name: sample}, attrs=source_grid_array.attrs)
+                    for bname in gridtype.bounds:
+                        if bname in source_grid_array and "time" not in bname:
+                            picked[bname] = source_grid_array[bname]
+                    sample = picked
                 generator = CdoGenerate(sample, target_grid, cdo=cdo,
                                         cdo_options=cdo_options, cdo_extra=cdo_extra,
                                         loglevel=loglevel)

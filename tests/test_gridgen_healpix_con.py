@@ -324,3 +324,40 @@ def test_healpix_field_with_coordinates_in_radians_is_recognised():
     mean_src = z["tas"][0].astype(np.float64).mean()                       # equal-area pixels
     dst = gridgen.parse_grid("r72x36")
     assert abs((y * _cell_areas(dst)).sum() / (4 * np.pi) - mean_src) < 0.05
+
+
+def test_cell_edges_come_from_the_files_bounds_variables():
+    """A lon/lat file that carries lat_bnds / lon_bnds (CF `bounds` attribute; tests/data/tas-ecearth.nc of the reference:
+    a Gaussian grid whose first cell reaches the pole) gives its cell edges to the native generator, as it does to CDO;
+    without them -- or when they are not contiguous -- the edges are the mid-points.  Either latitude direction."""
+    from smmregrid_amd import CdoGenerate, DataArray, Dataset
+    g = gridgen.gaussian_grid(16)
+    lat_b = g.lat_b.copy()
+    lat_b[3] += 0.05                                            # a file's edges need not be mid-points
+    lat_bnds = np.stack([lat_b[:-1], lat_b[1:]], axis=1)
+    lon_bnds = np.stack([g.lon_b[:-1], g.lon_b[1:]], axis=1)
+    x = np.ones((2, g.lat.size, g.lon.size))
+
+    def dataset(lat, lat_bnds):
+        coords = {"time": np.arange(2), "lat": DataArray(lat, dims=("lat",), attrs={"units": "degrees_north", "bounds": "lat_bnds"}),
+                  "lon": DataArray(g.lon, dims=("lon",), attrs={"units": "degrees_east", "bounds": "lon_bnds"})}
+        ds = Dataset({"tas": DataArray(x, dims=("time", "lat", "lon"), coords=coords, name="tas")})
+        ds["lat_bnds"] = (("lat", "bnds"), lat_bnds)
+        ds["lon_bnds"] = (("lon", "bnds"), lon_bnds)
+        return ds
+
+    ds = dataset(g.lat, lat_bnds)
+    got = CdoGenerate._grid_of(ds)
+    assert np.allclose(got.lat_b, lat_b) and np.allclose(got.lon_b, g.lon_b) and not got.lat_descending
+    alone = CdoGenerate._grid_of(ds["tas"])                     # no bounds in reach: mid-points
+    assert not np.allclose(alone.lat_b, lat_b) and np.isclose(alone.lat_b[1], 0.5 * (g.lat[0] + g.lat[1]))
+    desc = CdoGenerate._grid_of(dataset(g.lat[::-1].copy(), lat_bnds[::-1, ::-1].copy()))
+    assert desc.lat_descending and np.allclose(desc.lat_b, lat_b)
+    broken = lat_bnds.copy()
+    broken[5, 1] += 0.3                                         # a gap between two cells: not usable
+    assert np.allclose(CdoGenerate._grid_of(dataset(g.lat, broken)).lat_b, alone.lat_b)
+    # the conservative weights notice: the areas of the moved cells change, rows still sum to one
+    w = gridgen.generate_weights(got, "r18x9", method="con")
+    w0 = gridgen.generate_weights(alone, "r18x9", method="con")
+    assert not np.array_equal(w["remap_matrix"].values, w0["remap_matrix"].values)
+    assert np.allclose(np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0]), 1.0)
