@@ -361,3 +361,20 @@ def test_cell_edges_come_from_the_files_bounds_variables():
     w0 = gridgen.generate_weights(alone, "r18x9", method="con")
     assert not np.array_equal(w["remap_matrix"].values, w0["remap_matrix"].values)
     assert np.allclose(np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0]), 1.0)
+
+
+def test_areas_of_a_healpix_field_with_coordinates():
+    """areas_test.py:17-31, :34-46 with tas-healpix2.nc as source and as target: 12288 equal cells that add up to
+    the Earth's surface (the grid is recognised from its pixel centres in radians)."""
+    import os
+    from smmregrid_amd import CdoGenerate, DataArray
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tas_healpix2.npz"))
+    coords = {"lat": DataArray(z["lat"], dims=("pix",), attrs={"units": "radian"}),
+              "lon": DataArray(z["lon"], dims=("pix",), attrs={"units": "radian"})}
+    field = DataArray(z["tas"], dims=("time", "pix"), coords=coords, name="tas")
+    earth = 5.101e8
+    for gen, kw in ((CdoGenerate(field, "r360x180"), {}), (CdoGenerate("r360x180", field), {"target": True})):
+        area = gen.areas(**kw)
+        assert area["cell_area"].shape == (12288,)
+        assert abs(area["cell_area"].values.sum() / 1e6 - earth) < 0.02 * earth
+        assert np.allclose(area["cell_area"].values, area["cell_area"].values[0])
