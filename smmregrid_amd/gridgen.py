@@ -294,6 +294,35 @@ def _unit_vectors(lon, lat):
     return np.stack([np.cos(phi) * np.cos(lam), np.cos(phi) * np.sin(lam), np.sin(phi)], axis=1)
 
 
+def _is_cyclic(grid):
+    """A regular grid whose longitudes close the circle (last centre + one step = first centre + 360)."""
+    nx = grid.lon.size
+    if nx < 2:
+        return True
+    step = (grid.lon[-1] - grid.lon[0]) / (nx - 1)
+    return abs(grid.lon[-1] + step - grid.lon[0] - 360.0) < 1e-6 * max(1.0, abs(step)) * nx
+
+
+def _lon_corners(src, lon):
+    """(i0, i1, fx) of the two source columns either side of every longitude.  Global (cyclic) grids wrap and are
+    taken as equally spaced, as before; a REGIONAL grid does not wrap: points beyond its first / last column take
+    that column (fx clamped), the columns need not be equally spaced."""
+    nx = src.lon.size
+    if _is_cyclic(src):
+        dlon = 360.0 / nx if nx > 1 else 360.0
+        u = ((lon - src.lon[0]) % 360.0) / dlon
+        i0 = np.floor(u).astype(np.int64)
+        fx = u - i0
+        i0 = i0 % nx
+        return i0, (i0 + 1) % nx, fx
+    rel = ((np.asarray(lon) - src.lon[0] + 180.0) % 360.0) - 180.0 + src.lon[0]     # nearest image of the point
+    rel = np.where(rel < src.lon[0] - 180.0, rel + 360.0, rel)
+    i1 = np.clip(np.searchsorted(src.lon, rel, side="right"), 1, nx - 1)
+    i0 = i1 - 1
+    fx = np.clip((rel - src.lon[i0]) / (src.lon[i1] - src.lon[i0]), 0.0, 1.0)
+    return i0, i1, fx
+
+
 def bilinear_weights(src, dst, src_mask=None):
     """4-point bilinear from a regular lon/lat source (periodic in longitude,
     clamped at the first/last latitude row) to the destination cell centres.
@@ -309,12 +338,7 @@ def bilinear_weights(src, dst, src_mask=None):
         raise ValueError("bilinear generation needs a regular or HEALPix (hp<N>) source grid")
     nx, ny = src.lon.size, src.lat.size
     lon, lat = dst.centers()
-    dlon = 360.0 / nx if nx > 1 else 360.0
-    u = ((lon - src.lon[0]) % 360.0) / dlon
-    i0 = np.floor(u).astype(np.int64)
-    fx = u - i0
-    i0 = i0 % nx
-    i1 = (i0 + 1) % nx
+    i0, i1, fx = _lon_corners(src, lon)
     j1 = np.clip(np.searchsorted(src.lat, lat, side="right"), 1, ny - 1)
     j0 = j1 - 1
     fy = np.clip((lat - src.lat[j0]) / (src.lat[j1] - src.lat[j0]), 0.0, 1.0)
@@ -353,12 +377,7 @@ def bicubic_weights(src, dst, src_mask=None):
         raise ValueError("bicubic generation needs a regular source grid")
     nx, ny = src.lon.size, src.lat.size
     lon, lat = dst.centers()
-    dlon = 360.0 / nx if nx > 1 else 360.0
-    u = ((lon - src.lon[0]) % 360.0) / dlon
-    i0 = np.floor(u).astype(np.int64)
-    fx = u - i0
-    i0 = i0 % nx
-    i1 = (i0 + 1) % nx
+    i0, i1, fx = _lon_corners(src, lon)
     j1 = np.clip(np.searchsorted(src.lat, lat, side="right"), 1, ny - 1)
     j0 = j1 - 1
     fy = np.clip((lat - src.lat[j0]) / (src.lat[j1] - src.lat[j0]), 0.0, 1.0)
@@ -498,8 +517,8 @@ def nearest_weights(src, dst, src_mask=None):
         imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
         if imask.size != src.size:
             raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
-    if src.kind != "regular" or imask is not None:
-        # cell-centre list (HEALPix, unstructured) or masked source: nearest by great-circle
+    if src.kind != "regular" or imask is not None or not _is_cyclic(src):
+        # cell-centre list (HEALPix, unstructured), masked source or regional lon/lat grid: nearest by great-circle
         # distance == nearest by chord length between unit vectors
         from scipy.spatial import cKDTree
         slon, slat = src.centers()

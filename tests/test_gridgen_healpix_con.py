@@ -378,3 +378,29 @@ def test_areas_of_a_healpix_field_with_coordinates():
         assert area["cell_area"].shape == (12288,)
         assert abs(area["cell_area"].values.sum() / 1e6 - earth) < 0.02 * earth
         assert np.allclose(area["cell_area"].values, area["cell_area"].values[0])
+
+
+def test_regional_lonlat_sources_do_not_wrap():
+    """A regional lon/lat source (the layout of the reference's tests/data/regional.nc: 61 x 90 cells of one degree):
+    bilinear / bicubic corners are found by position, not by assuming 360 / nx spacing, points beyond the region take
+    its edge column (extrapolation by the nearest edge), nearest neighbour searches the centres; global grids keep the
+    equally spaced periodic rule bit for bit."""
+    lon, lat = np.arange(0.0, 61.0), np.arange(-19.5, 70.5)
+    reg = gridgen.regular_grid_from_centers(lon, lat)
+    assert not gridgen._is_cyclic(reg) and gridgen._is_cyclic(gridgen.parse_grid("r180x90")) and gridgen._is_cyclic(gridgen.gaussian_grid(16))
+    pts = gridgen.Grid("points", np.array([10.25, 59.9, 75.0, 350.0]), np.array([0.3, 10.0, 10.0, 10.0]), cdo_type="unstructured")
+    f = lambda lo, la: 2.0 + 0.1 * lo + 0.05 * la                          # bilinear reproduces a plane inside the region
+    lon2, lat2 = reg.centers()
+    for method in ("bil", "bic"):
+        m = _dense(gridgen.generate_weights(reg, pts, method=method))
+        assert np.allclose(m.sum(axis=1), 1.0)
+        y = m @ f(lon2, lat2)
+        if method == "bil":
+            assert np.allclose(y[:2], f(pts.lon[:2], pts.lat[:2]), atol=1e-12)
+        assert np.isclose(y[2], f(60.0, 10.0)) and np.isclose(y[3], f(0.0, 10.0))       # clamped to the edge columns
+    nn = gridgen.generate_weights(reg, pts, method="nn")
+    cols = (nn["src_address"].values - 1) % 61
+    assert list(cols) == [10, 60, 60, 0]
+    con = gridgen.generate_weights(reg, "r36x18", method="con")            # cells outside the region stay uncovered
+    frac = con["dst_grid_frac"].values.reshape(18, 36)
+    assert frac[:, 10:].max() == 0.0 and np.allclose(frac[8:15, 1:5], 1.0)
