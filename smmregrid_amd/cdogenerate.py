@@ -75,12 +75,18 @@ class CdoGenerate:
                 v = np.asarray(coord.values, dtype=np.float64)
                 return np.degrees(v) if str(coord.attrs.get("units", "")).lower().startswith("rad") else v
 
-            for k in ("lon", "longitude"):
+            for k in ("nav_lon", "lon", "longitude"):
                 if k in obj.coords:
                     lon = degrees(obj.coords[k])
-            for k in ("lat", "latitude"):
+            for k in ("nav_lat", "lat", "latitude"):
                 if k in obj.coords:
                     lat = degrees(obj.coords[k])
+            if lon is not None and lat is not None and lon.ndim == 2 and lon.shape == lat.shape:
+                # curvilinear grid (nav_lon / nav_lat style 2-D coordinates): its cell centres in storage order;
+                # nn / dis work from centres, the cell shapes (con, bil) stay with CDO
+                g = gridgen.Grid("points", lon.ravel(), lat.ravel(), name="curvilinear centres", cdo_type="curvilinear")
+                g.shape2d = tuple(int(v) for v in lon.shape[::-1])          # SCRIP dims: fastest first
+                return g
             if lon is not None and lat is not None and lon.ndim == 1 and lat.ndim == 1:
                 if obj.coords[[k for k in ("lon", "longitude") if k in obj.coords][0]].dims == \
                         obj.coords[[k for k in ("lat", "latitude") if k in obj.coords][0]].dims:

@@ -47,12 +47,15 @@ class Grid:
         # HEALPix grids made by parse_grid know their resolution and pixel order (conservative weights need them)
         self.nside = None
         self.nested = None
+        self.shape2d = None        # (nx, ny) of a curvilinear grid given by 2-D centre coordinates
 
     @property
     def dims(self):
         """SCRIP ``*_grid_dims`` (fastest first)."""
         if self.kind == "regular":
             return np.array([self.lon.size, self.lat.size], dtype=np.int32)
+        if getattr(self, "shape2d", None):                       # curvilinear centres: (nx, ny) of the 2-D coordinates
+            return np.array(self.shape2d, dtype=np.int32)
         return np.array([self.lon.size], dtype=np.int32)
 
     @property

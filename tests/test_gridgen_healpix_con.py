@@ -404,3 +404,28 @@ def test_regional_lonlat_sources_do_not_wrap():
     con = gridgen.generate_weights(reg, "r36x18", method="con")            # cells outside the region stay uncovered
     frac = con["dst_grid_frac"].values.reshape(18, 36)
     assert frac[:, 10:].max() == 0.0 and np.allclose(frac[8:15, 1:5], 1.0)
+
+
+def test_curvilinear_centres_feed_nn_and_dis():
+    """A NEMO-style field (2-D nav_lon / nav_lat on (y, x); the reference's so3d-nemo.nc / onlytos-ipsl.nc layout):
+    the native generator takes the cell centres in storage order for `nn` and `dis`, reports (nx, ny) as
+    src_grid_dims, and says that the cell-shape methods need regular grids."""
+    from smmregrid_amd import CdoGenerate, DataArray
+    ny, nx = 20, 30
+    j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    nav_lon = (i * 12.0 + j * 1.5) % 360.0
+    nav_lat = -80.0 + j * 8.0 + 0.5 * np.sin(i)
+    f = DataArray(np.ones((2, ny, nx)), dims=("time", "y", "x"),
+                  coords={"nav_lon": DataArray(nav_lon, dims=("y", "x")), "nav_lat": DataArray(nav_lat, dims=("y", "x"))}, name="tos")
+    g = CdoGenerate._grid_of(f)
+    assert g.kind == "points" and g.cdo_type == "curvilinear" and list(g.dims) == [nx, ny] and g.size == nx * ny
+    w = gridgen.generate_weights(g, "r36x18", method="nn")
+    assert list(w["src_grid_dims"].values) == [nx, ny] and w.sizes["num_links"] == 36 * 18
+    d = gridgen.parse_grid("r36x18")
+    dl, dla = d.centers()
+    v = lambda lo, la: np.stack([np.cos(la * DEG) * np.cos(lo * DEG), np.cos(la * DEG) * np.sin(lo * DEG), np.sin(la * DEG)], -1)
+    best = (v(dl, dla) @ v(nav_lon.ravel(), nav_lat.ravel()).T).argmax(axis=1)
+    assert np.array_equal(w["src_address"].values - 1, best)
+    assert gridgen.generate_weights(g, "r36x18", method="dis").sizes["num_links"] == 4 * 36 * 18
+    with pytest.raises(ValueError, match="regular"):
+        gridgen.generate_weights(g, "r36x18", method="con")
