@@ -454,6 +454,38 @@ def test_reference_test_data_tas_healpix2(hip, method):
             assert abs((out.values[t] * area).sum() / (4 * np.pi) - z["tas"][t].astype(np.float64).mean()) < 0.02
 
 
+@pytest.mark.parametrize("method", ["nn", "dis"])
+def test_curvilinear_source_field(hip, rng, method):
+    """A NEMO-style field with 2-D nav_lon / nav_lat on (y, x) and a depth dimension with its own land mask
+    (identity3d_test.py:10-15 uses so3d-nemo.nc like this): init from the data, weights per level from the centres,
+    results against the oracle level by level."""
+    ny, nx, nl = 24, 40, 3
+    j, i = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    nav_lon = (i * 9.0 + j * 0.7) % 360.0
+    nav_lat = -82.0 + j * 7.0 + 0.4 * np.sin(i)
+    x = (10.0 + rng.standard_normal((2, nl, ny, nx))).astype(np.float32)
+    for lev in range(nl):
+        x[:, lev, :, : 4 + 6 * lev] = np.nan                               # the land mask grows with depth
+    f = DataArray(x, dims=("time", "lev", "y", "x"),
+                  coords={"time": np.arange(2), "lev": np.array([5.0, 50.0, 500.0]),
+                          "nav_lon": DataArray(nav_lon, dims=("y", "x")), "nav_lat": DataArray(nav_lat, dims=("y", "x"))}, name="so")
+    rg = Regridder(source_grid=f, target_grid="r36x18", method=method)
+    assert rg.grids[0].mask_dim == "lev"
+    out = rg.regrid(f)
+    assert out.shape == (2, 3, 18, 36)
+    w3 = rg.grids[0].weights
+    assert list(w3["src_grid_dims"].values) == [nx, ny]
+    ll = w3["link_length"].values
+    for lev in range(nl):
+        csr = oracle.coo_to_csr_c(nx * ny, 36 * 18, w3["src_address"].values[lev, :ll[lev]], w3["dst_address"].values[lev, :ll[lev]],
+                                  w3["remap_matrix"].values[lev, :ll[lev], 0])
+        imask = w3["dst_grid_imask"].values[lev]
+        ref = oracle.apply_c(csr, x[:, lev].reshape(2, -1), bool(np.asarray(rg.grids[0].masked)[lev]), imask,
+                             w3["dst_grid_frac"].values if w3["dst_grid_frac"].values.ndim == 1 else w3["dst_grid_frac"].values[lev], 0.5)
+        assert_same(out.values[:, lev].reshape(2, -1), ref, exact=True)
+    assert np.isfinite(out.values).all()                                   # nn / dis reach the nearest unmasked cells
+
+
 def test_healpix_source_bilinear_with_setgrid(hip):
     """basic_test.py:14-29 with method bil: the ring-wise 4-point scheme from the 12 base pixels; results stay inside
     the range of the step's source values and equal the oracle bit for bit."""
