@@ -94,7 +94,9 @@ class CdoGenerate:
                     hp = gridgen.healpix_grid_of_centers(lon, lat)
                     if hp is not None:       # HEALPix pixel centres: con / bil know the pixels, not just the centres
                         return hp
-                    return gridgen.Grid("points", lon, lat, name="cell centres", cdo_type="unstructured")
+                    g = gridgen.Grid("points", lon, lat, name="cell centres", cdo_type="unstructured")
+                    g.vertices = CdoGenerate._cell_vertices(parent, obj, lon.size)   # polygons, if the file has them
+                    return g
                 def edges(coord_name, centres):
                     """nx + 1 cell edges from the file's (n, 2) bounds variable named by the coordinate's `bounds`
                     attribute (CF), when the cells are contiguous; None -> mid-points.  CDO uses a file's bounds too."""
@@ -121,6 +123,28 @@ class CdoGenerate:
                     return gridgen.regular_grid_from_centers(lon, lat)   # unusable bounds: mid-points, either direction
         raise NotImplementedError("native weight generation supports CDO grid names "
                                   "(r<NX>x<NY>, hp<N>) and regular lon/lat data only")
+
+    @staticmethod
+    def _cell_vertices(parent, var, n_cells):
+        """(lon_v, lat_v), each (cells, V) in degrees, from the bounds variables the lon / lat coordinates name (CF
+        `bounds`), or None.  Unstructured meshes written by CDO pad short polygons by repeating the last vertex."""
+        if parent is None:
+            return None
+        out = []
+        for names in (("lon", "longitude", "nav_lon"), ("lat", "latitude", "nav_lat")):
+            cname = next((k for k in names if k in var.coords), None)
+            bname = var.coords[cname].attrs.get("bounds") if cname else None
+            if not bname or bname not in parent:
+                return None
+            b = np.asarray(parent[bname].values, dtype=np.float64)
+            units = str(parent[bname].attrs.get("units", var.coords[cname].attrs.get("units", ""))).lower()
+            if units.startswith("rad"):
+                b = np.degrees(b)
+            b = b.reshape(-1, b.shape[-1])
+            if b.shape[0] != n_cells or b.shape[1] < 3:
+                return None
+            out.append(b)
+        return tuple(out)
 
     def _source_mask(self, level=None, mask_dim=None):
         """Land/sea mask from the NaNs of the source field (CDO's behaviour for data with missing values)."""

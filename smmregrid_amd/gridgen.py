@@ -48,6 +48,7 @@ class Grid:
         self.nside = None
         self.nested = None
         self.shape2d = None        # (nx, ny) of a curvilinear grid given by 2-D centre coordinates
+        self.vertices = None       # (lon_v, lat_v), each (cells, V): cell polygons of an unstructured / curvilinear grid
 
     @property
     def dims(self):
@@ -608,7 +609,9 @@ def conservative_weights(src, dst, src_mask=None, norm="fracarea"):
     `fracarea` (rows with frac > 0 sum to 1) or `destarea`."""
     src, dst = parse_grid(src), parse_grid(dst)
     if src.kind != "regular" or dst.kind != "regular":
-        raise ValueError("conservative generation needs regular source and destination grids")
+        raise ValueError("conservative generation needs cells: regular / Gaussian / HEALPix grids, or a list of cell "
+                         "centres that comes with its cell vertices (lon_bnds / lat_bnds in the source Dataset) and "
+                         "a regular destination grid; a bare list of centres has no areas to conserve")
     nx, mx = src.lon.size, dst.lon.size
     ld, ls, lw = _overlap_1d(src.lon_b, dst.lon_b, periodic=360.0)
     td, ts, tw = _overlap_1d(np.sin(src.lat_b * DEG), np.sin(dst.lat_b * DEG))
@@ -767,6 +770,122 @@ def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", sampl
     elif norm == "destarea":
         w = area / (dst_area[dst_addr] if hp_is_dst else np.maximum(np.bincount(reg_idx, weights=cnt / per * pix_area,
                                                                         minlength=dst.size), 1e-300)[dst_addr])
+    else:
+        raise ValueError("norm must be 'fracarea' or 'destarea'")
+    src_addr, dst_addr, w = _sort_links(src_addr + 1, dst_addr + 1, w)
+    return _scrip_dataset(src, dst, src_addr, dst_addr, w, "con", src_imask=imask, dst_frac=np.clip(frac, 0.0, 1.0),
+                          dst_area=dst_area, norm=norm)
+
+
+def _polygon_overlap_areas(src, dst, m, chunk=200000, neighbours=8):
+    """(dst cell, src cell, overlap area on the unit sphere) of every pair of a polygon-cell source grid and a regular
+    target grid that shares sub-cell centres: see polygon_conservative_weights.  Kept on the source grid per target,
+    so the levels of a 3-D field (same cells, another mask) pay for the geometry once."""
+    from scipy.spatial import cKDTree
+    cache = src.__dict__.setdefault("_overlap_cache", {})
+    key = (dst.lon_b.tobytes(), dst.lat_b.tobytes(), m)
+    if key in cache:
+        return cache[key]
+    lon_v, lat_v = (np.asarray(a, dtype=np.float64) for a in src.vertices)
+    n, V = lon_v.shape
+    if n != src.size:
+        raise ValueError("cell vertices do not match the number of cells")
+    mx = dst.lon.size
+    slon, slat = src.centers()
+    centre = _unit_vectors(slon, slat)                                        # (n, 3)
+    tree = cKDTree(centre)
+    k = int(min(neighbours, n))
+    # tangent basis of every source cell and its vertices in that plane (gnomonic: great circles are straight lines)
+    east = np.stack([-np.sin(np.radians(slon)), np.cos(np.radians(slon)), np.zeros(n)], axis=1)
+    north = np.cross(centre, east)
+    vert = _unit_vectors(lon_v.ravel(), lat_v.ravel()).reshape(n, V, 3)
+    dotc = np.einsum("nvk,nk->nv", vert, centre)
+    usable = (dotc > 1e-6).all(axis=1)                                        # a vertex beyond the horizon: not a cell
+    dotc = np.where(dotc > 1e-6, dotc, 1.0)
+    vx = np.einsum("nvk,nk->nv", vert, east) / dotc
+    vy = np.einsum("nvk,nk->nv", vert, north) / dotc
+    vx2, vy2 = np.roll(vx, -1, axis=1), np.roll(vy, -1, axis=1)
+    # equal-area sub-cell centres of the target grid, (ny * m) x (nx * m)
+    fr = (np.arange(m) + 0.5) / m
+    sub_lon = (dst.lon_b[:-1, None] + np.diff(dst.lon_b)[:, None] * fr[None, :]).ravel()
+    sb = np.sin(dst.lat_b * DEG)
+    sub_lat = np.degrees(np.arcsin(np.clip((sb[:-1, None] + np.diff(sb)[:, None] * fr[None, :]).ravel(), -1.0, 1.0)))
+    n_sub = sub_lon.size * sub_lat.size
+    keys, counts = [], []
+    for lo in range(0, n_sub, chunk):
+        idx = np.arange(lo, min(n_sub, lo + chunk), dtype=np.int64)
+        jj, ii = idx // sub_lon.size, idx % sub_lon.size
+        p = _unit_vectors(sub_lon[ii], sub_lat[jj])                           # (P, 3)
+        cell_d = (jj // m) * mx + (ii // m)
+        _, cand = tree.query(p, k=k)
+        cand = cand.reshape(-1, k)
+        owner = np.full(idx.size, -1, dtype=np.int64)
+        todo = np.arange(idx.size)
+        for c in range(k):               # nearest centre first: most sub-cells lie in that cell, few reach the later ones
+            if todo.size == 0:
+                break
+            cc = cand[todo, c]
+            q = p[todo]
+            dp = np.einsum("pk,pk->p", q, centre[cc])
+            ok = (dp > 1e-6) & usable[cc]
+            dp = np.where(ok, dp, 1.0)
+            px = (np.einsum("pk,pk->p", q, east[cc]) / dp)[:, None]
+            py = (np.einsum("pk,pk->p", q, north[cc]) / dp)[:, None]
+            x1, y1, x2, y2 = vx[cc], vy[cc], vx2[cc], vy2[cc]
+            with np.errstate(invalid="ignore", divide="ignore"):
+                cross = ((y1 > py) != (y2 > py)) & (px < (x2 - x1) * (py - y1) / (y2 - y1) + x1)
+            inside = ok & (np.sum(cross, axis=1) % 2 == 1)
+            owner[todo[inside]] = cc[inside]
+            todo = todo[~inside]
+        hit = owner >= 0
+        uk, uc = np.unique(cell_d[hit] * n + owner[hit], return_counts=True)
+        keys.append(uk)
+        counts.append(uc)
+    key_all = np.concatenate(keys) if keys else np.zeros(0, np.int64)
+    cnt = np.concatenate(counts).astype(np.float64) if counts else np.zeros(0)
+    uk, inv = np.unique(key_all, return_inverse=True)
+    cnt = np.bincount(inv, weights=cnt) if uk.size else cnt
+    dst_addr, src_addr = uk // n, uk % n
+    dst_area = (np.diff(sb)[:, None] * (np.diff(dst.lon_b) * DEG)[None, :]).ravel()
+    cache.clear()                                                             # one target at a time is enough
+    cache[key] = (dst_addr, src_addr, cnt / (m * m) * dst_area[dst_addr], dst_area)
+    return cache[key]
+
+
+def polygon_conservative_weights(src, dst, src_mask=None, norm="fracarea", samples=None):
+    """First-order conservative weights from a grid of POLYGON cells (unstructured meshes, curvilinear grids: the cell
+    vertices a file carries as lon_bnds / lat_bnds, edges taken as great circles as CDO does) to a regular lon/lat
+    grid.  Every target cell is cut into m x m equal-area sub-cells (uniform in longitude and in sin latitude); the
+    source cell holding a sub-cell's centre -- searched among the nearest cell centres, tested in the gnomonic plane of
+    the candidate, where great circles are straight lines -- gets 1 / m^2 of the target cell's area.  The overlap
+    areas are exact up to the sub-cells cut by a cell edge; `samples` = m (default: sub-cells a third of a source cell
+    wide, 3 <= m <= 10).  Target area no source cell covers (outside a regional mesh, land of an ocean mesh) counts
+    as uncovered: `dst_grid_frac` = unmasked covered share, as for lon/lat sources."""
+    src, dst = parse_grid(src), parse_grid(dst)
+    if src.vertices is None or dst.kind != "regular":
+        raise ValueError("polygon conservative weights need source cell vertices and a regular destination grid")
+    n = src.size
+    imask = None
+    if src_mask is not None:
+        imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+        if imask.size != n:
+            raise ValueError(f"src_mask has {imask.size} cells, the source grid {n}")
+    if samples is None:
+        src_deg = np.degrees(np.sqrt(4.0 * np.pi / max(n, 1)))               # typical cell width if the mesh were global
+        dst_deg = min(float(np.min(np.diff(dst.lon_b))), float(np.min(np.diff(dst.lat_b))))
+        m = int(np.clip(np.ceil(3.0 * dst_deg / max(src_deg, 1e-9)), 3, 10))
+    else:
+        m = max(1, int(samples))
+    dst_addr, src_addr, area, dst_area = _polygon_overlap_areas(src, dst, m)
+    if imask is not None:
+        keep = imask[src_addr] != 0
+        dst_addr, src_addr, area = dst_addr[keep], src_addr[keep], area[keep]
+    covered = np.bincount(dst_addr, weights=area, minlength=dst.size)
+    frac = covered / dst_area
+    if norm == "fracarea":
+        w = area / covered[dst_addr]
+    elif norm == "destarea":
+        w = area / dst_area[dst_addr]
     else:
         raise ValueError("norm must be 'fracarea' or 'destarea'")
     src_addr, dst_addr, w = _sort_links(src_addr + 1, dst_addr + 1, w)
@@ -949,6 +1068,8 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     if method in ("con", "ycon"):
         if src.cdo_type == "healpix" and dst.cdo_type == "healpix" and src.nside and dst.nside:
             ds = healpix_hierarchy_weights(src, dst, src_mask=src_mask, norm=norm)
+        elif src.vertices is not None and dst.kind == "regular":
+            ds = polygon_conservative_weights(src, dst, src_mask=src_mask, norm=norm)
         elif "healpix" in (src.cdo_type, dst.cdo_type) and (src.kind == "regular" or dst.kind == "regular"):
             ds = sampled_conservative_weights(src, dst, src_mask=src_mask, norm=norm)
         else:

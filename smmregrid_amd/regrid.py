@@ -219,6 +219,12 @@ class Regridder(object):
                 grids.append(gt)
                 known = gt
             known.variables[name] = arr          # gridinspector.py: variables living on this grid
+        if isinstance(data, Dataset):            # gridinspector.py:183-221: spatial bounds variables go with the grid
+            for name, arr in data.data_vars.items():
+                spatial = (name.endswith("_bnds") or name.endswith("_bounds") or name == "vertices") and "time" not in name
+                for gt in grids:
+                    if spatial and set(gt.dims) & set(arr.dims) and name not in gt.bounds:
+                        gt.bounds.append(name)
         return grids
 
     # ------------------------------------------------------------------ public API

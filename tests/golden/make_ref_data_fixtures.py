@@ -36,3 +36,12 @@ with netcdf_file("/root/reference/tests/data/tas-healpix2.nc", "r", mmap=False) 
                         lat=f.variables["lat"][:].astype(np.float64), lon=f.variables["lon"][:].astype(np.float64),
                         units=np.array(units.decode() if isinstance(units, bytes) else str(units)))
 print("missing per level:", np.isnan(ua).reshape(19, -1).sum(axis=1))
+with h5py.File("/root/reference/tests/data/temp3d-fesom.nc", "r") as f:
+    # tests/data/temp3d-fesom.nc (identity3d_test.py:28-32): an unstructured ocean mesh, 3140 nodes x 47 levels, with
+    # the cell polygons in lon_bnds / lat_bnds (16 vertices, short polygons padded with their last vertex); three of
+    # the levels (the file holds 0, not a missing value, below the sea floor) + the mesh
+    lev = [0, 23, 40]
+    np.savez_compressed(os.path.join(HERE, "temp3d_fesom.npz"), temp=f["temp"][0][lev].astype(np.float32),
+                        nz1=f["nz1"][:][lev].astype(np.float64),
+                        lon=f["lon"][:].astype(np.float64), lat=f["lat"][:].astype(np.float64),
+                        lon_bnds=f["lon_bnds"][...].astype(np.float32), lat_bnds=f["lat_bnds"][...].astype(np.float32))

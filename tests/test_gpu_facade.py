@@ -690,3 +690,45 @@ def test_pitched_upload_helper(hip, rng):
         xp = to_device_pitched(x)
         assert xp.shape == (11, aligned_pitch(op.n_src, dtype)) and xp.shape[1] % (128 // x.itemsize) == 0
         assert_same(op.apply(xp).to_host(), op.apply(to_device(x)).to_host(), exact=True)
+
+
+def test_unstructured_ocean_mesh_with_cell_polygons_conservative(hip, tmp_path):
+    """identity3d_test.py:28-32 (`con`, temp3d-fesom.nc -> r360x180.nc, init by grids): the reference's own mesh and
+    three of its levels (tests/golden/temp3d_fesom.npz) in a file of the same layout; the cell polygons of lon_bnds /
+    lat_bnds reach the native generator, land stays missing, values are the oracle's on the generated weights."""
+    from smmregrid_amd.io import open_dataset
+    from tests.test_gridgen_polygon import fesom_grid, write_fesom_like_file
+    _, z = fesom_grid()
+    path = str(tmp_path / "fesom_like.nc")
+    write_fesom_like_file(path, z, nt=2)
+    tfile = os.path.join(os.path.dirname(__file__), "golden", "refdata", "r360x180.nc")
+    rg = Regridder(source_grid=path, target_grid=tfile, method="con")
+    ds = open_dataset(path)
+    out = rg.regrid(ds)
+    assert out["temp"].shape == (2, 3, 180, 360) and out["temp"].dims == ("time", "nz1", "lat", "lon")
+    w = rg.grids[0].weights
+    assert w.sizes["src_grid_size"] == 3140 and w.sizes["dst_grid_size"] == 64800
+    # `nz1` is one of the reference's vertical dimensions (gridtype.py default dims): weights per level, one cell
+    # search for the three of them
+    assert rg.grids[0].mask_dim == "nz1" and w.sizes["nz1"] == 3
+    ll = w["link_length"].values
+    assert (ll == ll[0]).all()                             # the file holds 0, not a missing value, below the floor
+    csrs = [oracle.coo_to_csr_c(3140, 64800, w["src_address"].values[i, :ll[i]], w["dst_address"].values[i, :ll[i]],
+                                w["remap_matrix"].values[i, :ll[i], 0]) for i in range(3)]
+    imask = np.stack([oracle.mask_apply_c(csrs[i], w["src_grid_imask"].values[i]) for i in range(3)])
+    x = ds["temp"].values.astype(np.float64).reshape(2, 3, -1)
+    ref = oracle.apply_levels(csrs, x, 1, [0, 1, 2], oracle.check_mask(imask), imask, w["dst_grid_frac"].values, 0.5,
+                              True)
+    assert_same(out["temp"].values.reshape(ref.shape), ref, exact=True)
+    x = x.reshape(6, -1)
+    y = out["temp"].values
+    land = np.isnan(y[0, 0])
+    assert 0.30 < land.mean() < 0.45 and np.array_equal(land, w["dst_grid_frac"].values[0].reshape(180, 360) < 0.5)
+    sea = ~land
+    assert x[0].min() - 1e-9 <= y[0, 0][sea].min() and y[0, 0][sea].max() <= x[0].max() + 1e-9
+    # the surface level is warm in the tropics and cold at high latitudes on the target grid too
+    lat = out.coords["lat"].values
+    assert np.nanmean(y[0, 0][np.abs(lat) < 15]) > 24.0 and np.nanmean(y[0, 0][np.abs(lat) > 65]) < 5.0
+    # the DataArray alone has the centres but not the cells: the conservative generator says so
+    with pytest.raises((ValueError, NotImplementedError)):
+        Regridder(source_grid=ds["temp"], target_grid="r72x36", method="con")
