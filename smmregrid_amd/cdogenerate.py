@@ -83,9 +83,11 @@ class CdoGenerate:
                     lat = degrees(obj.coords[k])
             if lon is not None and lat is not None and lon.ndim == 2 and lon.shape == lat.shape:
                 # curvilinear grid (nav_lon / nav_lat style 2-D coordinates): its cell centres in storage order;
-                # nn / dis work from centres, the cell shapes (con, bil) stay with CDO
+                # nn / dis work from centres, bil from the quadrilaterals of neighbouring centres, con from the cell
+                # corners when the file carries them (bounds (y, x, 4))
                 g = gridgen.Grid("points", lon.ravel(), lat.ravel(), name="curvilinear centres", cdo_type="curvilinear")
                 g.shape2d = tuple(int(v) for v in lon.shape[::-1])          # SCRIP dims: fastest first
+                g.vertices = CdoGenerate._cell_vertices(parent, obj, lon.size)
                 return g
             if lon is not None and lat is not None and lon.ndim == 1 and lat.ndim == 1:
                 if obj.coords[[k for k in ("lon", "longitude") if k in obj.coords][0]].dims == \
@@ -131,7 +133,7 @@ class CdoGenerate:
         if parent is None:
             return None
         out = []
-        for names in (("lon", "longitude", "nav_lon"), ("lat", "latitude", "nav_lat")):
+        for names in (("nav_lon", "longitude", "lon"), ("nav_lat", "latitude", "lat")):
             cname = next((k for k in names if k in var.coords), None)
             bname = var.coords[cname].attrs.get("bounds") if cname else None
             if not bname or bname not in parent:

@@ -338,8 +338,10 @@ def bilinear_weights(src, dst, src_mask=None):
     src, dst = parse_grid(src), parse_grid(dst)
     if src.cdo_type == "healpix" and src.nside is not None:
         return _healpix_bilinear(src, dst, src_mask)
+    if src.kind != "regular" and src.shape2d is not None:
+        return _curvilinear_bilinear(src, dst, src_mask)
     if src.kind != "regular":
-        raise ValueError("bilinear generation needs a regular or HEALPix (hp<N>) source grid")
+        raise ValueError("bilinear generation needs a regular, curvilinear (2-D centres) or HEALPix (hp<N>) source grid")
     nx, ny = src.lon.size, src.lat.size
     lon, lat = dst.centers()
     i0, i1, fx = _lon_corners(src, lon)
@@ -510,6 +512,131 @@ def _healpix_bilinear(src, dst, src_mask=None):
     with np.errstate(invalid="ignore", divide="ignore"):
         wv = wv / tot[:, None]
     return _scrip_dataset(src, dst, (pix[valid] + 1).astype(np.int32), dst4[valid], wv[valid], "bil", src_imask=imask)
+
+
+def _curvilinear_bilinear(src, dst, src_mask=None, candidates=6, iterations=30):
+    """Bilinear weights from a curvilinear source (2-D lon / lat of the cell centres, e.g. an ORCA ocean grid): SCRIP's
+    scheme, as CDO's genbil uses it.  The four neighbouring centres (j, i), (j, i+1), (j+1, i+1), (j+1, i) span a
+    quadrilateral in the (lon, lat) plane -- longitudes taken relative to the target point, so the date line is no
+    seam; the quadrilateral that holds the target point is looked up among those whose centroids are nearest, the
+    point's (a, b) in [0, 1]^2 come from Newton's iteration on the bilinear map, and the weights are
+    (1-a)(1-b), a(1-b), ab, (1-a)b.  Points that plane cannot place (it tears at the geographic poles) are looked up
+    once more in the tangent plane at the point itself.  A grid that closes in longitude without repeating columns gets the wrap-around
+    quadrilaterals too.  Masked corners are dropped and the rest renormalised; a point in no quadrilateral (beyond the
+    edge of a regional grid, inside the hole of a tripolar one) or with four masked corners takes the nearest unmasked
+    centre with weight 1 -- CDO's REMAP_EXTRAPOLATE=on, which is what the reference's CdoGenerate sets by default."""
+    from scipy.spatial import cKDTree
+    nx, ny = src.shape2d
+    slon, slat = (np.asarray(a, dtype=np.float64).reshape(ny, nx) for a in src.centers())
+    imask = None
+    if src_mask is not None:
+        imask = (np.asarray(src_mask).ravel() != 0).astype(np.int32)
+        if imask.size != src.size:
+            raise ValueError(f"src_mask has {imask.size} cells, the source grid {src.size}")
+    if nx < 2 or ny < 2:
+        return nearest_weights(src, dst, src_mask=src_mask)
+    unit = _unit_vectors(slon.ravel(), slat.ravel()).reshape(ny, nx, 3)
+    step = np.linalg.norm(unit[:, 1:] - unit[:, :-1], axis=2)
+    seam = np.linalg.norm(unit[:, 0] - unit[:, -1], axis=1)
+    wrap = bool(np.median(seam) < 2.0 * np.median(step) and np.median(seam) > 0.25 * np.median(step))
+    ii = np.arange(nx if wrap else nx - 1)
+    jj = np.arange(ny - 1)
+    J, I = np.meshgrid(jj, ii, indexing="ij")
+    I1 = (I + 1) % nx
+    corner = np.stack([J * nx + I, J * nx + I1, (J + 1) * nx + I1, (J + 1) * nx + I], axis=-1).reshape(-1, 4)
+    flat_unit = unit.reshape(-1, 3)
+    centroid = flat_unit[corner].sum(axis=1)
+    norm = np.linalg.norm(centroid, axis=1)
+    good = norm > 1e-9
+    corner, centroid = corner[good], centroid[good] / norm[good, None]
+    tree = cKDTree(centroid)
+    tlon, tlat = dst.centers()
+    n = tlon.size
+    k = int(min(candidates, corner.shape[0]))
+    tunit = _unit_vectors(tlon, tlat)
+    _, cand = tree.query(tunit, k=k)
+    cand = cand.reshape(n, k)
+    flon, flat_ = slon.ravel(), slat.ravel()
+    east = np.stack([-np.sin(np.radians(tlon)), np.cos(np.radians(tlon)), np.zeros(n)], axis=1)
+    north = np.cross(tunit, east)
+
+    def plane(points, q, gnomonic):
+        """Corners `q` (P, 4) as seen from target points `points`: (lon, lat) offsets, or the tangent plane at the
+        point (great circles straight, no pole, no date line) for the places the first cannot handle."""
+        if not gnomonic:
+            return ((flon[q] - tlon[points, None] + 180.0) % 360.0) - 180.0, flat_[q] - tlat[points, None], \
+                np.ones(q.shape, dtype=bool)
+        v = flat_unit[q]                                                       # (P, 4, 3)
+        dp = np.einsum("pck,pk->pc", v, tunit[points])
+        front = dp > 0.2
+        dp = np.where(front, dp, 1.0)
+        return np.einsum("pck,pk->pc", v, east[points]) / dp, np.einsum("pck,pk->pc", v, north[points]) / dp, front
+
+    def locate(points, gnomonic):
+        """Quadrilateral, (a, b) and success flag of every point in `points`."""
+        quad = np.full(points.size, -1, dtype=np.int64)
+        todo = np.arange(points.size)
+        for c in range(k):
+            if todo.size == 0:
+                break
+            x, y, front = plane(points[todo], corner[cand[points[todo], c]], gnomonic)
+            x2, y2 = np.roll(x, -1, axis=1), np.roll(y, -1, axis=1)
+            cr = x * y2 - x2 * y                                               # side of every edge the point lies on
+            inside = ((cr >= 0).all(axis=1) | (cr <= 0).all(axis=1)) & (np.abs(cr).max(axis=1) > 0) & front.all(axis=1)
+            if not gnomonic:
+                inside &= np.abs(x).max(axis=1) < 90.0
+            quad[todo[inside]] = cand[points[todo[inside]], c]
+            todo = todo[~inside]
+        hit = np.flatnonzero(quad >= 0)
+        q = corner[quad[hit]]
+        x, y, _ = plane(points[hit], q, gnomonic)
+        a = np.full(hit.size, 0.5)
+        b = np.full(hit.size, 0.5)
+        dx1, dx2, dx3 = x[:, 1] - x[:, 0], x[:, 3] - x[:, 0], x[:, 0] - x[:, 1] + x[:, 2] - x[:, 3]
+        dy1, dy2, dy3 = y[:, 1] - y[:, 0], y[:, 3] - y[:, 0], y[:, 0] - y[:, 1] + y[:, 2] - y[:, 3]
+        for _ in range(iterations):                                            # Newton on x(a, b) = 0, y(a, b) = 0
+            fx = x[:, 0] + dx1 * a + dx2 * b + dx3 * a * b
+            fy = y[:, 0] + dy1 * a + dy2 * b + dy3 * a * b
+            xa, xb = dx1 + dx3 * b, dx2 + dx3 * a
+            ya, yb = dy1 + dy3 * b, dy2 + dy3 * a
+            det = xa * yb - xb * ya
+            det = np.where(np.abs(det) > 1e-300, det, 1e-300)
+            da, db = (-fx * yb + fy * xb) / det, (-fy * xa + fx * ya) / det
+            a, b = a + da, b + db
+            if max(np.abs(da).max(initial=0.0), np.abs(db).max(initial=0.0)) < 1e-13:
+                break
+        ok = np.isfinite(a) & np.isfinite(b) & (a > -1e-6) & (a < 1 + 1e-6) & (b > -1e-6) & (b < 1 + 1e-6)
+        return points[hit[ok]], q[ok], np.clip(a[ok], 0.0, 1.0), np.clip(b[ok], 0.0, 1.0)
+
+    found, q, a, b = locate(np.arange(n), gnomonic=False)
+    left = np.setdiff1d(np.arange(n), found, assume_unique=True)
+    if left.size:                     # around the geographic poles the (lon, lat) plane tears: look again on the sphere
+        f2, q2, a2, b2 = locate(left, gnomonic=True)
+        found, q, a, b = np.concatenate([found, f2]), np.concatenate([q, q2]), np.concatenate([a, a2]), \
+            np.concatenate([b, b2])
+    w4 = np.stack([(1 - a) * (1 - b), a * (1 - b), a * b, (1 - a) * b], axis=1)
+    valid = np.ones_like(q, dtype=bool) if imask is None else imask[q] != 0
+    # the overlap columns of a tripolar grid name the same place twice: two corners on one spot are fine, weights add up
+    wv = np.where(valid, w4, 0.0)
+    tot = wv.sum(axis=1)
+    flat0 = (tot == 0.0) & valid.any(axis=1)
+    wv[flat0] = valid[flat0] / valid[flat0].sum(axis=1, keepdims=True)
+    tot[flat0] = 1.0
+    usable = valid.any(axis=1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        wv = wv / tot[:, None]
+    keep = valid & usable[:, None]
+    d4 = np.repeat(found[:, None], 4, axis=1)
+    src_addr, dst_addr, w = q[keep], d4[keep], wv[keep]
+    rest = np.setdiff1d(np.arange(n), found[usable], assume_unique=True)    # extrapolation: nearest unmasked centre
+    cells = np.arange(src.size, dtype=np.int64) if imask is None else np.flatnonzero(imask)
+    if rest.size and cells.size:
+        _, idx = cKDTree(flat_unit[cells]).query(_unit_vectors(tlon[rest], tlat[rest]), k=1)
+        src_addr = np.concatenate([src_addr, cells[idx]])
+        dst_addr = np.concatenate([dst_addr, rest])
+        w = np.concatenate([w, np.ones(rest.size)])
+    src_addr, dst_addr, w = _sort_links(src_addr + 1, dst_addr + 1, w)
+    return _scrip_dataset(src, dst, src_addr.astype(np.int32), dst_addr.astype(np.int32), w, "bil", src_imask=imask)
 
 
 def nearest_weights(src, dst, src_mask=None):

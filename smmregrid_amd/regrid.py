@@ -113,14 +113,20 @@ class Regridder(object):
                     self.grids[index] = gridtype
                 # weights are generated from one variable of this gridtype (regrid.py:171-177)
                 sample = next(iter(gridtype.variables.values()), source_grid_array)
-                if isinstance(source_grid_array, Dataset) and isinstance(sample, DataArray) and gridtype.bounds:
-                    # ... together with the grid's bounds variables, as the reference stores them (regrid.py:173-175):
-                    # the native generator takes a lon/lat grid's cell edges from them, as CDO does
-                    picked = Dataset({sample.name: sample}, attrs=source_grid_array.attrs)
-                    for bname in gridtype.bounds:
-                        if bname in source_grid_array and "time" not in bname:
+                if isinstance(source_grid_array, Dataset) and isinstance(sample, DataArray):
+                    # ... together with the grid's bounds variables, as the reference stores them (regrid.py:173-175;
+                    # a file name goes to cdo whole, :168-169): the native generator takes a lon/lat grid's cell edges
+                    # and a mesh's cell polygons from them, as CDO does.  Bounds are the variables the reference's name
+                    # rule finds plus those the horizontal coordinates name in their CF `bounds` attribute
+                    # (`bounds_nav_lon` of a CMOR ocean file does not end in `_bounds`)
+                    named = [c.attrs.get("bounds") for k, c in sample.coords.items() if "time" not in str(k)]
+                    wanted = [b for b in dict.fromkeys(list(gridtype.bounds) + named)
+                              if b and b in source_grid_array and "time" not in b]
+                    if wanted:
+                        picked = Dataset({sample.name: sample}, attrs=source_grid_array.attrs)
+                        for bname in wanted:
                             picked[bname] = source_grid_array[bname]
-                    sample = picked
+                        sample = picked
                 generator = CdoGenerate(sample, target_grid, cdo=cdo,
                                         cdo_options=cdo_options, cdo_extra=cdo_extra,
                                         loglevel=loglevel)

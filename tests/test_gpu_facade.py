@@ -454,7 +454,7 @@ def test_reference_test_data_tas_healpix2(hip, method):
             assert abs((out.values[t] * area).sum() / (4 * np.pi) - z["tas"][t].astype(np.float64).mean()) < 0.02
 
 
-@pytest.mark.parametrize("method", ["nn", "dis"])
+@pytest.mark.parametrize("method", ["nn", "dis", "bil"])
 def test_curvilinear_source_field(hip, rng, method):
     """A NEMO-style field with 2-D nav_lon / nav_lat on (y, x) and a depth dimension with its own land mask
     (identity3d_test.py:10-15 uses so3d-nemo.nc like this): init from the data, weights per level from the centres,
@@ -732,3 +732,39 @@ def test_unstructured_ocean_mesh_with_cell_polygons_conservative(hip, tmp_path):
     # the DataArray alone has the centres but not the cells: the conservative generator says so
     with pytest.raises((ValueError, NotImplementedError)):
         Regridder(source_grid=ds["temp"], target_grid="r72x36", method="con")
+
+
+@pytest.mark.parametrize("method", ["con", "bil", "nn"])
+def test_orca_like_dataset_with_corner_bounds(hip, rng, method):
+    """identity2d_test.py:75-79 (`con`, `nn`, `bil` on a CMOR ocean file, init by grids): 2-D nav_lon / nav_lat that name
+    their corner arrays `bounds_nav_lon` / `bounds_nav_lat` (y, x, 4) in the CF `bounds` attribute, a displaced pole,
+    two overlap columns, land as NaN.  The corners reach the conservative generator through the Dataset."""
+    from tests.test_gridgen_curvilinear import rotated_pole_grid, sphere_field
+    lon, lat, clon, clat = rotated_pole_grid()
+    ny, nx = lon.shape
+    tos = np.stack([sphere_field(lon, lat) + t for t in range(3)]).astype(np.float32)
+    land = (np.abs(lat - 20.0) < 14.0) & (np.abs(((lon - 40.0 + 180.0) % 360.0) - 180.0) < 25.0)
+    tos[:, land] = np.nan
+    nav_lon = DataArray(lon, dims=("y", "x"), attrs={"units": "degrees_east", "bounds": "bounds_nav_lon"})
+    nav_lat = DataArray(lat, dims=("y", "x"), attrs={"units": "degrees_north", "bounds": "bounds_nav_lat"})
+    ds = Dataset({"tos": DataArray(tos, dims=("time", "y", "x"),
+                                   coords={"time": np.arange(3), "nav_lon": nav_lon, "nav_lat": nav_lat}, name="tos"),
+                  "bounds_nav_lon": DataArray(clon, dims=("y", "x", "nvertex")),
+                  "bounds_nav_lat": DataArray(clat, dims=("y", "x", "nvertex"))})
+    rg = Regridder(source_grid=ds, target_grid="r60x30", method=method)
+    out = rg.regrid(ds)
+    assert out["tos"].shape == (3, 30, 60) and "bounds_nav_lon" not in out.data_vars
+    w = rg.grids[0].weights
+    assert list(w["src_grid_dims"].values) == [nx, ny]
+    assert np.array_equal(w["src_grid_imask"].values, (~land).ravel().astype(np.int32))
+    ref = oracle_2d(w, tos.reshape(3, -1).astype(np.float64), masked=bool(np.asarray(rg.grids[0].masked).any()))
+    assert_same(out["tos"].values.reshape(3, -1), ref, exact=True)
+    y = out["tos"].values[0]
+    tl, tp = np.meshgrid(out.coords["lon"].values, out.coords["lat"].values)
+    sea = np.isfinite(y)
+    if method == "con":
+        assert 0.02 < (~sea).mean() < 0.08               # the continent stays missing (dst_grid_frac < 0.5)
+    else:
+        assert sea.all()                                 # bil / nn reach over to unmasked cells
+    far = sea & ~((np.abs(tp - 20.0) < 22.0) & (np.abs(((tl - 40.0 + 180.0) % 360.0) - 180.0) < 35.0))
+    assert np.abs(y[far] - sphere_field(tl[far], tp[far])).max() < {"con": 0.6, "bil": 0.08, "nn": 0.8}[method]

@@ -1,0 +1,147 @@
+"""Native bilinear / conservative weights from CURVILINEAR sources (2-D lon / lat centres; the reference's
+tests/identity2d_test.py:75-79 runs con / nn / bil on an ORCA ocean file, identity3d_test.py:15-24 con / nn on a 3-D
+one, both through cdo).  CPU checks of the geometry."""
+import numpy as np
+import pytest
+
+from smmregrid_amd import gridgen
+from smmregrid_amd.gridgen import Grid
+
+
+def curvilinear(lon2d, lat2d, corners=None):
+    g = Grid("points", np.asarray(lon2d, float).ravel() % 360.0, np.asarray(lat2d, float).ravel(),
+             name="curvilinear", cdo_type="curvilinear")
+    g.shape2d = tuple(int(v) for v in np.shape(lon2d)[::-1])
+    if corners is not None:
+        g.vertices = tuple(np.asarray(c, float).reshape(-1, 4) for c in corners)
+    return g
+
+
+def dense(ds):
+    a = np.zeros((ds.sizes["dst_grid_size"], ds.sizes["src_grid_size"]))
+    np.add.at(a, (ds["dst_address"].values - 1, ds["src_address"].values - 1), ds["remap_matrix"].values[:, 0])
+    return a
+
+
+def test_a_lonlat_grid_written_as_2d_coordinates_gives_the_regular_bilinear_weights():
+    reg = gridgen.parse_grid("r48x24")
+    lon2d, lat2d = np.meshgrid(reg.lon, reg.lat)
+    cur = curvilinear(lon2d, lat2d)
+    w_cur = gridgen.generate_weights(cur, "r50x15", method="bil")
+    w_reg = gridgen.generate_weights(reg, "r50x15", method="bil")
+    dst = gridgen.parse_grid("r50x15")
+    inside = np.repeat((dst.lat > reg.lat[0]) & (dst.lat < reg.lat[-1]), 50)
+    np.testing.assert_allclose(dense(w_cur)[inside], dense(w_reg)[inside], atol=1e-11)
+    # the grid closes in longitude without repeated columns: the seam is interpolated across, not extrapolated
+    seam = inside & (np.tile(dst.lon, 15) > reg.lon[-1])
+    assert seam.any() and (np.count_nonzero(dense(w_cur)[seam], axis=1) >= 2).all()
+    # beyond the first / last row of centres: nearest centre (REMAP_EXTRAPOLATE=on)
+    rows = dense(w_cur)[~inside]
+    assert ((rows == 1.0).sum(axis=1) == 1).all() and (rows.sum(axis=1) == 1.0).all()
+    assert w_cur["src_grid_dims"].values.tolist() == [48, 24]
+
+
+def sheared_grid(nx=60, ny=40):
+    """A regional grid whose lines are neither meridians nor parallels, across the date line."""
+    u, v = np.meshgrid(np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, ny))
+    lon = 150.0 + 70.0 * u + 12.0 * v + 6.0 * u * v
+    lat = -30.0 + 55.0 * v + 9.0 * u - 5.0 * u * u
+    return lon, lat
+
+
+def test_fields_linear_in_lon_and_lat_are_reproduced_exactly_on_a_sheared_grid_across_the_date_line():
+    lon, lat = sheared_grid()
+    cur = curvilinear(lon, lat)
+    tl, tp = np.meshgrid(np.arange(170.0, 215.0, 1.5), np.arange(-12.0, 18.0, 1.5))      # inside the region
+    dst = Grid("points", tl.ravel() % 360.0, tp.ravel(), name="targets", cdo_type="unstructured")
+    w = gridgen.generate_weights(cur, dst, method="bil")
+    a = dense(w)
+    np.testing.assert_allclose(a.sum(axis=1), 1.0, atol=1e-12)
+    assert (a >= -1e-12).all() and (np.count_nonzero(a, axis=1) <= 4).all()
+    field = 2.0 * lat.ravel() - 0.5 * lon.ravel() + 3.0                                   # unwrapped longitudes
+    want = 2.0 * tp.ravel() - 0.5 * tl.ravel() + 3.0
+    np.testing.assert_allclose(a @ field, want, atol=1e-9)
+    # links in CDO order
+    d, s = w["dst_address"].values, w["src_address"].values
+    assert (np.diff(d) >= 0).all() and (np.diff(s)[np.diff(d) == 0] > 0).all()
+
+
+def test_masked_corners_are_dropped_and_points_outside_take_the_nearest_unmasked_centre():
+    lon, lat = sheared_grid()
+    cur = curvilinear(lon, lat)
+    mask = np.ones(lon.shape, dtype=np.int32)
+    mask[10:20, 15:30] = 0                                                               # an island
+    tl, tp = np.meshgrid(np.arange(140.0, 250.0, 2.0), np.arange(-40.0, 40.0, 2.0))      # reaches beyond the region
+    dst = Grid("points", tl.ravel() % 360.0, tp.ravel(), name="targets", cdo_type="unstructured")
+    w = gridgen.generate_weights(cur, dst, method="bil", src_mask=mask.ravel())
+    assert (mask.ravel()[w["src_address"].values - 1] == 1).all()
+    a = dense(w)
+    np.testing.assert_allclose(a.sum(axis=1), 1.0, atol=1e-12)                             # every target point is mapped
+    free = gridgen.generate_weights(cur, dst, method="bil")
+    untouched = (dense(free)[:, mask.ravel() == 0] == 0).all(axis=1)
+    np.testing.assert_allclose(a[untouched], dense(free)[untouched], atol=1e-12)
+    far = (tl.ravel() < 145.0) | (tp.ravel() > 36.0)
+    assert ((a[far] == 1.0).sum(axis=1) == 1).all()
+    with pytest.raises(ValueError, match="cells"):
+        gridgen.generate_weights(cur, dst, method="bil", src_mask=np.ones(7))
+
+
+def test_conservative_from_the_corner_arrays_of_a_curvilinear_grid():
+    """Cells given by their four corners (bounds (y, x, 4) of a CMOR ocean file): the polygon generator."""
+    reg = gridgen.parse_grid("r40x20")
+    lon2d, lat2d = np.meshgrid(reg.lon, reg.lat)
+    w0, s0 = np.meshgrid(reg.lon_b[:-1], reg.lat_b[:-1])
+    e0, n0 = np.meshgrid(reg.lon_b[1:], reg.lat_b[1:])
+    cur = curvilinear(lon2d, lat2d, corners=(np.stack([w0, e0, e0, w0], -1), np.stack([s0, s0, n0, n0], -1)))
+    w = gridgen.generate_weights(cur, "r20x10", method="con")
+    exact = gridgen.generate_weights(reg, "r20x10", method="con")
+    band = np.repeat(np.abs(gridgen.parse_grid("r20x10").lat) < 40, 20)           # parallels ~ great circles there
+    assert np.abs(dense(w)[band] - dense(exact)[band]).max() < 0.03
+    np.testing.assert_allclose(w["dst_grid_frac"].values[band], 1.0, atol=1e-12)
+    assert w["src_grid_dims"].values.tolist() == [40, 20]
+
+
+def rotated_pole_grid(nx=72, ny=36, pole_lon=100.0, pole_lat=62.0, overlap=2):
+    """A global grid whose pole sits over land (as the ORCA grids' do), with `overlap` repeated columns at the eastern
+    end (ORCA's cyclic overlap): centres (ny, nx + overlap) and corners (ny, nx + overlap, 4), counter-clockwise."""
+    def rotate(rlon, rlat):
+        lam, phi = np.radians(rlon), np.radians(rlat)
+        v = np.stack([np.cos(phi) * np.cos(lam), np.cos(phi) * np.sin(lam), np.sin(phi)], axis=-1)
+        t = np.radians(90.0 - pole_lat)
+        ry = np.array([[np.cos(t), 0, np.sin(t)], [0, 1, 0], [-np.sin(t), 0, np.cos(t)]])
+        p = np.radians(pole_lon)
+        rz = np.array([[np.cos(p), -np.sin(p), 0], [np.sin(p), np.cos(p), 0], [0, 0, 1]])
+        w = v @ (rz @ ry).T
+        return np.degrees(np.arctan2(w[..., 1], w[..., 0])) % 360.0, np.degrees(np.arcsin(np.clip(w[..., 2], -1, 1)))
+    dx, dy = 360.0 / nx, 180.0 / ny
+    i = np.arange(nx + overlap) % nx
+    rl, rp = np.meshgrid(i * dx, -90.0 + dy * (np.arange(ny) + 0.5))
+    lon, lat = rotate(rl, rp)
+    cx = np.stack([rl - dx / 2, rl + dx / 2, rl + dx / 2, rl - dx / 2], -1)
+    cy = np.stack([rp - dy / 2, rp - dy / 2, rp + dy / 2, rp + dy / 2], -1)
+    clon, clat = rotate(cx, cy)
+    return lon, lat, clon, clat
+
+
+def sphere_field(lon, lat):
+    lam, phi = np.radians(lon), np.radians(lat)
+    return 10.0 + 4.0 * np.cos(phi) * np.cos(lam - 0.7) + 3.0 * np.sin(phi) + 2.0 * np.cos(phi) ** 2 * np.sin(2 * lam)
+
+
+@pytest.mark.parametrize("method", ["bil", "con", "nn"])
+def test_a_global_grid_with_displaced_pole_and_overlap_columns(method):
+    """identity2d_test.py:75-79's three methods on an ORCA-like layout: every target cell is mapped, a smooth field on
+    the sphere comes back within the truncation error of the method, duplicated columns do no harm."""
+    lon, lat, clon, clat = rotated_pole_grid()
+    cur = curvilinear(lon, lat, corners=(clon, clat))
+    w = gridgen.generate_weights(cur, "r60x30", method=method)
+    assert w["src_grid_dims"].values.tolist() == [74, 36] and w.sizes["dst_grid_size"] == 1800
+    a = dense(w)
+    np.testing.assert_allclose(a.sum(axis=1), 1.0, atol=1e-9)
+    if method == "con":
+        np.testing.assert_allclose(w["dst_grid_frac"].values, 1.0, atol=1e-9)      # the cells tile the sphere
+    dst = gridgen.parse_grid("r60x30")
+    tl, tp = dst.centers()
+    err = np.abs(a @ sphere_field(lon.ravel(), lat.ravel()) - sphere_field(tl, tp))
+    limit = {"bil": (0.08, 0.02), "con": (0.6, 0.15), "nn": (0.8, 0.3)}[method]    # cells of 5 degrees, field slope ~ 0.1 / degree
+    assert err.max() < limit[0] and err.mean() < limit[1]
