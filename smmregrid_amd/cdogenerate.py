@@ -329,7 +329,7 @@ class CdoGenerate:
     def areas(self, target=False):
         """Cell areas in m^2 (cdogenerate.py:345-400): `cdo gridarea` when the binary exists (the source
         grid with cdo_extra / cdo_options, the target grid without, as the reference does), else computed
-        here for regular and HEALPix grids."""
+        here for regular and HEALPix grids and for cells that come with their vertices."""
         if target and self.target_grid is None:
             raise TypeError('Target grid is not specified, cannot provide any area')
         if self.have_cdo:
@@ -342,7 +342,14 @@ class CdoGenerate:
             if getattr(grid, "cdo_type", "") == "healpix":     # equal-area pixels
                 n = grid.lon.size
                 return Dataset({"cell_area": (("cell",), np.full(n, 4.0 * np.pi * r * r / n), {"units": "m2"})})
-            raise NotImplementedError("areas need a regular or HEALPix grid without `cdo`")
+            if grid.vertices is not None:                      # mesh / curvilinear cells: great-circle polygons
+                area = gridgen.polygon_areas(*grid.vertices) * r * r
+                if grid.shape2d is not None:
+                    nx, ny = grid.shape2d
+                    return Dataset({"cell_area": (("y", "x"), area.reshape(ny, nx), {"units": "m2"})})
+                return Dataset({"cell_area": (("cell",), area, {"units": "m2"})})
+            raise NotImplementedError("areas need a regular or HEALPix grid, or cells with their vertices (bounds "
+                                      "variables in the Dataset), without `cdo`")
         area = (np.diff(np.sin(np.radians(grid.lat_b)))[:, None] *
                 np.radians(np.diff(grid.lon_b))[None, :]) * r * r
         return Dataset({"cell_area": (("lat", "lon"), area, {"units": "m2"})},

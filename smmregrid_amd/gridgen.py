@@ -904,6 +904,20 @@ def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", sampl
                           dst_area=dst_area, norm=norm)
 
 
+def polygon_areas(lon_v, lat_v):
+    """Areas on the unit sphere of cells given by their vertices (cells, V) in degrees, great-circle edges: the signed
+    spherical excesses of the triangles (vertex 0, vertex k, vertex k + 1), tan(E / 2) = a . (b x c) / (1 + a.b + b.c
+    + c.a).  Vertices repeated to pad a short polygon add triangles of no area; either orientation."""
+    lon_v, lat_v = np.asarray(lon_v, dtype=np.float64), np.asarray(lat_v, dtype=np.float64)
+    n, V = lon_v.shape
+    v = _unit_vectors(lon_v.ravel(), lat_v.ravel()).reshape(n, V, 3)
+    a, b, c = v[:, :1], v[:, 1:-1], v[:, 2:]
+    triple = np.einsum("nvk,nvk->nv", np.broadcast_to(a, b.shape), np.cross(b, c))
+    denom = 1.0 + np.einsum("nvk,nvk->nv", np.broadcast_to(a, b.shape), b) + np.einsum("nvk,nvk->nv", b, c) + \
+        np.einsum("nvk,nvk->nv", c, np.broadcast_to(a, c.shape))
+    return np.abs(2.0 * np.arctan2(triple, denom).sum(axis=1))
+
+
 def _polygon_overlap_areas(src, dst, m, chunk=200000, neighbours=8):
     """(dst cell, src cell, overlap area on the unit sphere) of every pair of a polygon-cell source grid and a regular
     target grid that shares sub-cell centres: see polygon_conservative_weights.  Kept on the source grid per target,

@@ -73,6 +73,9 @@ def open_weights(path):
         return ds
     with open(path, "rb") as f:
         magic = f.read(4)
+    if magic == b"GRIB":
+        from .griblite import open_grib      # GRIB edition 1 (the reference reads these through cfgrib)
+        return open_grib(path)
     if magic[:3] == b"CDF":
         from scipy.io import netcdf_file
         with netcdf_file(path, "r", mmap=False) as nc:

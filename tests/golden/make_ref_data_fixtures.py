@@ -45,3 +45,6 @@ with h5py.File("/root/reference/tests/data/temp3d-fesom.nc", "r") as f:
                         nz1=f["nz1"][:][lev].astype(np.float64),
                         lon=f["lon"][:].astype(np.float64), lat=f["lat"][:].astype(np.float64),
                         lon_bnds=f["lon_bnds"][...].astype(np.float32), lat_bnds=f["lat_bnds"][...].astype(np.float32))
+# tests/data/lsm-ifs.grb (identity2d_test.py:22-27): the one GRIB file of the reference's tests, a data file, copied as it is
+import shutil
+shutil.copy("/root/reference/tests/data/lsm-ifs.grb", os.path.join(HERE, "grib", "lsm-ifs.grb"))

@@ -197,3 +197,45 @@ def test_the_cell_polygons_of_a_file_reach_the_generator(tmp_path):
     assert bare.vertices is None
     with pytest.raises((ValueError, NotImplementedError)):
         gridgen.generate_weights(bare, "r36x18", method="con")
+
+
+def test_cell_areas_of_polygon_grids():
+    """areas_test.py:17-33 asks `CdoGenerate(file).areas()` for unstructured and curvilinear files: spherical polygon
+    areas from the vertices (CDO's gridarea does the same for such grids)."""
+    from smmregrid_amd import CdoGenerate, DataArray, Dataset
+    src, areas = voronoi_mesh(200, seed=9, pad_to=15)
+    got = gridgen.polygon_areas(*src.vertices)
+    np.testing.assert_allclose(got, areas, rtol=1e-9)
+    np.testing.assert_allclose(got.sum(), 4 * np.pi, rtol=1e-12)
+    np.testing.assert_allclose(gridgen.polygon_areas(src.vertices[0][:, ::-1], src.vertices[1][:, ::-1]), areas, rtol=1e-9)
+    # the reference's coarse FESOM mesh: an ocean (areas_test.py's OCEAN_SURFACE, for the finer tos-fesom.nc, is
+    # 3.6e8 km2 +- 2 % of the Earth's surface; this mesh's coasts are coarser)
+    fes, z = fesom_grid()
+    lon = DataArray(z["lon"], dims=("nod2",), attrs={"units": "degrees_east", "bounds": "lon_bnds"})
+    lat = DataArray(z["lat"], dims=("nod2",), attrs={"units": "degrees_north", "bounds": "lat_bnds"})
+    ds = Dataset({"temp": DataArray(z["temp"][0], dims=("nod2",), coords={"lon": lon, "lat": lat}, name="temp"),
+                  "lon_bnds": DataArray(z["lon_bnds"].astype(np.float64), dims=("nod2", "nv")),
+                  "lat_bnds": DataArray(z["lat_bnds"].astype(np.float64), dims=("nod2", "nv"))})
+    gen = CdoGenerate(ds, "r360x180", cdo="no-such-cdo-binary")
+    a = gen.areas()
+    assert a["cell_area"].shape == (3140,) and a["cell_area"].attrs["units"] == "m2"
+    assert a["cell_area"].values.sum() / 1e6 == pytest.approx(3.5e8, abs=0.03 * 5.101e8)
+    # ... and it is the area the conservative weights hand to the target grid (sampling error apart)
+    w = gridgen.generate_weights(fes, "r360x180", method="con")
+    covered = (w["dst_grid_frac"].values * w["dst_grid_area"].values).sum() * 6371000.0 ** 2
+    assert covered == pytest.approx(a["cell_area"].values.sum(), rel=2e-3)
+    # curvilinear cells keep their 2-D shape
+    from tests.test_gridgen_curvilinear import rotated_pole_grid
+    lon2, lat2, clon, clat = rotated_pole_grid(overlap=0)
+    nav_lon = DataArray(lon2, dims=("y", "x"), attrs={"bounds": "bounds_nav_lon"})
+    nav_lat = DataArray(lat2, dims=("y", "x"), attrs={"bounds": "bounds_nav_lat"})
+    ds2 = Dataset({"tos": DataArray(np.zeros(lon2.shape), dims=("y", "x"), coords={"nav_lon": nav_lon, "nav_lat": nav_lat},
+                                    name="tos"),
+                   "bounds_nav_lon": DataArray(clon, dims=("y", "x", "nvertex")),
+                   "bounds_nav_lat": DataArray(clat, dims=("y", "x", "nvertex"))})
+    a2 = CdoGenerate(ds2, "r360x180", cdo="no-such-cdo-binary").areas()
+    assert a2["cell_area"].shape == lon2.shape
+    assert a2["cell_area"].values.sum() / 1e6 == pytest.approx(5.101e8, rel=5e-3)   # rotated parallels vs great circles
+    bare = CdoGenerate(ds["temp"], "r360x180", cdo="no-such-cdo-binary")
+    with pytest.raises(NotImplementedError):
+        bare.areas()
