@@ -215,6 +215,8 @@ _HP_GRID = re.compile(r"^hp(\d+)(_nested|_ring)?$")
 _HPZ_GRID = re.compile(r"^hpz(\d+)$")
 _GAUSS_GRID = re.compile(r"^[Fn](\d+)$")
 _GLOBAL_GRID = re.compile(r"^global_(\d+(?:\.\d+)?)$")
+_ZONAL_GRID = re.compile(r"^zonal_(\d+(?:\.\d+)?)$")
+_POINT_GRID = re.compile(r"^lon=(-?\d+(?:\.\d+)?)/lat=(-?\d+(?:\.\d+)?)$")
 
 
 def parse_grid(spec):
@@ -247,7 +249,19 @@ def parse_grid(spec):
         lon = -180.0 + res * (np.arange(nx) + 0.5)          # CDO global_<res>: cell-centred from -180
         lat = -90.0 + res * (np.arange(ny) + 0.5)
         return regular_grid_from_centers(lon, lat, name=spec)
-    raise ValueError(f"grid '{spec}' is not supported by the native weight generator")
+    m = _ZONAL_GRID.match(spec)
+    if m:                                                   # CDO zonal_<dy>: one cell around the globe per latitude band
+        res = float(m.group(1))
+        ny = int(round(180.0 / res))
+        return regular_grid_from_centers(np.array([0.0]), -90.0 + res * (np.arange(ny) + 0.5), name=spec,
+                                         lon_b=np.array([-180.0, 180.0]))
+    m = _POINT_GRID.match(spec)
+    if m:                                                   # CDO lon=<x>/lat=<y>: one grid point (no cell: nn / bil / dis)
+        return Grid("points", np.array([float(m.group(1)) % 360.0]), np.array([float(m.group(2))]), name=spec,
+                    cdo_type="lonlat")
+    raise ValueError(f"grid '{spec}' is not supported by the native weight generator (r<NX>x<NY>, global_<res>, "
+                     "zonal_<res>, lon=<x>/lat=<y>, F<N> / n<N>, hp<N>[_nested|_ring], hpz<zoom>; dcw: regions "
+                     "and gme grids need the cdo binary)")
 
 
 # --------------------------------------------------------------------------- weights

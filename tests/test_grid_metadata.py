@@ -169,3 +169,30 @@ def test_nosource_areas_target():
     area = CdoGenerate(source_grid=None, target_grid="r180x91", loglevel="debug").areas(target=True)
     assert area["cell_area"].shape == (91, 180)
     assert area["cell_area"].values.sum() / 1e6 == pytest.approx(EARTH_SURFACE, abs=TOLERANCE)
+
+
+def test_cdo_grid_names_the_native_generator_knows():
+    """cdogrid.py:11-22 lists the CDO grid strings; without `cdo` the native generator builds the grids it can
+    (r, global_, zonal_, one point, F / n Gaussian, hp, hpz) and names the ones it cannot (dcw: regions, gme)."""
+    import numpy as np
+    from smmregrid_amd import gridgen
+    z = gridgen.parse_grid("zonal_2.5")
+    assert z.kind == "regular" and list(z.dims) == [1, 72] and z.lat[0] == -88.75 and list(z.lon_b) == [-180.0, 180.0]
+    w = gridgen.generate_weights("r72x36", "zonal_2.5", method="con")
+    a = np.zeros((72, 72 * 36))
+    np.add.at(a, (w["dst_address"].values - 1, w["src_address"].values - 1), w["remap_matrix"].values[:, 0])
+    np.testing.assert_allclose(a.sum(axis=1), 1.0, atol=1e-12)
+    lat = np.repeat(gridgen.parse_grid("r72x36").lat, 72)
+    assert np.abs(a @ np.cos(np.radians(lat)) - np.cos(np.radians(z.lat))).max() < 0.025  # zonal means (5-degree source rows)
+    p = gridgen.parse_grid("lon=-75.0/lat=40.0")
+    assert p.kind == "points" and p.size == 1 and p.lon[0] == 285.0 and p.lat[0] == 40.0
+    w = gridgen.generate_weights("r72x36", "lon=-75.0/lat=40.0", method="bil")
+    assert w.sizes["dst_grid_size"] == 1 and w["remap_matrix"].values[:, 0].sum() == pytest.approx(1.0)
+    assert gridgen.generate_weights("r72x36", "lon=-75.0/lat=40.0", method="nn").sizes["num_links"] == 1
+    with pytest.raises(ValueError, match="cells"):
+        gridgen.generate_weights("r72x36", "lon=-75.0/lat=40.0", method="con")
+    assert gridgen.parse_grid("F128").size == 512 * 256 == gridgen.parse_grid("n128").size      # basic_test.py:82
+    assert gridgen.parse_grid("global_2.5").size == 144 * 72 and gridgen.parse_grid("hpz3").size == 12 * 64
+    for name in ("dcw:US", "gme10", "random_string"):
+        with pytest.raises(ValueError, match="cdo binary"):
+            gridgen.parse_grid(name)
