@@ -48,3 +48,9 @@ with h5py.File("/root/reference/tests/data/temp3d-fesom.nc", "r") as f:
 # tests/data/lsm-ifs.grb (identity2d_test.py:22-27): the one GRIB file of the reference's tests, a data file, copied as it is
 import shutil
 shutil.copy("/root/reference/tests/data/lsm-ifs.grb", os.path.join(HERE, "grib", "lsm-ifs.grb"))
+with h5py.File("/root/reference/tests/data/tas-ecearth.nc", "r") as f:
+    # tests/data/tas-ecearth.nc (identity2d_test.py:30-53): EC-Earth near-surface temperature on the regular Gaussian
+    # grid N128 (256 x 512) with lat_bnds / lon_bnds; two of the twelve months + the grid as the file holds it
+    np.savez_compressed(os.path.join(HERE, "tas_ecearth.npz"), tas=f["tas"][:2].astype(np.float32),
+                        lat=f["lat"][:].astype(np.float64), lon=f["lon"][:].astype(np.float64),
+                        lat_bnds=f["lat_bnds"][...].astype(np.float64), lon_bnds=f["lon_bnds"][...].astype(np.float64))

@@ -788,3 +788,63 @@ def test_reduced_gaussian_grib_file_nearest_neighbour(hip):
     assert np.isin(y, ds["lsm"].values.astype(np.float64)).all() and (y[:8] > 0.999).all()     # Antarctica
     area = np.diff(np.sin(np.radians(np.linspace(-90, 90, 181))))[:, None] / 2 / 360
     assert (y * area).sum() == pytest.approx(0.29, abs=0.01)                                  # land share of the globe
+
+
+def ecearth_dataset():
+    """tests/golden/tas_ecearth.npz (two months of the reference's tests/data/tas-ecearth.nc) as the file lays it out:
+    tas(time, lat, lon) on the Gaussian grid N128 with lat_bnds / lon_bnds named by the coordinates."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "tas_ecearth.npz"))
+    coords = {"time": np.arange(2),
+              "lat": DataArray(z["lat"], dims=("lat",), attrs={"units": "degrees_north", "bounds": "lat_bnds"}),
+              "lon": DataArray(z["lon"], dims=("lon",), attrs={"units": "degrees_east", "bounds": "lon_bnds"})}
+    ds = Dataset({"tas": DataArray(z["tas"], dims=("time", "lat", "lon"), coords=coords, name="tas", attrs={"units": "K"})})
+    ds["lat_bnds"] = (("lat", "bnds"), z["lat_bnds"])
+    ds["lon_bnds"] = (("lon", "bnds"), z["lon_bnds"])
+    return ds, z
+
+
+@pytest.mark.parametrize("method,area_min", [("con", 0.5), ("nn", 0.5), ("con", 0.0), ("con", 0.75)])
+def test_gaussian_regular_data_of_the_reference(hip, method, area_min):
+    """identity2d_test.py:30-45 (`con` / `nn`, remap_area_min 0.0 / 0.5 / 0.75) on the reference's own EC-Earth field:
+    the Gaussian cell edges come from the file's bounds; with no missing values the area cut changes nothing."""
+    ds, z = ecearth_dataset()
+    tfile = os.path.join(os.path.dirname(__file__), "golden", "refdata", "r360x180.nc")
+    rg = Regridder(source_grid=ds, target_grid=tfile, method=method, remap_area_min=area_min)
+    out = rg.regrid(ds)
+    assert out["tas"].shape == (2, 180, 360) and "lat_bnds" not in out.data_vars
+    w = rg.grids[0].weights
+    assert list(w["src_grid_dims"].values) == [512, 256]
+    x = z["tas"].astype(np.float64).reshape(2, -1)
+    assert_same(out["tas"].values.reshape(2, -1), oracle_2d(w, x, area_min=area_min), exact=True)
+    y = out["tas"].values
+    assert np.isfinite(y).all() and x.min() - 1e-9 <= y.min() and y.max() <= x.max() + 1e-9
+    if method == "con":
+        src_area = np.diff(np.sin(np.radians(np.r_[z["lat_bnds"][:, 0], z["lat_bnds"][-1, 1]])))
+        dst_area = np.diff(np.sin(np.radians(np.linspace(-90, 90, 181))))
+        for t in range(2):
+            mean_src = (z["tas"][t].astype(np.float64).mean(axis=1) * src_area).sum() / src_area.sum()
+            mean_dst = (y[t].mean(axis=1) * dst_area).sum() / dst_area.sum()
+            assert abs(mean_dst - mean_src) < 1e-9 * mean_src * 1e3            # the global mean is conserved (1e-6 K)
+
+
+@pytest.mark.parametrize("method", ["bil", "con"])
+def test_gaussian_regular_to_the_regional_grid_of_the_reference(hip, method):
+    """identity2d_test.py:50-54: the same field to tests/data/regional.nc."""
+    from smmregrid_amd.io import open_dataset
+    ds, z = ecearth_dataset()
+    rfile = os.path.join(os.path.dirname(__file__), "golden", "refdata", "regional.nc")
+    reg = open_dataset(rfile)
+    rg = Regridder(source_grid=ds, target_grid=rfile, method=method)
+    out = rg.regrid(ds)
+    ny, nx = reg.coords["lat"].values.size, reg.coords["lon"].values.size
+    assert out["tas"].shape == (2, ny, nx)
+    np.testing.assert_allclose(out.coords["lat"].values, reg.coords["lat"].values, atol=1e-9)
+    np.testing.assert_allclose(out.coords["lon"].values % 360.0, reg.coords["lon"].values % 360.0, atol=1e-9)
+    w = rg.grids[0].weights
+    x = z["tas"].astype(np.float64).reshape(2, -1)
+    assert_same(out["tas"].values.reshape(2, -1), oracle_2d(w, x), exact=True)
+    # against a direct sample of the source field at the regional cell centres: smooth field, 0.7-degree source
+    jj = np.abs(z["lat"][None, :] - reg.coords["lat"].values[:, None]).argmin(axis=1)
+    ii = np.abs(((z["lon"][None, :] - reg.coords["lon"].values[:, None] + 180) % 360) - 180).argmin(axis=1)
+    near = z["tas"][0][jj][:, ii].astype(np.float64)
+    assert np.abs(out["tas"].values[0] - near).mean() < 1.0
