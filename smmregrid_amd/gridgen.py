@@ -932,93 +932,185 @@ def polygon_areas(lon_v, lat_v):
     return np.abs(2.0 * np.arctan2(triple, denom).sum(axis=1))
 
 
-def _polygon_overlap_areas(src, dst, m, chunk=200000, neighbours=8):
-    """(dst cell, src cell, overlap area on the unit sphere) of every pair of a polygon-cell source grid and a regular
-    target grid that shares sub-cell centres: see polygon_conservative_weights.  Kept on the source grid per target,
-    so the levels of a 3-D field (same cells, another mask) pay for the geometry once."""
-    from scipy.spatial import cKDTree
-    cache = src.__dict__.setdefault("_overlap_cache", {})
-    key = (dst.lon_b.tobytes(), dst.lat_b.tobytes(), m)
-    if key in cache:
-        return cache[key]
-    lon_v, lat_v = (np.asarray(a, dtype=np.float64) for a in src.vertices)
-    n, V = lon_v.shape
-    if n != src.size:
-        raise ValueError("cell vertices do not match the number of cells")
-    mx = dst.lon.size
-    slon, slat = src.centers()
-    centre = _unit_vectors(slon, slat)                                        # (n, 3)
-    tree = cKDTree(centre)
-    k = int(min(neighbours, n))
-    # tangent basis of every source cell and its vertices in that plane (gnomonic: great circles are straight lines)
-    east = np.stack([-np.sin(np.radians(slon)), np.cos(np.radians(slon)), np.zeros(n)], axis=1)
-    north = np.cross(centre, east)
-    vert = _unit_vectors(lon_v.ravel(), lat_v.ravel()).reshape(n, V, 3)
-    dotc = np.einsum("nvk,nk->nv", vert, centre)
-    usable = (dotc > 1e-6).all(axis=1)                                        # a vertex beyond the horizon: not a cell
-    dotc = np.where(dotc > 1e-6, dotc, 1.0)
-    vx = np.einsum("nvk,nk->nv", vert, east) / dotc
-    vy = np.einsum("nvk,nk->nv", vert, north) / dotc
-    vx2, vy2 = np.roll(vx, -1, axis=1), np.roll(vy, -1, axis=1)
-    # equal-area sub-cell centres of the target grid, (ny * m) x (nx * m)
-    fr = (np.arange(m) + 0.5) / m
-    sub_lon = (dst.lon_b[:-1, None] + np.diff(dst.lon_b)[:, None] * fr[None, :]).ravel()
-    sb = np.sin(dst.lat_b * DEG)
-    sub_lat = np.degrees(np.arcsin(np.clip((sb[:-1, None] + np.diff(sb)[:, None] * fr[None, :]).ravel(), -1.0, 1.0)))
-    n_sub = sub_lon.size * sub_lat.size
-    keys, counts = [], []
-    for lo in range(0, n_sub, chunk):
-        idx = np.arange(lo, min(n_sub, lo + chunk), dtype=np.int64)
-        jj, ii = idx // sub_lon.size, idx % sub_lon.size
-        p = _unit_vectors(sub_lon[ii], sub_lat[jj])                           # (P, 3)
-        cell_d = (jj // m) * mx + (ii // m)
-        _, cand = tree.query(p, k=k)
-        cand = cand.reshape(-1, k)
-        owner = np.full(idx.size, -1, dtype=np.int64)
-        todo = np.arange(idx.size)
-        for c in range(k):               # nearest centre first: most sub-cells lie in that cell, few reach the later ones
+class _PolygonLocator:
+    """Which cell of a polygon grid (cell vertices (cells, V) in degrees, great-circle edges) holds a direction?
+    Candidates are the cells with the nearest centres (KD-tree on unit vectors), tested nearest first in the
+    candidate's own gnomonic plane, where great circles are straight lines (crossing-number test)."""
+
+    def __init__(self, grid, neighbours=8):
+        from scipy.spatial import cKDTree
+        lon_v, lat_v = (np.asarray(a, dtype=np.float64) for a in grid.vertices)
+        n, V = lon_v.shape
+        if n != grid.size:
+            raise ValueError("cell vertices do not match the number of cells")
+        clon, clat = grid.centers()
+        self.n = n
+        self.centre = _unit_vectors(clon, clat)
+        self.tree = cKDTree(self.centre)
+        self.k = int(min(neighbours, n))
+        self.east = np.stack([-np.sin(np.radians(clon)), np.cos(np.radians(clon)), np.zeros(n)], axis=1)
+        self.north = np.cross(self.centre, self.east)
+        vert = _unit_vectors(lon_v.ravel(), lat_v.ravel()).reshape(n, V, 3)
+        dotc = np.einsum("nvk,nk->nv", vert, self.centre)
+        self.usable = (dotc > 1e-6).all(axis=1)                               # a vertex beyond the horizon: not a cell
+        dotc = np.where(dotc > 1e-6, dotc, 1.0)
+        self.vx = np.einsum("nvk,nk->nv", vert, self.east) / dotc
+        self.vy = np.einsum("nvk,nk->nv", vert, self.north) / dotc
+        self.vx2, self.vy2 = np.roll(self.vx, -1, axis=1), np.roll(self.vy, -1, axis=1)
+
+    def locate(self, p):
+        """Cell index per unit vector of `p` (P, 3); -1 where no candidate cell holds it."""
+        _, cand = self.tree.query(p, k=self.k)
+        cand = cand.reshape(-1, self.k)
+        owner = np.full(p.shape[0], -1, dtype=np.int64)
+        todo = np.arange(p.shape[0])
+        for c in range(self.k):               # nearest centre first: most points lie in that cell, few reach the later ones
             if todo.size == 0:
                 break
             cc = cand[todo, c]
             q = p[todo]
-            dp = np.einsum("pk,pk->p", q, centre[cc])
-            ok = (dp > 1e-6) & usable[cc]
+            dp = np.einsum("pk,pk->p", q, self.centre[cc])
+            ok = (dp > 1e-6) & self.usable[cc]
             dp = np.where(ok, dp, 1.0)
-            px = (np.einsum("pk,pk->p", q, east[cc]) / dp)[:, None]
-            py = (np.einsum("pk,pk->p", q, north[cc]) / dp)[:, None]
-            x1, y1, x2, y2 = vx[cc], vy[cc], vx2[cc], vy2[cc]
+            px = (np.einsum("pk,pk->p", q, self.east[cc]) / dp)[:, None]
+            py = (np.einsum("pk,pk->p", q, self.north[cc]) / dp)[:, None]
+            x1, y1, x2, y2 = self.vx[cc], self.vy[cc], self.vx2[cc], self.vy2[cc]
             with np.errstate(invalid="ignore", divide="ignore"):
                 cross = ((y1 > py) != (y2 > py)) & (px < (x2 - x1) * (py - y1) / (y2 - y1) + x1)
             inside = ok & (np.sum(cross, axis=1) % 2 == 1)
             owner[todo[inside]] = cc[inside]
             todo = todo[~inside]
-        hit = owner >= 0
-        uk, uc = np.unique(cell_d[hit] * n + owner[hit], return_counts=True)
+        return owner
+
+
+def _regular_cell_areas(grid):
+    return (np.diff(np.sin(grid.lat_b * DEG))[:, None] * (np.diff(grid.lon_b) * DEG)[None, :]).ravel()
+
+
+def _grid_cell_areas(grid):
+    """Cell areas on the unit sphere of any grid that has cells."""
+    if grid.kind == "regular":
+        return _regular_cell_areas(grid)
+    if grid.vertices is not None:
+        return polygon_areas(*grid.vertices)
+    if grid.cdo_type == "healpix" and grid.nside:
+        return np.full(grid.size, 4.0 * np.pi / grid.size)
+    raise ValueError("the grid has no cells (a list of centres)")
+
+
+def _typical_cell_degrees(grid):
+    if grid.kind == "regular":
+        return min(float(np.min(np.diff(grid.lon_b))), float(np.min(np.diff(grid.lat_b))))
+    return float(np.degrees(np.sqrt(np.median(_grid_cell_areas(grid)))))
+
+
+def _sample_lattice(grid, m, chunk):
+    """Equal-area sample points carried by the cells of a regular or HEALPix grid: yields (unit vectors, owning cell,
+    area of one sample) in chunks.  Regular: m x m sub-cells per cell, uniform in longitude and in sin latitude;
+    HEALPix: the 4^k pixels of the nested subdivision with 4^k >= m^2 (the parent pixel is their exact union)."""
+    if grid.kind == "regular":
+        mx = grid.lon.size
+        fr = (np.arange(m) + 0.5) / m
+        sub_lon = (grid.lon_b[:-1, None] + np.diff(grid.lon_b)[:, None] * fr[None, :]).ravel()
+        sb = np.sin(grid.lat_b * DEG)
+        sub_lat = np.degrees(np.arcsin(np.clip((sb[:-1, None] + np.diff(sb)[:, None] * fr[None, :]).ravel(), -1.0, 1.0)))
+        area = _regular_cell_areas(grid) / (m * m)
+        n_sub = sub_lon.size * sub_lat.size
+        for lo in range(0, n_sub, chunk):
+            idx = np.arange(lo, min(n_sub, lo + chunk), dtype=np.int64)
+            jj, ii = idx // sub_lon.size, idx % sub_lon.size
+            cell = (jj // m) * mx + (ii // m)
+            yield _unit_vectors(sub_lon[ii], sub_lat[jj]), cell, area[cell]
+        return
+    k = max(0, int(np.ceil(np.log2(max(m, 1)))))
+    fine = grid.nside << k
+    to_file_order = None
+    if not grid.nested:                                   # the field is stored in ring order
+        nlon, nlat = healpix_centers(grid.nside, nested=True)
+        to_file_order = healpix_ring_index(grid.nside, nlon, nlat)
+    area = 4.0 * np.pi / (12.0 * fine * fine)
+    for lo in range(0, 12 * fine * fine, chunk):
+        hi = min(12 * fine * fine, lo + chunk)
+        flon, flat = _healpix_centers_range(fine, lo, hi)
+        parent = np.arange(lo, hi, dtype=np.int64) >> (2 * k)
+        if to_file_order is not None:
+            parent = to_file_order[parent]
+        yield _unit_vectors(flon, flat), parent, np.full(hi - lo, area)
+
+
+def _polygon_overlap_areas(src, dst, m, chunk=200000):
+    """(dst cell, src cell, overlap area on the unit sphere) of every pair of cells of two grids of which at least one
+    is a grid of POLYGONS: see polygon_conservative_weights.  Kept on the source grid per target, so the levels of a
+    3-D field (same cells, another mask) pay for the geometry once."""
+    cache = src.__dict__.setdefault("_overlap_cache", {})
+    key = (dst.kind, dst.size, dst.lon.tobytes()[:4096], dst.lat.tobytes()[:4096],
+           None if dst.kind != "regular" else (dst.lon_b.tobytes(), dst.lat_b.tobytes()), m)
+    if key in cache:
+        return cache[key]
+    has_lattice = lambda g: g.kind == "regular" or (g.cdo_type == "healpix" and g.nside is not None)   # noqa: E731
+    if has_lattice(dst):                       # samples carried by the target cells, looked up in the source polygons
+        carrier, other, carrier_is_dst = dst, _PolygonLocator(src), True
+    elif has_lattice(src):                     # ... or carried by the source cells, looked up in the target polygons
+        carrier, other, carrier_is_dst = src, _PolygonLocator(dst), False
+    else:                                      # polygons on both sides: a fine HEALPix lattice looked up in both
+        cell = min(_typical_cell_degrees(src), _typical_cell_degrees(dst))
+        # pixels half as wide as cell / m (a HEALPix pixel of nside n is 58.6 / n degrees across)
+        nside = int(np.clip(2 ** int(np.ceil(np.log2(max(58.6 * 2 * m / max(cell, 1e-6), 1.0)))), 8, 1024))
+        carrier = Grid("points", np.zeros(0), np.zeros(0), name=f"hp{nside}", cdo_type="healpix")
+        carrier.nside, carrier.nested = nside, True
+        carrier.lon = carrier.lat = np.zeros(12 * nside * nside)          # sizes only; the centres come in chunks
+        loc_s, loc_d = _PolygonLocator(src), _PolygonLocator(dst)
+    n_src = src.size
+    keys, sums = [], []
+    both = not (has_lattice(dst) or has_lattice(src))
+    # the area of a polygon target cell AS THE SAMPLES SEE IT (so that a fully covered cell has fraction 1 exactly);
+    # only when the samples reach everywhere -- a regional carrier leaves part of a target cell unsampled
+    whole_sphere = both or carrier.kind != "regular" or \
+        (abs(carrier.lon_b[-1] - carrier.lon_b[0] - 360.0) < 1e-6 and carrier.lat_b[0] <= -90.0 + 1e-6
+         and carrier.lat_b[-1] >= 90.0 - 1e-6)
+    seen = np.zeros(dst.size) if (dst.vertices is not None and whole_sphere) else None
+    for p, cell, area in _sample_lattice(carrier, 1 if both else m, chunk):
+        if both:
+            d_own, s_own = loc_d.locate(p), loc_s.locate(p)
+        elif carrier_is_dst:
+            d_own, s_own = cell, other.locate(p)
+        else:
+            d_own, s_own = other.locate(p), cell
+        if seen is not None:
+            seen += np.bincount(d_own[d_own >= 0], weights=area[d_own >= 0], minlength=dst.size)
+        hit = (d_own >= 0) & (s_own >= 0)
+        uk, inv = np.unique(d_own[hit] * n_src + s_own[hit], return_inverse=True)
         keys.append(uk)
-        counts.append(uc)
+        sums.append(np.bincount(inv, weights=area[hit], minlength=uk.size))
     key_all = np.concatenate(keys) if keys else np.zeros(0, np.int64)
-    cnt = np.concatenate(counts).astype(np.float64) if counts else np.zeros(0)
+    tot = np.concatenate(sums) if sums else np.zeros(0)
     uk, inv = np.unique(key_all, return_inverse=True)
-    cnt = np.bincount(inv, weights=cnt) if uk.size else cnt
-    dst_addr, src_addr = uk // n, uk % n
-    dst_area = (np.diff(sb)[:, None] * (np.diff(dst.lon_b) * DEG)[None, :]).ravel()
+    tot = np.bincount(inv, weights=tot) if uk.size else tot
     cache.clear()                                                             # one target at a time is enough
-    cache[key] = (dst_addr, src_addr, cnt / (m * m) * dst_area[dst_addr], dst_area)
+    cache[key] = (uk // n_src, uk % n_src, tot, _grid_cell_areas(dst), seen)
     return cache[key]
 
 
 def polygon_conservative_weights(src, dst, src_mask=None, norm="fracarea", samples=None):
-    """First-order conservative weights from a grid of POLYGON cells (unstructured meshes, curvilinear grids: the cell
-    vertices a file carries as lon_bnds / lat_bnds, edges taken as great circles as CDO does) to a regular lon/lat
-    grid.  Every target cell is cut into m x m equal-area sub-cells (uniform in longitude and in sin latitude); the
-    source cell holding a sub-cell's centre -- searched among the nearest cell centres, tested in the gnomonic plane of
-    the candidate, where great circles are straight lines -- gets 1 / m^2 of the target cell's area.  The overlap
-    areas are exact up to the sub-cells cut by a cell edge; `samples` = m (default: sub-cells a third of a source cell
-    wide, 3 <= m <= 10).  Target area no source cell covers (outside a regional mesh, land of an ocean mesh) counts
-    as uncovered: `dst_grid_frac` = unmasked covered share, as for lon/lat sources."""
+    """First-order conservative weights when at least one side is a grid of POLYGON cells (unstructured meshes,
+    curvilinear grids: the cell vertices a file carries as lon_bnds / lat_bnds, edges taken as great circles as CDO
+    does); the other side may be a regular lon/lat grid, a HEALPix grid or polygons again.
+
+    The overlap areas are counted on a lattice of equal-area sample points: the m x m sub-cells (uniform in longitude
+    and in sin latitude) of the regular side's cells, or the nested sub-pixels of the HEALPix side's pixels, or -- with
+    polygons on both sides -- the pixels of a fine HEALPix grid.  A sample belongs to the polygon that holds it, searched
+    among the nearest cell centres and tested in the candidate's gnomonic plane, where great circles are straight
+    lines.  Areas are exact up to the samples cut by a polygon edge; `samples` = m (default: samples a third of the
+    smaller cells wide, 3 <= m <= 10); a polygon target cell's area is counted on the same samples, so a fully covered
+    cell has fraction 1 exactly (`dst_grid_area` holds the exact polygon area).  Target area no source cell covers (outside a regional mesh, land of an ocean
+    mesh) counts as uncovered: `dst_grid_frac` = unmasked covered share, as for lon/lat sources."""
     src, dst = parse_grid(src), parse_grid(dst)
-    if src.vertices is None or dst.kind != "regular":
-        raise ValueError("polygon conservative weights need source cell vertices and a regular destination grid")
+    if src.vertices is None and dst.vertices is None:
+        raise ValueError("polygon conservative weights need cell vertices on at least one side")
+    for g, side in ((src, "source"), (dst, "destination")):
+        if g.vertices is None and g.kind != "regular" and not (g.cdo_type == "healpix" and g.nside):
+            raise ValueError(f"polygon conservative weights: the {side} grid has no cells (regular, HEALPix or cell "
+                             "vertices are needed)")
     n = src.size
     imask = None
     if src_mask is not None:
@@ -1026,21 +1118,24 @@ def polygon_conservative_weights(src, dst, src_mask=None, norm="fracarea", sampl
         if imask.size != n:
             raise ValueError(f"src_mask has {imask.size} cells, the source grid {n}")
     if samples is None:
-        src_deg = np.degrees(np.sqrt(4.0 * np.pi / max(n, 1)))               # typical cell width if the mesh were global
-        dst_deg = min(float(np.min(np.diff(dst.lon_b))), float(np.min(np.diff(dst.lat_b))))
-        m = int(np.clip(np.ceil(3.0 * dst_deg / max(src_deg, 1e-9)), 3, 10))
+        carrier, other = (dst, src) if dst.vertices is None else (src, dst)
+        ratio = _typical_cell_degrees(carrier) / max(_typical_cell_degrees(other), 1e-9) if carrier.vertices is None \
+            else 1.0
+        m = int(np.clip(np.ceil(3.0 * ratio), 3, 10))
     else:
         m = max(1, int(samples))
-    dst_addr, src_addr, area, dst_area = _polygon_overlap_areas(src, dst, m)
+    dst_addr, src_addr, area, dst_area, seen = _polygon_overlap_areas(src, dst, m)
     if imask is not None:
         keep = imask[src_addr] != 0
         dst_addr, src_addr, area = dst_addr[keep], src_addr[keep], area[keep]
     covered = np.bincount(dst_addr, weights=area, minlength=dst.size)
-    frac = covered / dst_area
+    counted = dst_area if seen is None else seen                    # the target cell's area in the overlaps' own measure
+    with np.errstate(invalid="ignore", divide="ignore"):
+        frac = np.where(counted > 0, covered / counted, 0.0)
     if norm == "fracarea":
         w = area / covered[dst_addr]
     elif norm == "destarea":
-        w = area / dst_area[dst_addr]
+        w = area / counted[dst_addr]
     else:
         raise ValueError("norm must be 'fracarea' or 'destarea'")
     src_addr, dst_addr, w = _sort_links(src_addr + 1, dst_addr + 1, w)
@@ -1223,7 +1318,7 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     if method in ("con", "ycon"):
         if src.cdo_type == "healpix" and dst.cdo_type == "healpix" and src.nside and dst.nside:
             ds = healpix_hierarchy_weights(src, dst, src_mask=src_mask, norm=norm)
-        elif src.vertices is not None and dst.kind == "regular":
+        elif src.vertices is not None or dst.vertices is not None:
             ds = polygon_conservative_weights(src, dst, src_mask=src_mask, norm=norm)
         elif "healpix" in (src.cdo_type, dst.cdo_type) and (src.kind == "regular" or dst.kind == "regular"):
             ds = sampled_conservative_weights(src, dst, src_mask=src_mask, norm=norm)

@@ -112,13 +112,73 @@ def test_masked_cells_drop_their_links_and_lower_the_covered_fraction():
         gridgen.generate_weights(src, "r36x18", method="con", src_mask=np.ones(299))
 
 
-def test_polygon_sources_need_a_regular_target_and_vertices():
+def test_grids_without_cells_are_refused():
     src, _ = voronoi_mesh(50, seed=1)
-    with pytest.raises(ValueError):
-        gridgen.polygon_conservative_weights(src, "hp4")
     bare = Grid("points", src.lon, src.lat, name="centres only", cdo_type="unstructured")
     with pytest.raises(ValueError):
-        gridgen.polygon_conservative_weights(bare, "r36x18")
+        gridgen.polygon_conservative_weights(bare, "r36x18")          # no polygons at all
+    with pytest.raises(ValueError, match="no cells"):
+        gridgen.polygon_conservative_weights(src, bare)               # polygons -> a bare list of centres
+    with pytest.raises(ValueError):
+        gridgen.generate_weights(bare, "r36x18", method="con")
+
+
+def overlap_table(w):
+    """(dst, src) -> overlap area, from fracarea weights."""
+    d, s = w["dst_address"].values - 1, w["src_address"].values - 1
+    return {(int(a), int(b)): float(v) for a, b, v in zip(d, s, link_areas(w))}
+
+
+def test_polygons_as_the_target_mirror_polygons_as_the_source():
+    """lon/lat -> mesh and mesh -> lon/lat count the same overlaps (the samples ride on the lon/lat cells both times),
+    so the overlap area of a pair is the same number in both directions; HEALPix on the other side likewise."""
+    mesh, areas = voronoi_mesh(90, seed=4)
+    for other in ("r36x18", "hp4", "hp4_ring"):
+        fwd = gridgen.generate_weights(mesh, other, method="con")                 # mesh -> other
+        bwd = gridgen.generate_weights(other, mesh, method="con")                 # other -> mesh
+        assert bwd.sizes["dst_grid_size"] == 90 and bwd["dst_grid_dims"].values.tolist() == [90]
+        np.testing.assert_allclose(bwd["dst_grid_area"].values, areas, rtol=1e-9)
+        np.testing.assert_allclose(bwd["dst_grid_frac"].values, 1.0, atol=1e-12)   # counted on the overlaps' own samples
+        # link_areas() scales by the exact cell area; undo to the sampled measure: w * (sampled area of the target cell)
+        d, s_ = bwd["dst_address"].values - 1, bwd["src_address"].values - 1
+        sampled = np.zeros(90)
+        for (dd, ss), v in overlap_table(fwd).items():
+            sampled[ss] += v
+        b = {(int(ss), int(dd)): float(wv * sampled[dd]) for dd, ss, wv in zip(d, s_, bwd["remap_matrix"].values[:, 0])}
+        a = overlap_table(fwd)
+        assert a.keys() == b.keys()
+        for k, v in a.items():
+            assert v == pytest.approx(b[k], rel=1e-9, abs=1e-12), (other, k)
+        rows = np.bincount(d, weights=bwd["remap_matrix"].values[:, 0], minlength=90)
+        np.testing.assert_allclose(rows, 1.0, atol=1e-12)
+        assert np.abs(sampled - areas).max() / areas.mean() < 0.2                # sampling error of the cell areas at the default m
+    # ring order is the nested answer, renumbered
+    nested = gridgen.generate_weights(mesh, "hp4", method="con")
+    ring = gridgen.generate_weights(mesh, "hp4_ring", method="con")
+    nlon, nlat = gridgen.healpix_centers(4, nested=True)
+    to_ring = gridgen.healpix_ring_index(4, nlon, nlat)
+    tn = {(int(to_ring[d]), s): v for (d, s), v in overlap_table(nested).items()}
+    tr = overlap_table(ring)
+    assert tn.keys() == tr.keys() and all(tn[k] == pytest.approx(tr[k], rel=1e-12) for k in tn)
+
+
+def test_polygons_on_both_sides():
+    """Mesh -> mesh: both are looked up on a fine HEALPix lattice; a constant stays a constant, every target cell is
+    covered, and the cell areas re-assembled from the overlaps are the polygons' own."""
+    a, area_a = voronoi_mesh(60, seed=21)
+    b, area_b = voronoi_mesh(45, seed=22)
+    assert gridgen.generate_weights(a, b, method="con").sizes["dst_grid_size"] == 45      # the dispatch finds it
+    w = gridgen.polygon_conservative_weights(a, b, samples=8)
+    assert w.sizes["src_grid_size"] == 60 and w.sizes["dst_grid_size"] == 45
+    np.testing.assert_allclose(w["dst_grid_frac"].values, 1.0, atol=1e-12)
+    d, s = w["dst_address"].values - 1, w["src_address"].values - 1
+    np.testing.assert_allclose(np.bincount(d, weights=w["remap_matrix"].values[:, 0], minlength=45), 1.0, atol=1e-12)
+    got = np.bincount(s, weights=link_areas(w), minlength=60)
+    assert np.abs(got - area_a).max() / area_a.mean() < 0.03
+    # the identity: a mesh onto itself is the unit matrix (off-diagonal overlaps only from samples on an edge)
+    same = gridgen.generate_weights(a, a, method="con")
+    diag = same["dst_address"].values == same["src_address"].values
+    assert same["remap_matrix"].values[diag, 0].min() > 0.999 and diag.sum() == 60
 
 
 def fesom_grid():
