@@ -848,3 +848,34 @@ def test_gaussian_regular_to_the_regional_grid_of_the_reference(hip, method):
     ii = np.abs(((z["lon"][None, :] - reg.coords["lon"].values[:, None] + 180) % 360) - 180).argmin(axis=1)
     near = z["tas"][0][jj][:, ii].astype(np.float64)
     assert np.abs(out["tas"].values[0] - near).mean() < 1.0
+
+
+@pytest.mark.parametrize("method", ["con", "bil", "nn"])
+def test_curvilinear_target_grid(hip, rng, method):
+    """A lon/lat field onto an ORCA-like grid given as a Dataset (2-D nav_lon / nav_lat + corner bounds): the output
+    keeps the reference's (i, j) dimensions with 2-D lat / lon coordinates (regrid.py:598-612 only swaps to lat / lon
+    when the degenerate-axis squeeze leaves 1-D coordinates); `con` counts the overlaps with the target's polygons."""
+    from tests.test_gridgen_curvilinear import rotated_pole_grid, sphere_field
+    lon, lat, clon, clat = rotated_pole_grid(nx=36, ny=18, overlap=0)
+    nav_lon = DataArray(lon, dims=("y", "x"), attrs={"bounds": "bounds_nav_lon"})
+    nav_lat = DataArray(lat, dims=("y", "x"), attrs={"bounds": "bounds_nav_lat"})
+    target = Dataset({"tos": DataArray(np.zeros(lon.shape), dims=("y", "x"), coords={"nav_lon": nav_lon, "nav_lat": nav_lat},
+                                       name="tos"),
+                      "bounds_nav_lon": DataArray(clon, dims=("y", "x", "nvertex")),
+                      "bounds_nav_lat": DataArray(clat, dims=("y", "x", "nvertex"))})
+    g = gridgen.parse_grid("r96x48")
+    sl, sp = np.meshgrid(g.lon, g.lat)
+    x = np.stack([sphere_field(sl, sp) + t for t in range(2)])
+    field = DataArray(x, dims=("time", "lat", "lon"), coords={"time": np.arange(2), "lat": g.lat, "lon": g.lon}, name="tas")
+    rg = Regridder(source_grid=field, target_grid=target, method=method)
+    out = rg.regrid(field)
+    assert out.shape == (2, 18, 36) and out.dims == ("time", "i", "j")
+    assert out.coords["lat"].dims == ("i", "j") and out.coords["lon"].shape == (18, 36)
+    np.testing.assert_allclose(out.coords["lat"].values, lat, atol=1e-9)
+    w = rg.grids[0].weights
+    assert list(w["dst_grid_dims"].values) == [36, 18]
+    assert_same(out.values.reshape(2, -1), oracle_2d(w, x.reshape(2, -1)), exact=True)
+    err = np.abs(out.values[0] - sphere_field(lon, lat))
+    assert np.isfinite(out.values).all() and err.max() < {"con": 0.8, "bil": 0.05, "nn": 0.4}[method]
+    if method == "con":
+        np.testing.assert_allclose(w["dst_grid_frac"].values, 1.0, atol=1e-12)
