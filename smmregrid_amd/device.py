@@ -32,7 +32,7 @@ def current_device():
 def device_name(device=0):
     buf = ctypes.create_string_buffer(256)
     _lib.call("smm_device_name", int(device), buf, 256)
-    return buf.value.decode()
+    return buf.value.decode().strip()        # boxes without a marketing name report " (gfx950..., 256 CUs)"
 
 
 def mem_info():
