@@ -1044,7 +1044,9 @@ def _polygon_overlap_areas(src, dst, m, chunk=200000):
     3-D field (same cells, another mask) pay for the geometry once."""
     cache = src.__dict__.setdefault("_overlap_cache", {})
     key = (dst.kind, dst.size, dst.lon.tobytes()[:4096], dst.lat.tobytes()[:4096],
-           None if dst.kind != "regular" else (dst.lon_b.tobytes(), dst.lat_b.tobytes()), m)
+           None if dst.kind != "regular" else (dst.lon_b.tobytes(), dst.lat_b.tobytes()),
+           None if dst.vertices is None else tuple(np.asarray(v).tobytes()[:4096] for v in dst.vertices),
+           getattr(dst, "nested", None), m)
     if key in cache:
         return cache[key]
     has_lattice = lambda g: g.kind == "regular" or (g.cdo_type == "healpix" and g.nside is not None)   # noqa: E731
