@@ -119,6 +119,41 @@ def test_detect_grid_on_reference_files(file_name, expected_grid):
     assert gridtype.kind == expected_grid
 
 
+def _fixture_dataset(name):
+    """The grids of the reference's other data files, rebuilt from the committed fixtures with the dimension and
+    coordinate names the files use (tests/golden/make_ref_data_fixtures.py)."""
+    from smmregrid_amd import Dataset
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(golden, name))
+    if name == "tas_healpix2.npz":        # tas(time, pix), lon(pix) / lat(pix) in radians
+        c = {"lat": DataArray(z["lat"], dims=("pix",), attrs={"units": "radian"}),
+             "lon": DataArray(z["lon"], dims=("pix",), attrs={"units": "radian"})}
+        return Dataset({"tas": DataArray(z["tas"], dims=("time", "pix"), coords=c, name="tas")})
+    if name == "tas_ecearth.npz":         # tas(time, lat, lon) on N128
+        return Dataset({"tas": DataArray(z["tas"], dims=("time", "lat", "lon"),
+                                         coords={"lat": z["lat"], "lon": z["lon"]}, name="tas")})
+    if name == "temp3d_fesom.npz":        # temp(time, nz1, nod2), lon(nod2) / lat(nod2)
+        c = {"lat": DataArray(z["lat"], dims=("nod2",)), "lon": DataArray(z["lon"], dims=("nod2",)), "nz1": z["nz1"]}
+        return Dataset({"temp": DataArray(z["temp"][None], dims=("time", "nz1", "nod2"), coords=c, name="temp")})
+    if name == "ua_ipsl_t0.npz":          # ua(time, plev, lat, lon)
+        return Dataset({"ua": DataArray(z["ua"][None], dims=("time", "plev", "lat", "lon"),
+                                        coords={"plev": z["plev"], "lat": z["lat"], "lon": z["lon"]}, name="ua")})
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("fixture,expected_grid,dims,mask_dim,other", [
+    ("tas_healpix2.npz", "HEALPix", ["pix"], None, []), ("tas_ecearth.npz", "GaussianRegular", ["lat", "lon"], None, []),
+    ("temp3d_fesom.npz", "Unstructured", ["nod2", "nz1"], "nz1", []), ("ua_ipsl_t0.npz", "Regular", ["lat", "lon"], None, ["plev"])])
+def test_detect_grid_on_the_grids_of_the_other_reference_files(fixture, expected_grid, dims, mask_dim, other):
+    """util_test.py:41-67 (tas-healpix2.nc HEALPix, tas-ecearth.nc GaussianRegular, temp3d-fesom.nc Unstructured,
+    ua-ipsl.nc Regular) and gridinspector_test.py:17 (temp3d-fesom.nc: dims nod2 + nz1, one grid, variable temp).
+    `plev` is no masked vertical dimension by name: check_nan finds it from the data (basic_test.py:95-102)."""
+    (gridtype,) = GridInspector(_fixture_dataset(fixture)).get_gridtype()
+    assert gridtype.kind == expected_grid
+    assert set(gridtype.dims) == set(dims) and gridtype.mask_dim == mask_dim and list(gridtype.other_dims) == other
+    assert gridtype.time_dims == ["time"] and len(gridtype.variables) == 1
+
+
 def test_gridinspector_on_2t_era5():
     """gridinspector_test.py:12-60: Dataset, DataArray and path input; get_gridtype_attr; raises."""
     from smmregrid_amd.io import open_dataset
