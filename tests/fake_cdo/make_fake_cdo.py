@@ -4,7 +4,10 @@ The stand-in logs its argv and the remap environment as one JSON line per call
 ($FAKE_CDO_LOG) and answers `gen<method>,<target> [-sellevidx,<k>] <source> <out>` with weights
 from this package's own generator, written as NetCDF-3 -- enough to exercise the command line,
 the environment and the read-back of CdoGenerate's subprocess path (cdogenerate.py:234-303 of
-the reference) on a box without CDO."""
+the reference) on a box without CDO.  `remap<method>,<target> <source> <out>` regrids every field of the
+source file the way CDO does -- weights for the missing-value mask of each time step and level, applied
+here with scipy on the CPU, cells below REMAP_AREA_MIN or without a link missing -- for the checker
+(smmregrid_amd/checker.py, the reference's checker.py)."""
 import os
 import stat
 import sys
@@ -31,6 +34,56 @@ if "gridarea" in argv:                       # cdo [options] -f nc4 gridarea [ex
     r = 6371000.0
     area = (np.diff(np.sin(np.radians(g.lat_b)))[:, None] * np.radians(np.diff(g.lon_b))[None, :]) * r * r
     io.write_netcdf3(Dataset({{"cell_area": (("lat", "lon"), area)}}, coords={{"lat": g.lat, "lon": g.lon}}), out)
+    sys.exit(0)
+remap = next((a for a in argv if a.startswith("remap")), None)
+if remap is not None:                        # cdo remap<method>,<target> <source> <out>
+    import scipy.sparse as sp
+    method, target = remap[5:].split(",", 1)
+    out, source = argv[-1], argv[-2]
+    ds = io.open_dataset(source)
+    if os.path.isfile(target):
+        dst = CdoGenerate._grid_of(io.open_dataset(target))
+    else:
+        dst = gridgen.parse_grid(target)
+    src = CdoGenerate._grid_of(ds)
+    area_min = float(os.environ.get("REMAP_AREA_MIN", "0.0"))
+    res = Dataset(attrs={{"title": "fake cdo remap"}})
+    tdims = ("lat", "lon") if dst.kind == "regular" else ("cell",)
+    tshape = (dst.lat.size, dst.lon.size) if dst.kind == "regular" else (dst.size,)
+    cache = {{}}
+    for name, fld in ds.data_vars.items():
+        gt = GridType(fld.dims)
+        if not gt.horizontal_dims or any(t in name for t in ("bnds", "bounds", "vertices")):
+            continue
+        nh = len(gt.horizontal_dims)
+        lead_dims, lead_shape = tuple(fld.dims[:-nh]), tuple(fld.shape[:-nh])
+        x = np.asarray(fld.values, dtype=np.float64).reshape(-1, src.size)
+        y = np.full((x.shape[0], dst.size), np.nan)
+        for r in range(x.shape[0]):
+            ok = np.isfinite(x[r])
+            key = ok.tobytes()
+            if key not in cache:
+                w = gridgen.generate_weights(src, dst, method=method, src_mask=None if ok.all() else ok.astype(np.int32),
+                                             norm=os.environ.get("CDO_REMAP_NORM", "fracarea"))
+                a = sp.coo_matrix((w["remap_matrix"].values[:, 0], (w["dst_address"].values - 1, w["src_address"].values - 1)),
+                                  shape=(dst.size, src.size)).tocsr()
+                linked = np.diff(a.indptr) > 0
+                if method in ("con", "ycon", "con2", "laf") and area_min > 0.0:
+                    linked &= ~(w["dst_grid_frac"].values < area_min)
+                cache[key] = (a, linked)
+            a, linked = cache[key]
+            y[r] = np.where(linked, a @ np.where(ok, x[r], 0.0), np.nan)
+        coords = {{k: c for k, c in fld.coords.items() if set(c.dims) <= set(lead_dims) and c.dims}}
+        res[name] = DataArray(y.reshape(lead_shape + tshape), dims=lead_dims + tdims, coords=coords, name=name)
+    if dst.kind == "regular":
+        lat = dst.lat[::-1] if dst.lat_descending else dst.lat
+        res.coords["lat"] = DataArray(lat, dims=("lat",))
+        res.coords["lon"] = DataArray(dst.lon, dims=("lon",))
+        if dst.lat_descending:
+            for name in list(res.data_vars):
+                v = res[name]
+                res[name] = DataArray(v.values[..., ::-1, :], dims=v.dims, coords=dict(v.coords), name=name)
+    io.write_netcdf3(res, out)
     sys.exit(0)
 gen = next(a for a in argv if a.startswith("gen"))
 method, target = gen[3:].split(",", 1)

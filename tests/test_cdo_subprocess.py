@@ -149,3 +149,57 @@ def test_areas_through_cdo_gridarea(fake_cdo):
     assert fake_cdo()[1]["argv"][:3] == ["-f", "nc4", "gridarea"] and t["cell_area"].shape == (8, 16)
     with pytest.raises(TypeError):
         CdoGenerate("r32x16").areas(target=True)
+
+
+def test_checker_needs_the_cdo_binary(monkeypatch):
+    """checker.py of the reference compares with CDO: without the binary there is nothing to compare with."""
+    from smmregrid_amd.checker import check_cdo_regrid, find_var
+    from smmregrid_amd import Dataset
+    monkeypatch.setenv("PATH", "/nonexistent")
+    with pytest.raises(FileNotFoundError, match="cdo"):
+        check_cdo_regrid(os.path.join(ROOT, "tests", "golden", "refdata", "2t-era5.nc"), "r36x18")
+    ds = Dataset({"tas": DataArray(np.zeros((2, 3, 4)), dims=("time", "lat", "lon")),
+                  "time_bnds": DataArray(np.zeros((2, 2)), dims=("time", "bnds")),
+                  "orog": DataArray(np.zeros((3, 4)), dims=("lat", "lon"))})
+    assert find_var(ds) == ["tas"]                                    # checker.py:10-21
+    assert find_var(Dataset({"orog": ds["orog"]})) == ["orog"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,init_method", [("con", "grids"), ("bil", "weights"), ("nn", "grids")])
+def test_check_cdo_regrid_on_a_reference_file(hip, fake_cdo, method, init_method):
+    """identity2d_test.py:57-62 (`test_lonlat`: 2t-era5.nc -> r360x180.nc, init by weights) and the init-by-grids
+    form: CDO's remap (the stand-in: per-step weights applied with scipy) against the GPU regrid, through the same
+    function the reference's tests call."""
+    from smmregrid_amd.checker import check_cdo_regrid
+    golden = os.path.join(ROOT, "tests", "golden", "refdata")
+    assert check_cdo_regrid(os.path.join(golden, "2t-era5.nc"), os.path.join(golden, "r360x180.nc"),
+                            remap_method=method, init_method=init_method) is True
+    calls = [c["argv"] for c in fake_cdo()]
+    assert calls[0][0].startswith(f"remap{method},") and any(a[0].startswith(f"gen{method},") or
+                                                             any(x.startswith(f"gen{method},") for x in a) for a in calls)
+    with pytest.raises(KeyError):
+        check_cdo_regrid(os.path.join(golden, "2t-era5.nc"), "r36x18", init_method="nothing")
+
+
+@pytest.mark.gpu
+def test_check_cdo_regrid_levels_and_masks(hip, fake_cdo, tmp_path, rng):
+    """levels_test.py:10-27 / identity3d_test.py: a 3-D ocean-like file with a land mask growing with depth; all
+    levels through check_cdo_regrid, levels [1, 3] and [2] through check_cdo_regrid_levels."""
+    from smmregrid_amd import io
+    from smmregrid_amd.checker import check_cdo_regrid, check_cdo_regrid_levels
+    g = gridgen.parse_grid("r48x24")
+    x = (10.0 + rng.standard_normal((2, 4, 24, 48))).astype(np.float32)
+    for lev in range(4):
+        x[:, lev, 4:8 + 3 * lev, 5:12 + 4 * lev] = np.nan
+    field = DataArray(x, dims=("time", "lev", "lat", "lon"),
+                      coords={"time": np.arange(2.0), "lev": np.array([5.0, 50.0, 500.0, 2000.0]), "lat": g.lat,
+                              "lon": g.lon}, name="so")
+    path = str(tmp_path / "so3d.nc")
+    io.write_netcdf3(field, path)
+    assert check_cdo_regrid(path, "r24x12", remap_method="con") is True
+    assert check_cdo_regrid(path, "r24x12", remap_method="con", access="DataArray") is True
+    assert check_cdo_regrid_levels(path, "r24x12", "lev", [1, 3], remap_method="con") is True
+    assert check_cdo_regrid_levels(path, "r24x12", "lev", [2], remap_method="con") is True
+    # the comparison notices a difference: a cut CDO did not apply
+    assert check_cdo_regrid(path, "r24x12", remap_method="con", remap_area_min=0.9) is False
