@@ -170,8 +170,12 @@ class CdoGenerate:
                 vertical_dim=None, nproc=1):
         """Weights Dataset in CDO/SCRIP layout; 3-D (per level) when mask_dim is given
         (cdogenerate.py:101-228)."""
-        if vertical_dim is not None and mask_dim is None:
-            mask_dim = vertical_dim
+        if vertical_dim is not None:                 # deprecated_argument (util.py:26-39, cdogenerate.py:156)
+            import warnings
+            warnings.warn("vertical_dim is deprecated and will be removed in future versions. "
+                          "Please use mask_dim instead.", DeprecationWarning)
+            if mask_dim is None:
+                mask_dim = vertical_dim
         if self.target_grid is None:
             raise TypeError('Target grid is not specified, cannot provide any regridding')
         if self.source_grid is None:

@@ -203,3 +203,17 @@ def test_check_cdo_regrid_levels_and_masks(hip, fake_cdo, tmp_path, rng):
     assert check_cdo_regrid_levels(path, "r24x12", "lev", [2], remap_method="con") is True
     # the comparison notices a difference: a cut CDO did not apply
     assert check_cdo_regrid(path, "r24x12", remap_method="con", remap_area_min=0.9) is False
+
+
+def test_vertical_dim_is_a_deprecated_alias_of_mask_dim(fake_cdo):
+    """cdogenerate.py:156 / basic_test.py:104-110: `vertical_dim` still works and warns."""
+    g = gridgen.parse_grid("r24x12")
+    x = np.ones((1, 2, 12, 24))
+    x[:, 1, 2:5, 3:9] = np.nan
+    field = DataArray(x, dims=("time", "lev", "lat", "lon"),
+                      coords={"time": np.arange(1), "lev": np.array([5.0, 50.0]), "lat": g.lat, "lon": g.lon}, name="so")
+    gen = CdoGenerate(field, "r12x6")
+    gen._with_masked_flag = lambda ds, mask_dim: ds            # the mask pass needs the GPU; not the subject here
+    with pytest.warns(DeprecationWarning, match="vertical_dim"):
+        w = gen.weights(method="nn", vertical_dim="lev")
+    assert "lev" in w.sizes and w.sizes["lev"] == 2             # "Vertical coordinate 'lev' ... in weights dimensions"
