@@ -96,9 +96,8 @@ class Regridder(object):
         else:
             self.init_mode = 'grids'
             from .cdogenerate import CdoGenerate
-            if isinstance(source_grid, str) and os.path.sep in source_grid \
-                    and not os.path.isfile(source_grid):
-                raise FileNotFoundError(f'Cannot find grid file {source_grid}')
+            if isinstance(source_grid, str) and not os.path.isfile(source_grid):
+                raise FileNotFoundError(f'Cannot find grid file {source_grid}')      # regrid.py:133-138
             if isinstance(source_grid, str) and os.path.isfile(source_grid):
                 from .io import open_dataset       # regrid.py:133-136: a data file as source grid
                 source_grid = open_dataset(source_grid)

@@ -92,6 +92,9 @@ def test_constructor_and_call_errors(hip, rng):
         CdoGenerate("r96x48", "r36x18").weights(method="foo")   # cdogenerate.py:70-76 (_safe_check)
     with pytest.raises(ValueError):
         CdoGenerate("r96x48", "r36x18").weights(remap_norm="foo")   # cdogenerate.py:77-78
+    for missing in ("no_such_file.nc", "/no/such/dir/file.nc", "r96x48"):
+        with pytest.raises(FileNotFoundError):                  # regrid.py:133-138: a string source is a file name
+            Regridder(source_grid=missing, target_grid="r36x18")
 
 
 def test_remap_area_min_counts_monotone(hip, rng):
