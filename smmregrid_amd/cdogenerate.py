@@ -192,9 +192,6 @@ class CdoGenerate:
         if method not in NATIVE_METHODS:
             raise NotImplementedError(f"method '{method}' needs the cdo binary (`cdo gen{method},<target> <source> "
                                       f"<weights>`); the native generator knows {', '.join(NATIVE_METHODS)}")
-        if not extrapolate:
-            raise NotImplementedError("extrapolate=False (REMAP_EXTRAPOLATE=off) needs the cdo binary; the "
-                                      "native generator always maps every target point")
         if self.cdo_options or [e for e in self.cdo_extra if not str(e).startswith("-setgrid,")]:
             self.loggy.warning("cdo_options / cdo_extra %s %s are ignored without the cdo binary",
                                self.cdo_options, self.cdo_extra)
@@ -204,8 +201,8 @@ class CdoGenerate:
         src = gridgen.parse_grid(setgrid[-1]) if setgrid else self._grid_of(self.source_grid)
         dst = self._grid_of(self.target_grid)
         if mask_dim is None:
-            ds = gridgen.generate_weights(src, dst, method=method,
-                                          src_mask=self._source_mask(), norm=remap_norm)
+            ds = gridgen.generate_weights(src, dst, method=method, src_mask=self._source_mask(), norm=remap_norm,
+                                          extrapolate=extrapolate)
             return self._with_masked_flag(ds, None)
         obj = self.source_grid
         if isinstance(obj, Dataset):
@@ -213,7 +210,7 @@ class CdoGenerate:
         levels = obj.coords[mask_dim].values
         per_level = [gridgen.generate_weights(src, dst, method=method,
                                               src_mask=self._source_mask(i, mask_dim),
-                                              norm=remap_norm)
+                                              norm=remap_norm, extrapolate=extrapolate)
                      for i in range(len(levels))]
         ds = gridgen.stack_level_weights(per_level, levels, mask_dim=mask_dim, method=method)
         return self._with_masked_flag(ds, mask_dim)

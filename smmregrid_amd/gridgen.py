@@ -341,7 +341,7 @@ def _lon_corners(src, lon):
     return i0, i1, fx
 
 
-def bilinear_weights(src, dst, src_mask=None):
+def bilinear_weights(src, dst, src_mask=None, extrapolate=True):
     """4-point bilinear from a regular lon/lat source (periodic in longitude,
     clamped at the first/last latitude row) to the destination cell centres.
     Without a mask: four links per destination cell, zero weights kept (as CDO's genbil does).
@@ -353,7 +353,7 @@ def bilinear_weights(src, dst, src_mask=None):
     if src.cdo_type == "healpix" and src.nside is not None:
         return _healpix_bilinear(src, dst, src_mask)
     if src.kind != "regular" and src.shape2d is not None:
-        return _curvilinear_bilinear(src, dst, src_mask)
+        return _curvilinear_bilinear(src, dst, src_mask, extrapolate=extrapolate)
     if src.kind != "regular":
         raise ValueError("bilinear generation needs a regular, curvilinear (2-D centres) or HEALPix (hp<N>) source grid")
     nx, ny = src.lon.size, src.lat.size
@@ -528,7 +528,7 @@ def _healpix_bilinear(src, dst, src_mask=None):
     return _scrip_dataset(src, dst, (pix[valid] + 1).astype(np.int32), dst4[valid], wv[valid], "bil", src_imask=imask)
 
 
-def _curvilinear_bilinear(src, dst, src_mask=None, candidates=6, iterations=30):
+def _curvilinear_bilinear(src, dst, src_mask=None, candidates=6, iterations=30, extrapolate=True):
     """Bilinear weights from a curvilinear source (2-D lon / lat of the cell centres, e.g. an ORCA ocean grid): SCRIP's
     scheme, as CDO's genbil uses it.  The four neighbouring centres (j, i), (j, i+1), (j+1, i+1), (j+1, i) span a
     quadrilateral in the (lon, lat) plane -- longitudes taken relative to the target point, so the date line is no
@@ -538,7 +538,8 @@ def _curvilinear_bilinear(src, dst, src_mask=None, candidates=6, iterations=30):
     once more in the tangent plane at the point itself.  A grid that closes in longitude without repeating columns gets the wrap-around
     quadrilaterals too.  Masked corners are dropped and the rest renormalised; a point in no quadrilateral (beyond the
     edge of a regional grid, inside the hole of a tripolar one) or with four masked corners takes the nearest unmasked
-    centre with weight 1 -- CDO's REMAP_EXTRAPOLATE=on, which is what the reference's CdoGenerate sets by default."""
+    centre with weight 1 -- CDO's REMAP_EXTRAPOLATE=on, which is what the reference's CdoGenerate sets by default; with
+    `extrapolate=False` such a point gets no link."""
     from scipy.spatial import cKDTree
     nx, ny = src.shape2d
     slon, slat = (np.asarray(a, dtype=np.float64).reshape(ny, nx) for a in src.centers())
@@ -644,7 +645,7 @@ def _curvilinear_bilinear(src, dst, src_mask=None, candidates=6, iterations=30):
     src_addr, dst_addr, w = q[keep], d4[keep], wv[keep]
     rest = np.setdiff1d(np.arange(n), found[usable], assume_unique=True)    # extrapolation: nearest unmasked centre
     cells = np.arange(src.size, dtype=np.int64) if imask is None else np.flatnonzero(imask)
-    if rest.size and cells.size:
+    if rest.size and cells.size and extrapolate:
         _, idx = cKDTree(flat_unit[cells]).query(_unit_vectors(tlon[rest], tlat[rest]), k=1)
         src_addr = np.concatenate([src_addr, cells[idx]])
         dst_addr = np.concatenate([dst_addr, rest])
@@ -1308,7 +1309,27 @@ def _flip_address(addr, nx, ny):
     return ((ny - 1 - a // nx) * nx + a % nx + 1).astype(np.int32)
 
 
-def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
+def _inside_source(src, dst, method):
+    """Target points the source grid reaches WITHOUT extrapolation (CDO's REMAP_EXTRAPOLATE=off): for the point-wise
+    interpolations (bil, bic) the hull of the source cell CENTRES -- a point beyond the first / last row or column of
+    centres has no enclosing cell --, for nn / dis the area the source CELLS cover.  A bare list of centres has no
+    extent: everything counts as inside."""
+    lon, lat = dst.centers()
+    inside = np.ones(lon.size, dtype=bool)
+    if src.kind == "regular":
+        centres = method in ("bil", "bic")
+        la = src.lat if centres else src.lat_b
+        inside &= (lat >= la[0] - 1e-12) & (lat <= la[-1] + 1e-12)
+        if not _is_cyclic(src):
+            lo = src.lon if centres else src.lon_b
+            u = (lon - lo[0]) % 360.0
+            inside &= u <= (lo[-1] - lo[0]) + 1e-12
+    elif src.vertices is not None and method not in ("bil", "bic"):
+        inside &= _PolygonLocator(src).locate(_unit_vectors(lon, lat)) >= 0
+    return inside
+
+
+def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea", extrapolate=True):
     """Dispatch on CDO method names (cdogenerate.py:73): con/ycon -> conservative,
     bil -> bilinear, nn -> nearest, dis -> inverse-distance average of four neighbours.  Grids whose latitude axis runs north-to-south are
     computed south-to-north and renumbered to the file's cell order afterwards."""
@@ -1327,7 +1348,7 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
         else:
             ds = conservative_weights(src, dst, src_mask=src_mask, norm=norm)
     elif method == "bil":
-        ds = bilinear_weights(src, dst, src_mask=src_mask)
+        ds = bilinear_weights(src, dst, src_mask=src_mask, extrapolate=extrapolate)
     elif method == "nn":
         ds = nearest_weights(src, dst, src_mask=src_mask)
     elif method == "dis":
@@ -1351,6 +1372,13 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea"):
     else:
         raise ValueError(f"method '{method}' is not available without the cdo binary "
                          "(native generator: con, ycon, con2, bil, bic, nn, dis, laf)")
+    if not extrapolate and method in ("bil", "bic", "nn", "dis"):
+        # REMAP_EXTRAPOLATE=off: target points outside the source grid get no link (missing after the regrid)
+        keep = _inside_source(_unflipped(src), _unflipped(dst), method)[ds["dst_address"].values - 1]
+        if not keep.all():
+            for name in ("src_address", "dst_address"):
+                ds[name] = (("num_links",), ds[name].values[keep])
+            ds["remap_matrix"] = (("num_links", "num_wgts"), ds["remap_matrix"].values[keep])
     if not (flip_s or flip_d):
         return ds
     src_addr, dst_addr = ds["src_address"].values, ds["dst_address"].values

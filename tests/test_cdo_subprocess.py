@@ -108,8 +108,24 @@ def test_without_cdo_the_native_generator_says_so(monkeypatch, caplog):
         assert w.sizes["dst_grid_size"] == 16 * 8 and w.sizes["num_wgts"] == {"bic": 4, "con2": 3}.get(method, 1)
     with pytest.raises(ValueError, match="regular"):
         gridgen.generate_weights("r32x16", "hp4", method="con2")
-    with pytest.raises(NotImplementedError, match="extrapolate=False"):
-        gen.weights(method="bil", extrapolate=False)
+    # REMAP_EXTRAPOLATE=off natively: target points outside the source grid get no link.  A regional source ...
+    reg = gridgen.regular_grid_from_centers(np.arange(10.0, 60.0, 2.0), np.arange(-20.0, 31.0, 2.0))
+    for method in ("bil", "bic", "nn", "dis"):
+        on = gridgen.generate_weights(reg, "r36x18", method=method)
+        off = gridgen.generate_weights(reg, "r36x18", method=method, extrapolate=False)
+        linked_on, linked_off = np.unique(on["dst_address"].values), np.unique(off["dst_address"].values)
+        assert linked_on.size == 36 * 18 and 0 < linked_off.size < 60
+        dst = gridgen.parse_grid("r36x18")
+        tl, tp = dst.centers()
+        edge = 0.0 if method in ("bil", "bic") else 1.0            # hull of the centres / of the cells
+        want = (tl >= 10.0 - edge) & (tl <= 58.0 + edge) & (tp >= -20.0 - edge) & (tp <= 30.0 + edge)
+        assert np.array_equal(np.flatnonzero(want) + 1, linked_off)
+        sel = np.isin(on["dst_address"].values, linked_off)        # inside, the weights are the same
+        assert np.array_equal(on["remap_matrix"].values[sel], off["remap_matrix"].values)
+    # ... and a global one only loses the bilinear rows beyond its first / last row of centres
+    off = gridgen.generate_weights("r32x16", "r16x30", method="bil", extrapolate=False)     # rows at +-87 > +-84.4
+    assert np.unique(off["dst_address"].values).size == 16 * 28
+    assert np.unique(gridgen.generate_weights("r32x16", "r16x30", method="nn", extrapolate=False)["dst_address"].values).size == 16 * 30
 
 
 @pytest.mark.gpu

@@ -882,3 +882,20 @@ def test_curvilinear_target_grid(hip, rng, method):
     assert np.isfinite(out.values).all() and err.max() < {"con": 0.8, "bil": 0.05, "nn": 0.4}[method]
     if method == "con":
         np.testing.assert_allclose(w["dst_grid_frac"].values, 1.0, atol=1e-12)
+
+
+def test_regional_source_without_extrapolation(hip, rng):
+    """CdoGenerate.weights(extrapolate=False) (REMAP_EXTRAPOLATE=off, cdogenerate.py:277): target cells the regional
+    source does not reach carry no link and come back missing; inside, the values are those of the default."""
+    lon, lat = np.arange(10.0, 60.0, 2.0), np.arange(-20.0, 31.0, 2.0)
+    x = 280.0 + rng.standard_normal((2, lat.size, lon.size))
+    field = DataArray(x, dims=("time", "lat", "lon"), coords={"time": np.arange(2), "lat": lat, "lon": lon}, name="tas")
+    gen = CdoGenerate(field, "r72x36")
+    w_on, w_off = gen.weights(method="bil"), gen.weights(method="bil", extrapolate=False)
+    y_on = Regridder(weights=w_on).regrid(field).values
+    y_off = Regridder(weights=w_off).regrid(field).values
+    tl, tp = np.meshgrid(gridgen.parse_grid("r72x36").lon, gridgen.parse_grid("r72x36").lat)
+    inside = (tl >= 10.0) & (tl <= 58.0) & (tp >= -20.0) & (tp <= 30.0)
+    assert np.isfinite(y_on).all() and np.array_equal(np.isfinite(y_off[0]), inside)
+    assert_same(y_off[:, inside], y_on[:, inside], exact=True)
+    assert_same(y_off.reshape(2, -1), oracle_2d(w_off, x.reshape(2, -1)), exact=True)

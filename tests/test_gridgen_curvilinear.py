@@ -84,6 +84,12 @@ def test_masked_corners_are_dropped_and_points_outside_take_the_nearest_unmasked
     assert ((a[far] == 1.0).sum(axis=1) == 1).all()
     with pytest.raises(ValueError, match="cells"):
         gridgen.generate_weights(cur, dst, method="bil", src_mask=np.ones(7))
+    # REMAP_EXTRAPOLATE=off: the points no quadrilateral holds (and those whose corners are all masked) get no link
+    off = gridgen.generate_weights(cur, dst, method="bil", src_mask=mask.ravel(), extrapolate=False)
+    b = dense(off)
+    linked = b.sum(axis=1) > 0
+    assert not linked[far].any() and 0.2 < linked.mean() < 0.6
+    np.testing.assert_allclose(b[linked], a[linked], atol=1e-12)
 
 
 def test_conservative_from_the_corner_arrays_of_a_curvilinear_grid():
