@@ -2,6 +2,7 @@
 NetCDF-3 classic / 64-bit-offset (``scipy.io.netcdf_file``) and HDF5-based NetCDF-4 -- through
 xarray or h5py when importable, else the built-in pure-Python reader (``hdf5lite.py``)."""
 import json
+from collections import OrderedDict
 
 import numpy as np
 
@@ -31,16 +32,27 @@ def write_netcdf3(ds, path):
     if isinstance(ds, DataArray):
         da = ds
         ds = Dataset({da.name or "field": da}, coords=dict(da.coords))
+    # as xarray.to_netcdf: coordinates that hang on a field but not on the Dataset are written too, and a field names
+    # its auxiliary coordinates (lon / lat per cell, 2-D nav_lon / nav_lat) in the CF `coordinates` attribute -- that
+    # attribute is how CDO finds the grid of an unstructured or curvilinear field
+    variables = OrderedDict(ds.variables)
+    aux = {}
+    for name, v in ds.data_vars.items():
+        for ck, c in v.coords.items():
+            if c.dims and ck not in variables:
+                variables[ck] = c
+            if c.dims and ck not in v.dims and set(c.dims) <= set(v.dims) and (c.dims != (ck,)):
+                aux.setdefault(name, []).append(ck)
     with netcdf_file(path, "w", version=2) as nc:
         for k, v in ds.attrs.items():
             setattr(nc, k, v if isinstance(v, (int, float, str)) else str(v))
         sizes = {}
-        for v in ds.variables.values():
+        for v in variables.values():
             for d, n in zip(v.dims, v.shape):
                 sizes.setdefault(d, int(n))
         for d, n in sizes.items():
             nc.createDimension(d, n)
-        for k, v in ds.variables.items():
+        for k, v in variables.items():
             values = np.asarray(v.values)
             if values.dtype == np.int64:
                 values = values.astype(np.int32)       # classic NetCDF has no 64-bit integers
@@ -54,6 +66,8 @@ def write_netcdf3(ds, path):
             for a, av in v.attrs.items():
                 if isinstance(av, (int, float, str, np.generic)):
                     setattr(var, a, av)
+            if k in aux and "coordinates" not in v.attrs:
+                var.coordinates = " ".join(aux[k])
             if values.dtype.kind == "f" and np.isnan(values).any():
                 var._FillValue = values.dtype.type(np.nan)
     return path

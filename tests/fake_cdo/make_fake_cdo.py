@@ -94,8 +94,9 @@ if source.startswith("-const,1,"):
     src = gridgen.parse_grid(source.split(",", 2)[2])
 else:
     ds = io.open_dataset(source)
-    fld = next(v for v in ds.data_vars.values() if GridType(v.dims).horizontal_dims)
-    src = CdoGenerate._grid_of(fld)
+    fld = next(v for v in ds.data_vars.values() if GridType(v.dims).horizontal_dims
+               and not any(t in str(v.name) for t in ("bnds", "bounds", "vertices")))
+    src = CdoGenerate._grid_of(ds)            # the whole file: cell bounds / corners belong to the grid
     gt = GridType(fld.dims)
     sel = {{d: 0 for d in fld.dims if d not in gt.horizontal_dims}}
     if lev is not None:

@@ -233,3 +233,32 @@ def test_vertical_dim_is_a_deprecated_alias_of_mask_dim(fake_cdo):
     with pytest.warns(DeprecationWarning, match="vertical_dim"):
         w = gen.weights(method="nn", vertical_dim="lev")
     assert "lev" in w.sizes and w.sizes["lev"] == 2             # "Vertical coordinate 'lev' ... in weights dimensions"
+
+
+def test_fields_on_curvilinear_and_unstructured_grids_reach_cdo_with_their_coordinates(fake_cdo, tmp_path):
+    """cdogenerate.py:82-87: a source given as data is written to a temporary NetCDF file for cdo.  CDO finds the grid of
+    a curvilinear / unstructured field through the CF `coordinates` attribute and the bounds the coordinates name: the
+    file written here carries both (as xarray.to_netcdf's does), and reading it back gives the same grid."""
+    from smmregrid_amd import Dataset, io
+    from tests.test_gridgen_curvilinear import rotated_pole_grid
+    lon, lat, clon, clat = rotated_pole_grid(nx=12, ny=6)
+    nav_lon = DataArray(lon, dims=("y", "x"), attrs={"bounds": "bounds_nav_lon", "units": "degrees_east"})
+    nav_lat = DataArray(lat, dims=("y", "x"), attrs={"bounds": "bounds_nav_lat", "units": "degrees_north"})
+    ds = Dataset({"tos": DataArray(np.ones((2,) + lon.shape), dims=("time", "y", "x"),
+                                   coords={"time": np.arange(2.0), "nav_lon": nav_lon, "nav_lat": nav_lat}, name="tos"),
+                  "bounds_nav_lon": DataArray(clon, dims=("y", "x", "nvertex")),
+                  "bounds_nav_lat": DataArray(clat, dims=("y", "x", "nvertex"))})
+    path = str(tmp_path / "curv.nc")
+    io.write_netcdf3(ds, path)
+    back = io.open_dataset(path)
+    assert back["tos"].attrs["coordinates"].split() == ["nav_lon", "nav_lat"] and "nav_lon" in back["tos"].coords
+    g = CdoGenerate._grid_of(back)
+    assert g.shape2d == (14, 6) and g.vertices[0].shape == (84, 4)
+    np.testing.assert_allclose(g.vertices[1], clat.reshape(-1, 4))
+    # the subprocess path: cdo (the stand-in reads the temporary file) sees the curvilinear cells and their corners
+    gen = CdoGenerate(ds, "r24x12")
+    w = gen._cdo_weights("con", True, "fracarea", None, 1)
+    assert w["src_grid_dims"].values.tolist() == [14, 6] and w.sizes["dst_grid_size"] == 24 * 12
+    ref = gridgen.generate_weights(CdoGenerate._grid_of(ds), "r24x12", method="con")
+    assert np.array_equal(w["src_address"].values, ref["src_address"].values)
+    np.testing.assert_allclose(w["remap_matrix"].values, ref["remap_matrix"].values, atol=1e-12)
