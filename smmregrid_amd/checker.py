@@ -16,7 +16,7 @@ import numpy as np
 
 from .cdogenerate import CdoGenerate
 from .regrid import Regridder
-from .xrlite import DataArray, Dataset, from_xarray
+from .xrlite import Dataset, from_xarray
 
 
 def find_var(xfield):
