@@ -98,6 +98,10 @@ class CdoGenerate:
                         return hp
                     g = gridgen.Grid("points", lon, lat, name="cell centres", cdo_type="unstructured")
                     g.vertices = CdoGenerate._cell_vertices(parent, obj, lon.size)   # polygons, if the file has them
+                    if g.vertices is None:       # a reduced (Gaussian) grid implies its cells: bands x arcs
+                        g.vertices = gridgen.reduced_grid_vertices(lon, lat)
+                        if g.vertices is not None:
+                            g.name, g.cdo_type = "reduced grid", "gaussian_reduced"
                     return g
                 def edges(coord_name, centres):
                     """nx + 1 cell edges from the file's (n, 2) bounds variable named by the coordinate's `bounds`

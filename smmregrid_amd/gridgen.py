@@ -198,6 +198,49 @@ def healpix_grid_of_centers(lon, lat, tol=1e-6):
     return None
 
 
+def reduced_grid_vertices(lon, lat, tol=1e-6):
+    """Cell polygons (cells, V) of a REDUCED grid given as a list of centres: rows of constant latitude, each with its
+    own number of evenly spaced points around the full circle (reduced / octahedral Gaussian grids of IFS, as GRIB
+    files carry them).  A cell spans +-180 / n_row degrees around its centre and the latitude band of its row; the band
+    edges are the Gaussian ones (sin(edge) = 1 - cumulative Gaussian weights) when the rows are the Gaussian latitudes,
+    else the mid-points between rows, with the poles closing the first and last band.  None if the list is no such
+    grid."""
+    lon, lat = np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64)
+    if lon.ndim != 1 or lon.size != lat.size or lon.size < 8:
+        return None
+    start = np.flatnonzero(np.r_[True, np.abs(np.diff(lat)) > tol])
+    count = np.diff(np.r_[start, lat.size])
+    rows = lat[start]
+    if rows.size < 2 or rows.size == lat.size or not (np.all(np.diff(rows) < 0) or np.all(np.diff(rows) > 0)):
+        return None
+    step = 360.0 / np.repeat(count, count)
+    k = np.arange(lat.size) - np.repeat(start, count)
+    if np.abs(((lon - np.repeat(lon[start], count) - k * step + 180.0) % 360.0) - 180.0).max() > 1e-4:
+        return None
+    nrow = rows.size
+    edges = None
+    if nrow % 2 == 0:
+        x, w = np.polynomial.legendre.leggauss(nrow)
+        glat = np.degrees(np.arcsin(x))[::-1]                                   # north to south
+        north_first = rows[0] > rows[-1]
+        if np.abs((rows if north_first else rows[::-1]) - glat).max() < 2e-3:
+            e = np.degrees(np.arcsin(np.clip(1.0 - np.r_[0.0, np.cumsum(w[::-1])], -1.0, 1.0)))
+            edges = e if north_first else e[::-1]
+    if edges is None:
+        mid = 0.5 * (rows[1:] + rows[:-1])
+        edges = np.r_[90.0 if rows[0] > rows[-1] else -90.0, mid, -90.0 if rows[0] > rows[-1] else 90.0]
+    e0, e1 = np.repeat(edges[:-1], count), np.repeat(edges[1:], count)
+    south, north = np.minimum(e0, e1), np.maximum(e0, e1)
+    # the polygon generator joins vertices by great circles, a cell's north and south edges are parallels: put a vertex
+    # every <= 2 degrees of longitude along them (the 20 cells next to the pole of an octahedral grid are 18 degrees wide)
+    q = int(np.clip(np.ceil(step.max() / 2.0), 1, 16))
+    t = np.arange(q + 1) / q
+    along = (lon - step / 2.0)[:, None] + step[:, None] * t[None, :]                     # west -> east
+    lon_v = np.concatenate([along, along[:, ::-1]], axis=1) % 360.0
+    lat_v = np.concatenate([np.repeat(south[:, None], q + 1, axis=1), np.repeat(north[:, None], q + 1, axis=1)], axis=1)
+    return lon_v, lat_v
+
+
 def gaussian_grid(n, name=None):
     """Regular Gaussian grid F<N> / n<N>: 4N longitudes from 0, 2N Gauss-Legendre latitudes
     (south to north here; cell bounds at mid-points, clipped at the poles)."""
@@ -960,7 +1003,22 @@ class _PolygonLocator:
         self.vx2, self.vy2 = np.roll(self.vx, -1, axis=1), np.roll(self.vy, -1, axis=1)
 
     def locate(self, p):
-        """Cell index per unit vector of `p` (P, 3); -1 where no candidate cell holds it."""
+        """Cell index per unit vector of `p` (P, 3); -1 where no candidate cell holds it.  A point that lies exactly on
+        an edge two cells share can fall out of both (each cell is tested in its own projection): points nobody claims
+        are tried once more a hair (1e-7 rad) to the north-east, which decides for one side and changes no area."""
+        owner = self._locate(p)
+        lost = np.flatnonzero(owner < 0)
+        if lost.size:
+            q = p[lost]
+            east = np.stack([-q[:, 1], q[:, 0], np.zeros(lost.size)], axis=1)
+            norm = np.linalg.norm(east, axis=1, keepdims=True)
+            east = np.where(norm > 1e-12, east / np.where(norm > 1e-12, norm, 1.0), np.array([[1.0, 0.0, 0.0]]))
+            north = np.cross(q, east)
+            q = q + 1e-7 * (0.6 * east + 0.8 * north)
+            owner[lost] = self._locate(q / np.linalg.norm(q, axis=1, keepdims=True))
+        return owner
+
+    def _locate(self, p):
         _, cand = self.tree.query(p, k=self.k)
         cand = cand.reshape(-1, self.k)
         owner = np.full(p.shape[0], -1, dtype=np.int64)

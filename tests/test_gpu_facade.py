@@ -773,13 +773,14 @@ def test_orca_like_dataset_with_corner_bounds(hip, rng, method):
     assert np.abs(y[far] - sphere_field(tl[far], tp[far])).max() < {"con": 0.6, "bil": 0.08, "nn": 0.8}[method]
 
 
-def test_reduced_gaussian_grib_file_nearest_neighbour(hip):
+@pytest.mark.parametrize("method", ["nn", "con"])
+def test_reduced_gaussian_grib_file(hip, method):
     """identity2d_test.py:22-27: `lsm-ifs.grb` (GRIB-1, reduced Gaussian grid, read by the built-in griblite) to
-    r360x180.nc with `nn`, init by grids from the file name."""
+    r360x180.nc with `nn`, init by grids from the file name; `con` as well, from the cells the reduced grid implies."""
     from smmregrid_amd.io import open_dataset
     golden = os.path.join(os.path.dirname(__file__), "golden", "refdata")
     path, tfile = os.path.join(golden, "..", "grib", "lsm-ifs.grb"), os.path.join(golden, "r360x180.nc")
-    rg = Regridder(source_grid=path, target_grid=tfile, method="nn")
+    rg = Regridder(source_grid=path, target_grid=tfile, method=method)
     ds = open_dataset(path)
     out = rg.regrid(ds)
     assert out["lsm"].shape == (180, 360) and out["lsm"].dims == ("lat", "lon")
@@ -788,7 +789,9 @@ def test_reduced_gaussian_grib_file_nearest_neighbour(hip):
     ref = oracle_2d(w, ds["lsm"].values.astype(np.float64).reshape(1, -1), masked=False)
     assert_same(out["lsm"].values.reshape(1, -1), ref, exact=True)
     y = out["lsm"].values
-    assert np.isin(y, ds["lsm"].values.astype(np.float64)).all() and (y[:8] > 0.999).all()     # Antarctica
+    assert (y[:8] > 0.999).all() and 0.0 <= y.min() and y.max() <= 1.0 + 1e-12                  # Antarctica
+    if method == "nn":
+        assert np.isin(y, ds["lsm"].values.astype(np.float64)).all()
     area = np.diff(np.sin(np.radians(np.linspace(-90, 90, 181))))[:, None] / 2 / 360
     assert (y * area).sum() == pytest.approx(0.29, abs=0.01)                                  # land share of the globe
 

@@ -200,3 +200,36 @@ def test_the_grid_of_the_grib_file_is_recognised_and_feeds_the_generator():
     assert w.sizes["num_links"] == 72 * 36 and w["src_grid_dims"].values.tolist() == [40320]
     y = ds["lsm"].values[w["src_address"].values - 1].reshape(36, 72)
     assert y[0].min() == 1.0 and y[:, 40].mean() < 0.2 and 0.2 < y.mean() < 0.45     # Antarctica, the date line, the globe
+
+
+def test_reduced_grid_cells_for_conservative_weights_and_areas():
+    """A reduced Gaussian grid implies its cells (latitude bands of the Gaussian weights x equal arcs of longitude): the
+    native generator builds them from the list of centres, so `con` and `areas()` work on the GRIB file as well
+    (CDO does the same for gridtype gaussian_reduced)."""
+    from smmregrid_amd import CdoGenerate, gridgen
+    ds = open_dataset(REF)
+    g = CdoGenerate._grid_of(ds)
+    assert g.cdo_type == "gaussian_reduced" and g.vertices[0].shape[0] == 40320
+    m = griblite.read_messages(REF)[0]
+    _, wg = np.polynomial.legendre.leggauss(192)
+    exact = np.repeat(2 * np.pi * wg[::-1] / m.pl, m.pl)                     # band area / points of the row
+    got = gridgen.polygon_areas(*g.vertices)
+    np.testing.assert_allclose(got, exact, rtol=5e-4)                         # parallels followed by <= 2-degree chords
+    area = CdoGenerate(ds, "r360x180", cdo="no-such-cdo-binary").areas()["cell_area"].values
+    assert area.shape == (40320,) and area.sum() / 1e6 == pytest.approx(5.101e8, rel=1e-3)      # areas_test.py:12
+    w = gridgen.generate_weights(g, "r180x90", method="con")
+    np.testing.assert_allclose(w["dst_grid_frac"].values, 1.0, atol=1e-12)   # no target sample falls between cells
+    d, s = w["dst_address"].values - 1, w["src_address"].values - 1
+    y = np.bincount(d, weights=w["remap_matrix"].values[:, 0] * ds["lsm"].values[s], minlength=180 * 90)
+    land_exact = (np.repeat(wg[::-1] / 2 / m.pl, m.pl) * ds["lsm"].values).sum()
+    assert (y * w["dst_grid_area"].values).sum() / (4 * np.pi) == pytest.approx(land_exact, abs=3e-4)
+    # lists that are no reduced grid: scattered points, rows with uneven spacing
+    rng = np.random.default_rng(1)
+    assert gridgen.reduced_grid_vertices(rng.uniform(0, 360, 50), rng.uniform(-90, 90, 50)) is None
+    lon = np.r_[0.0, 100.0, 200.0, 0.0, 90.0, 180.0, 270.0, 0.0, 120.0, 240.0]
+    lat = np.r_[[60.0] * 3, [0.0] * 4, [-60.0] * 3]
+    assert gridgen.reduced_grid_vertices(lon, lat) is None                    # first row is not evenly spaced
+    lon[1:3] = [120.0, 240.0]
+    lon_v, lat_v = gridgen.reduced_grid_vertices(lon, lat)                    # non-Gaussian rows: mid-point bands
+    assert lat_v[0].min() == 30.0 and lat_v[0].max() == 90.0 and lat_v[4].min() == -30.0 and lat_v[-1].min() == -90.0
+    np.testing.assert_allclose(gridgen.polygon_areas(lon_v, lat_v).sum(), 4 * np.pi, rtol=2e-2)
