@@ -210,10 +210,9 @@ def test_the_reference_fesom_mesh_to_one_degree():
     t = np.bincount(d, weights=w["remap_matrix"].values[:, 0] * z["temp"][0][s].astype(np.float64), minlength=frac.size)
     assert z["temp"][0].min() - 1e-9 <= t[frac > 0].min() and t.max() <= z["temp"][0].max() + 1e-9
     # the geometry is kept per target: a second mask costs no second search
-    import time
-    t0 = time.perf_counter()
+    (kept,) = src._overlap_cache.values()
     gridgen.generate_weights(src, "r360x180", method="con", src_mask=(z["temp"][2] != 0))
-    assert time.perf_counter() - t0 < 1.0
+    assert next(iter(src._overlap_cache.values())) is kept
 
 
 def write_fesom_like_file(path, z, nt=2):
