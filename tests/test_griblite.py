@@ -167,10 +167,10 @@ def test_round_trip_gaussian_grids_regular_and_reduced(tmp_path, rng):
 def test_what_is_not_decoded_says_so(tmp_path):
     good = encode(np.arange(12.0).reshape(3, 4), 0, 4, 3, 10, 0, -10, 30, 10000)
     bad = bytearray(good)
-    bad[7] = 2
-    p = tmp_path / "ed2.grb"
+    bad[7] = 3
+    p = tmp_path / "ed3.grb"
     p.write_bytes(bytes(bad))
-    with pytest.raises(griblite.GribUnsupported, match="edition 2"):
+    with pytest.raises(griblite.GribUnsupported, match="edition 3"):
         open_dataset(str(p))
     rot = bytearray(good)
     rot[8 + 28 + 5] = 10                                # rotated lon/lat
@@ -233,3 +233,136 @@ def test_reduced_grid_cells_for_conservative_weights_and_areas():
     lon_v, lat_v = gridgen.reduced_grid_vertices(lon, lat)                    # non-Gaussian rows: mid-point bands
     assert lat_v[0].min() == 30.0 and lat_v[0].max() == 90.0 and lat_v[4].min() == -30.0 and lat_v[-1].min() == -90.0
     np.testing.assert_allclose(gridgen.polygon_areas(lon_v, lat_v).sum(), 4 * np.pi, rtol=2e-2)
+
+
+# ---------------------------------------------------------------------------------------------- edition 2
+def section(number, body):
+    return (5 + len(body)).to_bytes(4, "big") + bytes([number]) + bytes(body)
+
+
+def encode2(fields, template=0, ni=0, nj=0, la1=0.0, lo1=0.0, la2=0.0, lo2=0.0, n_or_dj=0, pl=None, scan=0,
+            date=(2022, 5, 17, 6, 0, 0), discipline=0):
+    """A GRIB-2 message written from the section layout (WMO FM 92, edition 2): identification, one grid (template 3.0
+    or 3.40), then sections 4 - 7 once per field.  `fields`: dicts with values, category, number, and optionally
+    surface (type, value), step, nbits, decimal, bitmap, pdt."""
+    y, mo, d, h, mi, sec_ = date
+    s1 = (98).to_bytes(2, "big") + (0).to_bytes(2, "big") + bytes([27, 0, 1]) + y.to_bytes(2, "big") + \
+        bytes([mo, d, h, mi, sec_, 0, 1])
+    n_points = int(np.sum(pl)) if pl is not None else ni * nj
+    g = bytearray(58)                                    # template octets 15 .. 72
+    g[0] = 6
+    g[16:20] = (0xFFFFFFFF if pl is not None else ni).to_bytes(4, "big")
+    g[20:24] = nj.to_bytes(4, "big")
+    g[24:28], g[28:32] = (0).to_bytes(4, "big"), (0xFFFFFFFF).to_bytes(4, "big")
+    micro = lambda v: sm(int(round(v * 1e6)), 4)         # noqa: E731
+    g[32:36], g[36:40] = micro(la1), micro(lo1)
+    g[40] = 48
+    g[41:45], g[45:49] = micro(la2), micro(lo2)
+    g[49:53] = (0xFFFFFFFF).to_bytes(4, "big")
+    g[53:57] = int(n_or_dj).to_bytes(4, "big")
+    g[57] = scan
+    opt = b"" if pl is None else b"".join(int(p).to_bytes(2, "big") for p in pl)
+    s3 = bytes([0]) + n_points.to_bytes(4, "big") + bytes([2 if pl is not None else 0, 1 if pl is not None else 0]) + \
+        template.to_bytes(2, "big") + bytes(g) + opt
+    body = section(1, s1) + section(3, s3)
+    for f in fields:
+        vals = np.asarray(f["values"], dtype=np.float64).ravel()
+        bitmap = f.get("bitmap")
+        present = vals if bitmap is None else vals[np.asarray(bitmap, bool).ravel()]
+        nbits, decimal = f.get("nbits", 16), f.get("decimal", 0)
+        scaled = present * 10.0 ** decimal
+        ref = float(np.float32(np.floor(scaled.min())))
+        span = scaled.max() - ref
+        e = 0 if span == 0 else int(np.ceil(np.log2(span / ((1 << nbits) - 1))))
+        x = np.round((scaled - ref) / 2.0 ** e).astype(np.uint64)
+        bits = ((x[:, None] >> np.arange(nbits - 1, -1, -1, dtype=np.uint64)) & np.uint64(1)).astype(np.uint8).ravel()
+        data = np.packbits(bits).tobytes()
+        stype, svalue = f.get("surface", (1, 0))
+        s4 = (0).to_bytes(2, "big") + int(f.get("pdt", 0)).to_bytes(2, "big") + bytes([f["category"], f["number"], 2, 0, 0]) + \
+            (0).to_bytes(2, "big") + bytes([0, 1]) + int(f.get("step", 0)).to_bytes(4, "big") + \
+            bytes([stype, 0]) + sm(int(svalue), 4) + bytes([255, 255]) + (0xFFFFFFFF).to_bytes(4, "big")
+        s5 = present.size.to_bytes(4, "big") + (0).to_bytes(2, "big") + np.array(ref, dtype=">f4").tobytes() + \
+            sm(e, 2) + sm(decimal, 2) + bytes([nbits, 0])
+        s6 = bytes([255]) if bitmap is None else bytes([0]) + np.packbits(np.asarray(bitmap, np.uint8).ravel()).tobytes()
+        body += section(4, s4) + section(5, s5) + section(6, s6) + section(7, data)
+    body += b"7777"
+    return b"GRIB" + bytes([0, 0, discipline, 2]) + (16 + len(body)).to_bytes(8, "big") + body
+
+
+def test_edition_2_round_trip_lonlat_levels_bitmap_and_several_fields_per_message(tmp_path, rng):
+    ni, nj = 24, 13
+    lat, lon = np.linspace(90, -90, nj), np.arange(ni) * 15.0
+    grid = dict(template=0, ni=ni, nj=nj, la1=90.0, lo1=0.0, la2=-90.0, lo2=345.0, n_or_dj=15000000)
+    t = {lev: 220.0 + 40.0 * np.cos(np.radians(lat))[:, None] + rng.standard_normal((nj, ni)) + lev / 100.0
+         for lev in (85000, 50000)}
+    t2m = 280.0 + rng.standard_normal((nj, ni))
+    sst = 290.0 + rng.standard_normal((nj, ni))
+    sea = rng.random((nj, ni)) > 0.4
+    msg_a = encode2([dict(values=t[85000], category=0, number=0, surface=(100, 85000), nbits=20),
+                     dict(values=t[50000], category=0, number=0, surface=(100, 50000), nbits=20),
+                     dict(values=t2m, category=0, number=0, surface=(103, 2), nbits=12, decimal=1)], **grid)
+    msg_b = encode2([dict(values=sst, category=3, number=0, bitmap=sea, nbits=14)], discipline=10, **grid)
+    path = tmp_path / "mixed.grib2"
+    path.write_bytes(msg_a + msg_b)
+    ds = open_dataset(str(path))
+    assert ds.attrs["GRIB_edition"] == 2 and set(ds.data_vars) == {"t", "t2m", "sst"}
+    assert ds["t"].dims == ("isobaricInhPa", "latitude", "longitude")
+    assert ds["t"].coords["isobaricInhPa"].values.tolist() == [500.0, 850.0]                 # Pa -> hPa, sorted
+    np.testing.assert_allclose(ds["t"].values[1], t[85000], atol=50.0 / (1 << 20) * 2 + 4e-5)
+    np.testing.assert_allclose(ds["t"].values[0], t[50000], atol=50.0 / (1 << 20) * 2 + 4e-5)
+    np.testing.assert_allclose(ds["t2m"].values, t2m, atol=0.06)                              # one decimal
+    assert np.array_equal(np.isnan(ds["sst"].values), ~sea)
+    np.testing.assert_allclose(ds["sst"].values[sea], sst[sea], atol=8.0 / (1 << 14) + 4e-5)
+    np.testing.assert_allclose(ds.coords["latitude"].values, lat)
+    np.testing.assert_allclose(ds.coords["longitude"].values, lon)
+
+
+def test_edition_2_gaussian_regular_and_reduced_and_times(tmp_path, rng):
+    n = 8
+    lat = griblite.gaussian_latitudes(n)
+    pl = np.array([8, 12, 16, 20, 24, 28, 32, 36, 36, 32, 28, 24, 20, 16, 12, 8])
+    red = [rng.random(pl.sum()) for _ in range(3)]
+    msgs = [encode2([dict(values=red[k], category=0, number=0, discipline=2, step=6 * k)], template=40, nj=16,
+                    la1=lat[0], lo1=0.0, la2=lat[-1], lo2=348.75, n_or_dj=n, pl=pl, discipline=2) for k in range(3)]
+    p = tmp_path / "lsm_reduced.grib2"
+    p.write_bytes(b"".join(msgs))
+    ds = open_dataset(str(p))
+    assert ds["lsm"].dims == ("time", "values") and ds["lsm"].shape == (3, pl.sum())
+    assert np.diff(ds["lsm"].coords["time"].values).tolist() == [21600.0, 21600.0]          # steps of 6 h
+    np.testing.assert_allclose(ds["lsm"].values, np.stack(red), atol=2.0 / (1 << 16))
+    assert np.array_equal(ds.coords["latitude"].values, np.repeat(lat, pl))
+    from smmregrid_amd.gridmeta import GridInspector
+    assert GridInspector(ds).get_gridtype()[0].kind == "GaussianReduced"
+    reg = rng.random((16, 32))
+    p2 = tmp_path / "regular_gg.grib2"
+    p2.write_bytes(encode2([dict(values=reg[::-1], category=0, number=0)], template=40, ni=32, nj=16, la1=lat[-1], lo1=0.0,
+                           la2=lat[0], lo2=348.75, n_or_dj=n, scan=0x40, discipline=2))
+    ds2 = open_dataset(str(p2))
+    assert ds2["lsm"].attrs["GRIB_gridType"] == "regular_gg"
+    np.testing.assert_allclose(ds2.coords["latitude"].values, lat[::-1], atol=1e-6)
+    np.testing.assert_allclose(ds2["lsm"].values, reg[::-1], atol=2.0 / (1 << 16))
+
+
+def test_edition_2_says_what_it_does_not_decode(tmp_path):
+    base = dict(template=0, ni=4, nj=3, la1=10.0, lo1=0.0, la2=-10.0, lo2=30.0, n_or_dj=10000000)
+    good = encode2([dict(values=np.arange(12.0).reshape(3, 4), category=0, number=0)], **base)
+    assert open_dataset_bytes(tmp_path, good)["t"].shape == (3, 4)
+    sec3 = good.index(section(3, b"")[4:5], 16 + 21)                  # first byte "3" after section 1
+    rot = bytearray(good)
+    rot[16 + 21 + 12:16 + 21 + 14] = (1).to_bytes(2, "big")           # template 3.1: rotated lon/lat
+    with pytest.raises(griblite.GribUnsupported, match="template 3.1"):
+        open_dataset_bytes(tmp_path, bytes(rot))
+    ccsds = bytearray(good)
+    s5 = good.index(b"\x00\x00\x00\x15\x05")                          # section 5: length 21, number 5
+    ccsds[s5 + 9:s5 + 11] = (42).to_bytes(2, "big")
+    with pytest.raises(griblite.GribUnsupported, match="CCSDS"):
+        open_dataset_bytes(tmp_path, bytes(ccsds))
+    with pytest.raises(ValueError):
+        open_dataset_bytes(tmp_path, good[:-9])
+    assert sec3 > 0
+
+
+def open_dataset_bytes(tmp_path, raw):
+    p = tmp_path / "x.grib2"
+    p.write_bytes(raw)
+    return open_dataset(str(p))
