@@ -902,3 +902,26 @@ def test_regional_source_without_extrapolation(hip, rng):
     assert np.isfinite(y_on).all() and np.array_equal(np.isfinite(y_off[0]), inside)
     assert_same(y_off[:, inside], y_on[:, inside], exact=True)
     assert_same(y_off.reshape(2, -1), oracle_2d(w_off, x.reshape(2, -1)), exact=True)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int64, np.float16, np.uint8])
+def test_fields_of_other_dtypes_are_promoted_to_float64(hip, rng, dtype):
+    """regrid.py:550: the result type is result_type(field, float64) -- integer (packed, undecoded) and half-precision
+    fields regrid as their float64 values; 2-D and 3-D (level) paths."""
+    g = gridgen.parse_grid("r48x24")
+    raw = rng.integers(0, 200, size=(2, 3, 24, 48)).astype(dtype)
+    w = CdoGenerate("r48x24", "r24x12").weights(method="con")
+    f2 = DataArray(raw[:, 0], dims=("time", "lat", "lon"), coords={"time": np.arange(2), "lat": g.lat, "lon": g.lon}, name="v")
+    rg = Regridder(weights=w)
+    out = rg.regrid(f2)
+    assert out.values.dtype == np.float64
+    want = rg.regrid(DataArray(raw[:, 0].astype(np.float64), dims=f2.dims, coords=dict(f2.coords), name="v"))
+    assert_same(out.values, want.values, exact=True)
+    assert_same(out.values.reshape(2, -1), oracle_2d(w, raw[:, 0].astype(np.float64).reshape(2, -1)), exact=True)
+    f3 = DataArray(raw, dims=("time", "lev", "lat", "lon"),
+                   coords={"time": np.arange(2), "lev": np.array([1.0, 2.0, 3.0]), "lat": g.lat, "lon": g.lon}, name="v")
+    rg3 = Regridder(source_grid=f3, target_grid="r24x12", method="con")
+    o3 = rg3.regrid(f3)
+    w3 = rg3.regrid(DataArray(raw.astype(np.float64), dims=f3.dims, coords=dict(f3.coords), name="v"))
+    assert o3.values.dtype == np.float64 and o3.shape == (2, 3, 12, 24)
+    assert_same(o3.values, w3.values, exact=True)
