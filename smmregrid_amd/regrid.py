@@ -254,7 +254,18 @@ class Regridder(object):
     def regrid_array(self, source_data):
         """regrid.py:273-312."""
         source_data = from_xarray(source_data)
+        scalars = [name for name, coord in source_data.coords.items() if coord.dims == ()]
+        if scalars:                                   # regrid.py:288-294
+            self.loggy.warning("Found scalar coordinates %s. If have selected a along a masked dimensions,"
+                               "regridding might fail. Please consider subsetting with [] or with slice", scalars)
         datagridtype = GridType(dims=source_data.dims, extra_dims=self.extra_dims)
+        name = source_data.name or ''
+        is_bounds = (name.endswith('_bnds') or name.endswith('_bounds') or name == 'vertices') and 'time' not in name
+        if not (datagridtype.horizontal_dims or datagridtype.mask_dim) or is_bounds:
+            # GridInspector finds no grid in such a variable (spatial bounds are skipped, gridinspector.py:70-78; a grid
+            # without horizontal or mask dimension is cleaned away, :133-143 -- time_bnds(time, bnds) is one): nothing
+            # to regrid, and the empty result is dropped from a Dataset (regrid.py:308-312, :262-264)
+            return DataArray(data=None)
         if datagridtype.mask_dim:
             return self.regrid3d(source_data, datagridtype)
         return self.regrid2d(source_data, datagridtype)

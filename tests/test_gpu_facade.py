@@ -48,7 +48,11 @@ def test_regrid_dataarray_and_dataset(hip, rng, method):
     ds = Dataset({"tas": field, "time_bnds": DataArray(np.zeros((4, 2)), dims=("time", "bnds"), name="time_bnds")})
     outds = rg.regrid(ds)
     assert outds["tas"].shape == (4, 18, 36)
-    assert outds["time_bnds"].shape == (4, 2)                   # time bounds are passed through
+    # time_bnds(time, bnds) has neither a horizontal nor a mask dimension: GridInspector cleans its grid away
+    # (gridinspector.py:133-143), regrid_array returns the empty DataArray and regrid() drops it (regrid.py:262-264);
+    # apply_weights itself hands a time-bounds variable back unchanged (regrid.py:482-487)
+    assert list(outds.data_vars) == ["tas"]
+    assert rg.apply_weights(ds["time_bnds"], w).shape == (4, 2)
 
 
 @pytest.mark.parametrize("method", ["con", "nn", "bic"])
@@ -925,3 +929,27 @@ def test_fields_of_other_dtypes_are_promoted_to_float64(hip, rng, dtype):
     w3 = rg3.regrid(DataArray(raw.astype(np.float64), dims=f3.dims, coords=dict(f3.coords), name="v"))
     assert o3.values.dtype == np.float64 and o3.shape == (2, 3, 12, 24)
     assert_same(o3.values, w3.values, exact=True)
+
+
+def test_variables_without_a_grid_are_dropped_from_a_dataset(hip, rng, caplog):
+    """regrid.py:297-312 + gridinspector.py:139-143: a variable that has no horizontal dimension (a time series, a
+    scalar, time bounds) defines no grid -- regrid_array returns the empty DataArray and Dataset.regrid drops it; a
+    field with a scalar coordinate regrids with the reference's warning."""
+    field = tas_field(rng, nt=3)
+    w = CdoGenerate("r96x48", "r36x18").weights(method="nn")
+    ds = Dataset({"tas": field,
+                  "gmean": DataArray(np.arange(3.0), dims=("time",), name="gmean"),
+                  "height": DataArray(np.array(2.0), dims=(), name="height"),
+                  "time_bnds": DataArray(np.zeros((3, 2)), dims=("time", "bnds"), name="time_bnds"),
+                  "lat_bnds": DataArray(np.zeros((48, 2)), dims=("lat", "bnds"), name="lat_bnds")})
+    rg = Regridder(weights=w)
+    out = rg.regrid(ds)
+    assert set(out.data_vars) == {"tas"} and out["tas"].shape == (3, 18, 36)
+    assert rg.regrid_array(ds["gmean"]).dims == () and rg.regrid_array(ds["lat_bnds"]).dims == ()
+    assert rg.grids[0].horizontal_dims == ["lat", "lon"] or set(rg.grids[0].horizontal_dims) == {"lat", "lon"}
+    one = field.isel(time=0)
+    one.coords["time"] = DataArray(np.array(0.0), dims=())
+    import logging
+    with caplog.at_level(logging.WARNING):
+        y = rg.regrid(one)
+    assert y.shape == (18, 36) and any("scalar coordinates" in r.message for r in caplog.records)
