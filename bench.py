@@ -114,8 +114,8 @@ def parse_args():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="override the batch rows per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "sell", "tile"])
-    ap.add_argument("--variant", type=int, default=0, help="kernel variant knob (0 = default)")
-    ap.add_argument("--jpb", type=int, default=0, help="tile kernel: batch rows per workgroup")
+    ap.add_argument("--tune", default="", help="tuning knobs for A/B runs, e.g. tile_walk=64,xcd_run=8 "
+                                               "(smm_debug_set_tuning; names in smmregrid_amd/_lib.py TUNE_KNOBS)")
     ap.add_argument("--gather", default="root", choices=["root", "none"],
                     help="N>1: also time the steps followed by the RCCL gather of the Y shards to rank 0")
     ap.add_argument("--gather-tiles", type=int, default=8,
@@ -743,7 +743,7 @@ def traffic_entry(args, workload, batch):
     are the ones the PMC pass ran (sha recorded by tools/summarize_pmc.py); else null."""
     if not (args.traffic_json and os.path.exists(args.traffic_json)):
         return None, None
-    key = f"{workload}/{batch or 'default'}/{args.kernel}/{args.variant}"
+    key = f"{workload}/{batch or 'default'}/{args.kernel}/{args.tune or 0}"
     entry = json.load(open(args.traffic_json)).get(key)
     if not entry:
         return None, None
@@ -1081,7 +1081,8 @@ def main():
         prob = cls(args.workload, local_rank, rank, batch=args.batch)
         y = DeviceArray(prob.y_shape, getattr(prob, "y_dt", np.float64))
         flags = {"auto": 0, "sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE}[args.kernel]
-        flags |= (args.variant << 16) | (args.jpb << 20)
+        for kv in [kv for kv in args.tune.split(",") if kv]:      # process-wide, for the whole run
+            _lib.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
         new_event, dev_name = Event, device_name(local_rank)
     runner = Runner(rdv, new_event, synchronize)
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SMM_ABI_VERSION 4
+#define SMM_ABI_VERSION 5
 
 /* status codes */
 enum {
@@ -66,15 +66,6 @@ enum {
   SMM_APPLY_KERNEL_SELL = 1u << 8, /* force the row-per-lane SELL-64 kernel                  */
   SMM_APPLY_KERNEL_TILE = 1u << 9  /* force the LDS-staged source-tile kernel (if planned)   */
 };
-/* tuning knobs for benchmarks (0 = library default; results are identical for every value):
- * kernel variant in bits 16..19 -- tile kernel: 3 / 4 non-temporal / cached X loads, 10 / 9 / 11 LDS-DMA staging
- * forced with one / two / four batch rows per step, 8 register staging forced,
- * 6 dispatcher block order instead of runs of 32 consecutive blocks per XCD (7 / 13: runs of
- * 8 / 128), 12 single-row steps on small tiles; SELL kernel: 1 / 2 = 8 / 2 batch rows per thread -- and the batch rows walked per
- * workgroup of the tile kernel in bits 20..27 */
-#define SMM_APPLY_VARIANT_SHIFT 16
-#define SMM_APPLY_JPB_SHIFT 20
-
 typedef struct smm_operator* smm_operator_t; /* one (S x D) weights matrix resident in HBM      */
 typedef struct smm_group* smm_group_t;       /* ordered set of operators (one per masked level) */
 
@@ -341,6 +332,26 @@ int smm_debug_fail_at_chunk(int64_t chunk);
  * range, then of the inner one; smm_apply_sb: runs of whole 128-entry batch tiles).  This test hook lowers
  * that limit so that small inputs reach the split path; 0 restores the default.  Process-wide; for tests only. */
 int smm_debug_set_grid_limit(int64_t max_blocks);
+
+/* Tuning knobs of tests, tools and benchmarks -- NOT part of the apply flags, product callers never set them.
+ * Every knob only changes how a launch is shaped (which kernel form, how many rows per workgroup, which stream);
+ * the results are bit-identical for every value.  value 0 restores the library's own choice; *previous (may be
+ * NULL) receives the former value.  Process-wide; set them while no apply call is in flight. */
+enum {
+  SMM_TUNE_SELL_BATCH_ROWS = 0, /* row-per-lane kernel: batch rows per thread (2, 4, 8)                         */
+  SMM_TUNE_TILE_WALK,           /* tile kernel: batch rows walked by one workgroup                             */
+  SMM_TUNE_TILE_STAGING,        /* tile kernel: 1 = source tiles staged through registers, 2 = by LDS-DMA      */
+  SMM_TUNE_TILE_ROWS_PER_STEP,  /* tile kernel, small tiles: batch rows staged per step (1, 2, 4)              */
+  SMM_TUNE_TILE_X_LOADS,        /* tile kernel: 1 = non-temporal, 2 = cached loads of X                        */
+  SMM_TUNE_TILE_SPLIT_ROWS,     /* tile kernel, part-of-a-slice blocks: 1 = rows are not split over lane groups */
+  SMM_TUNE_TILE_LINKS,          /* single-wave tile kernel: 1 = links streamed per batch row, not kept in registers */
+  SMM_TUNE_XCD_RUN,             /* tile + batch-fastest kernels: consecutive blocks per XCD (-1 = dispatcher order) */
+  SMM_TUNE_SB_STRIP,            /* batch-fastest kernel: destination tiles per strip (-1 = whole-grid order)   */
+  SMM_TUNE_SB_LOADS,            /* batch-fastest kernel: loads per batch of the link walk (4, 8)               */
+  SMM_TUNE_SB_POOL_STREAMS,     /* smm_group_apply_sb: streams of the level pool (-1 = the caller's stream only) */
+  SMM_TUNE_COUNT
+};
+int smm_debug_set_tuning(int knob, int value, int* previous);
 
 /* Host threads of operator creation (the sort / duplicate sum replacing weights.py:25-44, the SELL layout and
  * the tile plans are built on several cores): n > 0 fixes the count, 0 (the initial state) = automatic -- the

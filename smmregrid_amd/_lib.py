@@ -29,6 +29,12 @@ CREATE_PRUNE_ZEROS = 1 << 0
 APPLY_KERNEL_SELL = 1 << 8
 APPLY_KERNEL_TILE = 1 << 9
 
+# smm_debug_set_tuning knobs (tests, tools, benchmarks; the results do not depend on them)
+TUNE_KNOBS = ("sell_batch_rows", "tile_walk", "tile_staging", "tile_rows_per_step", "tile_x_loads",
+              "tile_split_rows", "tile_links", "xcd_run", "sb_strip", "sb_loads", "sb_pool_streams")
+TUNE = {name: i for i, name in enumerate(TUNE_KNOBS)}
+STAGING_REGISTERS, STAGING_DMA = 1, 2
+
 
 class SmmError(RuntimeError):
     """A libsmmregrid_hip call failed (status code in .code)."""
@@ -109,6 +115,7 @@ SIGNATURES = {
     "smm_group_apply_host": [_p, _p, _int, _p, _int, _i64, _i64, _i64, _int, _p, _p, _dbl, _uint, _i64],
     "smm_debug_fail_at_chunk": [_i64],
     "smm_debug_set_grid_limit": [_i64],
+    "smm_debug_set_tuning": [_int, _int, ctypes.POINTER(_int)],
     "smm_set_host_threads": [_int, ctypes.POINTER(_int)],
     "smm_comm_unique_id": [_p],
     "smm_comm_create": [_p, _int, _int, _pp],
@@ -180,3 +187,30 @@ def device_count():
         return 0
     check(status)
     return n.value
+
+
+def set_tuning(knob, value):
+    """smm_debug_set_tuning: one named knob (TUNE_KNOBS), 0 = the library's own choice.  Returns the former value."""
+    prev = _int(0)
+    call("smm_debug_set_tuning", TUNE[knob] if isinstance(knob, str) else int(knob), int(value), ctypes.byref(prev))
+    return prev.value
+
+
+class tuning:
+    """`with tuning(tile_staging=STAGING_DMA, tile_rows_per_step=2): ...` -- knobs set for the block, restored after."""
+
+    def __init__(self, **knobs):
+        unknown = [k for k in knobs if k not in TUNE]
+        if unknown:
+            raise KeyError(f"unknown tuning knob(s) {unknown}; known: {TUNE_KNOBS}")
+        self.knobs, self.prev = knobs, {}
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            self.prev[k] = set_tuning(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_tuning(k, v)
+        return False

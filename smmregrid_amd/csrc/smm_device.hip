@@ -61,8 +61,14 @@ int fail(int code, const std::string& msg) {
 
 }  // namespace
 
+namespace {
+// smm_debug_set_tuning: process-wide knobs of tests / tools / benchmarks, 0 = the library's own choice
+std::atomic<int> g_tuning[SMM_TUNE_COUNT];
+}  // namespace
+
 namespace smm {
 int fail_msg(int code, const std::string& msg) { return fail(code, msg); }  // for smm_comm.cpp
+int tuning(int knob) { return (knob >= 0 && knob < SMM_TUNE_COUNT) ? g_tuning[knob].load(std::memory_order_relaxed) : 0; }
 }
 
 namespace {
@@ -436,8 +442,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
       info_only->dma = c.dma;
       info_only->rows_per_block = (int)shape_rows(tile_which);
     } else {
-      const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
-      const int bt = (a.n_j >= 8 && variant == 1) ? 8 : ((a.n_j >= 4 && variant <= 1) ? 4 : (a.n_j >= 2 ? 2 : 1));
+      const int bt = smm_launch::sell_batch_rows(a.n_j);
       info_only->j_per_block = bt;
       info_only->n_jtiles = (a.n_j + bt - 1) / bt;
       info_only->n_blocks = a.n_dblocks * info_only->n_jtiles * n_lev;
@@ -454,8 +459,7 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
     t.n_inner = n_i;
     if (use_tile)
       return smm_launch::tile_launch_cfg(t, n_lev, tile_which, tile_max_chunks, max_row_nnz, flags, xsz).total;
-    const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
-    const int bt = (t.n_j >= 8 && variant == 1) ? 8 : ((t.n_j >= 4 && variant <= 1) ? 4 : (t.n_j >= 2 ? 2 : 1));
+    const int bt = smm_launch::sell_batch_rows(t.n_j);
     return t.n_dblocks * ((t.n_j + bt - 1) / bt) * n_lev;
   };
   const size_t ysz = y_dtype == SMM_F64 ? 8 : 4;
@@ -675,6 +679,13 @@ int smm_memcpy2d_d2h(void* dst, size_t dpitch, const void* src, size_t spitch, s
 int smm_debug_set_grid_limit(int64_t max_blocks) {
   if (max_blocks < 0) return fail(SMM_ERR_INVALID, "negative grid limit");
   g_grid_limit.store(max_blocks == 0 || max_blocks > 0x7fffffffLL ? 0x7fffffffLL : max_blocks);
+  return SMM_OK;
+}
+
+int smm_debug_set_tuning(int knob, int value, int* previous) {
+  if (knob < 0 || knob >= SMM_TUNE_COUNT) return fail(SMM_ERR_INVALID, "unknown tuning knob " + std::to_string(knob));
+  const int prev = g_tuning[knob].exchange(value);
+  if (previous) *previous = prev;
   return SMM_OK;
 }
 
@@ -1469,10 +1480,12 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
     int vrc = check_sb_levels(g, n_lev, level_index, masked_levels, remap_area_min, flags);
     if (vrc) return vrc;
   }
-  // One launch per data level (see smm_group: the stream pool).  Tuning variants: 12 = all levels on the
-  // caller's stream (the round-3 form), 9 / 11 = 4 / 16 pool streams instead of 8.
-  const unsigned variant = (flags >> SMM_APPLY_VARIANT_SHIFT) & 0xFu;
-  const int n_pool = (n_lev < 2 || variant == 12) ? 0 : (int)std::min<int64_t>(n_lev, variant == 9 ? 4 : (variant == 11 ? 16 : 8));
+  // One launch per data level (see smm_group: the stream pool).  SMM_TUNE_SB_POOL_STREAMS: -1 = all levels on
+  // the caller's stream (the round-3 form), n = that many pool streams instead of 8.
+  const int pool_knob = smm::tuning(SMM_TUNE_SB_POOL_STREAMS);
+  const int n_pool = (n_lev < 2 || pool_knob < 0)
+                         ? 0
+                         : (int)std::min<int64_t>(n_lev, std::min(pool_knob > 0 ? pool_knob : 8, (int)smm_group::kSbStreams));
   hipStream_t caller = (hipStream_t)stream;
   DeviceGuard guard(g->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
@@ -1480,30 +1493,52 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
   if (n_pool > 0) {
     pool_lock.lock();
     if (!g->sb_pool_ready) {
+      // every stream / event is created once: a call that failed half-way leaves what it made for the next one
       for (int i = 0; i < smm_group::kSbStreams; ++i) {
-        SMM_HIP(hipStreamCreateWithFlags(&g->sb_stream[i], hipStreamNonBlocking));
-        SMM_HIP(hipEventCreateWithFlags(&g->sb_join[i], hipEventDisableTiming));
+        if (!g->sb_stream[i]) SMM_HIP(hipStreamCreateWithFlags(&g->sb_stream[i], hipStreamNonBlocking));
+        if (!g->sb_join[i]) SMM_HIP(hipEventCreateWithFlags(&g->sb_join[i], hipEventDisableTiming));
       }
-      SMM_HIP(hipEventCreateWithFlags(&g->sb_fork, hipEventDisableTiming));
+      if (!g->sb_fork) SMM_HIP(hipEventCreateWithFlags(&g->sb_fork, hipEventDisableTiming));
       g->sb_pool_ready = true;
     }
-    SMM_HIP(hipEventRecord(g->sb_fork, caller));                 // fork: the pool starts after the caller's queue
-    for (int i = 0; i < n_pool; ++i) SMM_HIP(hipStreamWaitEvent(g->sb_stream[i], g->sb_fork, 0));
   }
   int status = SMM_OK;
+  hipError_t herr = hipSuccess;
+  const char* hwhat = "";
+  auto note = [&](hipError_t e, const char* what) {
+    if (e != hipSuccess && herr == hipSuccess) {
+      herr = e;
+      hwhat = what;
+    }
+    return e == hipSuccess;
+  };
+  int n_forked = 0;   // pool streams that wait for the fork event: exactly these are joined below
+  if (n_pool > 0 && note(hipEventRecord(g->sb_fork, caller), "hipEventRecord(fork)")) {   // the pool starts after the caller's queue
+    for (; n_forked < n_pool; ++n_forked)
+      if (!note(hipStreamWaitEvent(g->sb_stream[n_forked], g->sb_fork, 0), "hipStreamWaitEvent(fork)")) break;
+  }
+  const bool fork_failed = n_pool > 0 && n_forked < n_pool;
+  if (fork_failed) status = SMM_ERR_HIP;     // nothing is launched on a half-forked pool
   for (int64_t l = 0; l < n_lev && status == SMM_OK; ++l) {
     const int w = level_index[l];
     unsigned fl = flags & ~(unsigned)SMM_APPLY_MASKED;
     if ((flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w])) fl |= SMM_APPLY_MASKED;   // regrid.py:405
-    if (variant == 9 || variant == 11 || variant == 12) fl &= ~(0xFu << SMM_APPLY_VARIANT_SHIFT);       // knobs of this loop only
     status = smm_apply_sb(g->ops[(size_t)w], (const char*)x + (size_t)l * xs_lev * xsz, x_dtype, ldx,
                           (char*)y + (size_t)l * ys_lev * ysz, y_dtype, ys_batch, n_batch, remap_area_min, fl,
                           n_pool > 0 ? g->sb_stream[l % n_pool] : caller);
   }
-  // join: whatever was queued on the pool -- also after a failing level -- is waited for by the caller's stream
-  for (int i = 0; i < n_pool; ++i) {
-    SMM_HIP(hipEventRecord(g->sb_join[i], g->sb_stream[i]));
-    SMM_HIP(hipStreamWaitEvent(caller, g->sb_join[i], 0));
+  // join: whatever was queued on the pool -- also after a failing level or a failing HIP call -- is waited for by
+  // the caller's stream; a stream that cannot be joined by an event is drained on the host instead, so nothing
+  // is still writing Y when the call returns an error
+  for (int i = 0; i < n_forked; ++i) {
+    const bool joined = note(hipEventRecord(g->sb_join[i], g->sb_stream[i]), "hipEventRecord(join)") &&
+                        note(hipStreamWaitEvent(caller, g->sb_join[i], 0), "hipStreamWaitEvent(join)");
+    if (!joined) (void)hipStreamSynchronize(g->sb_stream[i]);
+  }
+  if (herr != hipSuccess) {
+    (void)hipGetLastError();
+    // a level's own failure keeps its status and message; a fork / join failure is reported as such
+    if (status == SMM_OK || fork_failed) return fail(SMM_ERR_HIP, std::string(hwhat) + ": " + hipGetErrorString(herr));
   }
   return status;
 }

@@ -38,9 +38,25 @@ def test_ctypes_table_matches_header():
     assert table == set(declared_symbols())
 
 
+def test_tuning_knobs_match_the_header_and_are_not_apply_flags():
+    """ABI v5: the tuning knobs are named entries of smm_debug_set_tuning's enum, in the order of _lib.TUNE_KNOBS;
+    the apply flags carry no variant / walk-length bit fields any more."""
+    text = open(HEADER).read()
+    names = re.findall(r"\b(SMM_TUNE_[A-Z_]+)\b\s*(?:=\s*0)?\s*,", text)
+    assert [n[len("SMM_TUNE_"):].lower() for n in names] == list(_lib.TUNE_KNOBS)
+    assert "SMM_APPLY_VARIANT_SHIFT" not in text and "SMM_APPLY_JPB_SHIFT" not in text
+    lib = _lib.load()
+    prev = ctypes.c_int(-7)
+    assert lib.smm_debug_set_tuning(_lib.TUNE["tile_walk"], 5, ctypes.byref(prev)) == 0 and prev.value == 0
+    assert lib.smm_debug_set_tuning(_lib.TUNE["tile_walk"], 0, ctypes.byref(prev)) == 0 and prev.value == 5
+    assert lib.smm_debug_set_tuning(len(_lib.TUNE_KNOBS), 1, None) == _lib.SMM_ERR_INVALID
+    with pytest.raises(KeyError):
+        _lib.tuning(no_such_knob=1)
+
+
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.smm_abi_version() == 4
+    assert lib.smm_abi_version() == 5
     assert isinstance(lib.smm_last_error(), (bytes, type(None)))
 
 

@@ -118,10 +118,11 @@ def test_config4_geometry_f32(hip):
     y = _check_2d(op, x, host, [0, 1, 127, 128, 129], False, 0.0, None, None)
     assert y.dtype == np.float64                               # result_type(f32, f64), regrid.py:550
     # register staging with multi-row steps (R = 2 or 4) serves fields that are not 16-B aligned and is
-    # what tuning variant 8 forces: same bits
-    info8 = op.launch_info(B, np.float32, flags=8 << 16)
-    assert info8["kernel"] == "tile" and info8["rows_per_step"] > 1
-    _assert_device_equal(op.apply(x, flags=8 << 16), y)
+    # what the tuning knob tile_staging = 1 forces: same bits
+    with _lib.tuning(tile_staging=_lib.STAGING_REGISTERS):
+        info8 = op.launch_info(B, np.float32)
+        assert info8["kernel"] == "tile" and info8["rows_per_step"] > 1
+        _assert_device_equal(op.apply(x), y)
     # a short batch takes the same kernels with a clipped walk
     x8 = x.rows(0, 8)
     y8 = op.apply(x8)

@@ -1,5 +1,5 @@
 """Tile kernel with LDS-DMA staging (global_load_lds_dwordx4 into a two-slot ring; the default for small
-tiles of aligned fields, forced by tuning variant 10, switched off by 8 / 12): bit-identical to the
+tiles of aligned fields, forced by the tuning knob tile_staging = 2, switched off by 1): bit-identical to the
 register-staged kernel and to the oracle."""
 import numpy as np
 import pytest
@@ -9,7 +9,13 @@ from smmregrid_amd import SparseOperator, _lib, gridgen, to_device
 from tests.helpers import assert_same, field
 
 pytestmark = pytest.mark.gpu
-T, DMA = _lib.APPLY_KERNEL_TILE, _lib.APPLY_KERNEL_TILE | (10 << 16)
+T = _lib.APPLY_KERNEL_TILE
+REG, DMA = _lib.STAGING_REGISTERS, _lib.STAGING_DMA
+# staging form x rows per step x walk length (smm_debug_set_tuning knobs; {} = the library's own choice)
+KNOBS = [{}, dict(tile_staging=DMA, tile_rows_per_step=1), dict(tile_staging=DMA, tile_rows_per_step=1, tile_walk=3),
+         dict(tile_staging=REG), dict(tile_staging=REG, tile_rows_per_step=1), dict(tile_staging=DMA, tile_rows_per_step=2),
+         dict(tile_staging=DMA, tile_rows_per_step=4), dict(tile_staging=DMA, tile_rows_per_step=2, tile_walk=3),
+         dict(tile_staging=DMA, tile_rows_per_step=4, tile_walk=5)]
 
 
 @pytest.mark.parametrize("method,src,dst", [("bil", "r360x180", "r90x45"), ("con", "r360x180", "r180x90"),
@@ -27,7 +33,7 @@ def test_dma_staging_matches_oracle(hip, rng, method, src, dst, dtype):
     for n_batch in (1, 5, 70):
         x = field(rng, n_batch, op.n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.003)
         ref = oracle.apply_c(op.export_csr(), x, True, imask, w["dst_grid_frac"].values, 0.5)
-        for fl in (T, DMA, DMA | (3 << 20), T | (8 << 16), T | (12 << 16), T | (9 << 16), T | (11 << 16),
-                   T | (9 << 16) | (3 << 20), T | (11 << 16) | (5 << 20)):
-            y = op.apply(to_device(x), masked=True, remap_area_min=0.5, flags=fl).to_host()
+        for knobs in KNOBS:
+            with _lib.tuning(**knobs):
+                y = op.apply(to_device(x), masked=True, remap_area_min=0.5, flags=T).to_host()
             assert_same(y, ref, exact=True)

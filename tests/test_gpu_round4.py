@@ -154,14 +154,15 @@ def test_levels_created_by_worker_threads_match_serial_creation(hip, rng):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_dma_request_on_unaligned_fields_falls_back_bit_equal(hip, rng, dtype):
-    """Variant 10 asks for LDS-DMA staging, which moves aligned 16-B pieces.  A field whose base or row pitch
+    """The tuning knob tile_staging = 2 asks for LDS-DMA staging, which moves aligned 16-B pieces.  A field whose base or row pitch
     is not a multiple of 16 B must take the register-staged kernel (the DMA kernel skips the piece rotation
     such rows need): launch_info -- which assumes an aligned field -- says tile-dma, the results of the odd
     base / odd pitch fields equal the oracle bit for bit."""
     w = gridgen.generate_weights("r360x180", "r90x45", method="bil")
     op = _operator(w)
     op.set_epilogue(None, w["dst_grid_frac"].values)
-    assert op.launch_info(12, dtype, flags=T | (10 << 16))["kernel"] == "tile-dma"
+    with _lib.tuning(tile_staging=_lib.STAGING_DMA, tile_rows_per_step=1):
+        assert op.launch_info(12, dtype, flags=T)["kernel"] == "tile-dma"
     S = op.n_src
     n_batch = 12
     for pitch, offset in ((S + 1, 0), (S, 1), (S + 3, 1), (S + (16 // np.dtype(dtype).itemsize), 0)):
@@ -173,8 +174,10 @@ def test_dma_request_on_unaligned_fields_falls_back_bit_equal(hip, rng, dtype):
         buf.copy_from_host(host)
         xv = DeviceArray((n_batch, pitch), dtype, ptr=buf.ptr + offset * np.dtype(dtype).itemsize, base=buf)
         ref = oracle.apply_c(op.export_csr(), x, False, None, w["dst_grid_frac"].values, 0.5)
-        for fl in (T | (10 << 16), T | (9 << 16), T):
-            y = op.apply(xv, remap_area_min=0.5, flags=fl).to_host()
+        for knobs in (dict(tile_staging=_lib.STAGING_DMA, tile_rows_per_step=1),
+                      dict(tile_staging=_lib.STAGING_DMA, tile_rows_per_step=2), {}):
+            with _lib.tuning(**knobs):
+                y = op.apply(xv, remap_area_min=0.5, flags=T).to_host()
             assert_same(y, ref, exact=True)
         buf.free()
 
@@ -182,7 +185,7 @@ def test_dma_request_on_unaligned_fields_falls_back_bit_equal(hip, rng, dtype):
 def test_group_sb_levels_over_the_stream_pool(hip, rng):
     """smm_group_apply_sb deals its per-level launches over a pool of streams forked from / joined to the
     caller's stream.  Same bits with 4 / 8 / 16 pool streams and with all levels on the caller's stream
-    (tuning variants 9 / default / 11 / 12); on a caller stream of its own the call is ordered between the
+    (tuning knob sb_pool_streams = 4 / default / 16 / -1); on a caller stream of its own the call is ordered between the
     upload queued before it and the download queued after it; repeated calls reuse the pool."""
     from smmregrid_amd.device import Stream
     S, D, n_ops, B = 1100, 260, 7, 50
@@ -203,9 +206,10 @@ def test_group_sb_levels_over_the_stream_pool(hip, rng):
     ref = oracle.apply_levels(csrs, x, 1, level_index, ml.astype(bool), imask, frac, 0.4, True)   # (B, 1, L, D)
     x_sb = np.ascontiguousarray(np.transpose(x[:, :, 0, :], (1, 2, 0)))                            # (L, S, B)
     xd = to_device(x_sb)
-    for variant in (0, 9, 11, 12):
+    for pool in (0, 4, 16, -1):
         for _ in range(2):
-            y = grp.apply_sb(xd, level_index, ml, masked=True, remap_area_min=0.4, flags=variant << 16).to_host()
+            with _lib.tuning(sb_pool_streams=pool):
+                y = grp.apply_sb(xd, level_index, ml, masked=True, remap_area_min=0.4).to_host()
             assert_same(y.reshape(ref.shape), ref, exact=True)
     # a caller stream of its own: H2D, apply, D2H all queued on it, one synchronisation at the end
     st = Stream()

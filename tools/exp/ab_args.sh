@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of bench argument sets for one workload; each set is one quoted string:
-#   bash tools/exp/ab_args.sh cfg3 "--jpb 64" "--jpb 120"        (the environment is inherited)
+#   bash tools/exp/ab_args.sh cfg3 "--tune tile_walk=64" "--tune tile_walk=120"        (the environment is inherited)
 wl=$1; shift
 out=gpurun_out/ab_args_$wl
 rm -rf $out; mkdir -p $out

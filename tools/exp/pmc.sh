@@ -1,5 +1,5 @@
 # a few derived counters for one workload: bash tools/exp/pmc.sh cfg3 "LDSBankConflict MemUnitStalled" "VALUBusy SALUBusy" ...
-# extra bench arguments (e.g. a tuning variant) through SMM_BENCH_ARGS="--variant 10"
+# extra bench arguments (e.g. tuning knobs) through SMM_BENCH_ARGS="--tune tile_staging=2"
 set -e
 export TMPDIR=/tmp
 root=$PWD

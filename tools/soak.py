@@ -35,15 +35,19 @@ for seed in range(n):
     x = field(rng, int(rng.integers(1, 70)), n_src, dtype=dtype, nan_frac=0.03, inf_frac=0.003)
     amin = float(rng.choice([0.0, 0.5])); masked = bool((seed // 8) % 2)
     ref = oracle.apply_c(csr, x, masked, imask, frac, amin)
-    ks = [0, _lib.APPLY_KERNEL_SELL]
+    ks = [(0, {}), (_lib.APPLY_KERNEL_SELL, {})]
     if op.plan_info()["tile_plan"]:
-        # default tile kernel, other block orders, single-row steps, odd walk lengths (tails of multi-row steps)
+        # default tile kernel, other block orders, single-row steps, odd walk lengths (tails of multi-row steps),
+        # LDS-DMA staging forced wherever the field is 16-B aligned, register staging forced
         t = _lib.APPLY_KERNEL_TILE
-        # (10: LDS-DMA staging forced wherever the field is 16-B aligned, 8: register staging forced)
-        ks += [t, t | (6 << 16), t | (7 << 16), t | (13 << 16), t | (12 << 16), t | (15 << 16), t | (10 << 16),
-               t | (8 << 16), t | (10 << 16) | (3 << 20)] + [t | (j << 20) for j in (1, 3, 5, 7)]
+        ks += [(t, k) for k in ({}, dict(xcd_run=-1), dict(xcd_run=8), dict(xcd_run=128),
+                                dict(tile_staging=1, tile_rows_per_step=1), dict(tile_split_rows=1),
+                                dict(tile_staging=2, tile_rows_per_step=1), dict(tile_staging=1),
+                                dict(tile_staging=2, tile_rows_per_step=1, tile_walk=3))]
+        ks += [(t, dict(tile_walk=j)) for j in (1, 3, 5, 7)]
     dx = to_device(x)
-    for fl in ks:
+    for fl, knobs in ks:
+      with _lib.tuning(**knobs):
         for rep in range(3):
             # round 4: every third repetition with a launch-grid limit a few parts below the grid the batch needs
             if rep == 2:
@@ -54,7 +58,7 @@ for seed in range(n):
             same = np.array_equal(np.isnan(y), np.isnan(ref)) and np.array_equal(y[~np.isnan(y)], ref[~np.isnan(ref)])
             _lib.call("smm_debug_set_grid_limit", 0)
             if not same:
-                bad += 1; print("MISMATCH seed", seed, "flags", fl, "rep", rep, flush=True)
+                bad += 1; print("MISMATCH seed", seed, "flags", fl, knobs, "rep", rep, flush=True)
     # batch-fastest entry point (full and packed X) and the host pipeline (packing when the operator qualifies)
     xt = np.ascontiguousarray(x.T)
     for packed in (False, True):

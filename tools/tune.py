@@ -2,9 +2,9 @@
 """Interleaved A/B timing of kernel variants in ONE process (HIP events, median/min).
 
   python tools/tune.py --workload cfg2 --batch 3600 --rounds 7 \
-      --variants sell:0:0 tile:1:16 tile:2:16 tile:3:16 tile:2:32
+      --variants sell tile:tile_walk=16 tile:tile_walk=16,tile_x_loads=1 tile:tile_staging=2,tile_rows_per_step=1
 
-variant = kernel:variant:j_per_block (0 = library default).
+variant = kernel[:knob=value,...] with the named knobs of smm_debug_set_tuning (smmregrid_amd/_lib.py: TUNE_KNOBS).
 """
 import argparse
 import json
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--variants", nargs="+", default=["sell:0:0", "tile:1:16", "tile:2:16", "tile:3:16"])
+    ap.add_argument("--variants", nargs="+", default=["sell", "tile", "tile:tile_walk=16", "tile:tile_x_loads=1"])
     ap.add_argument("--check", action="store_true", help="compare every variant's Y with the first one")
     args = ap.parse_args()
     method, sgrid, tgrid, n_batch, x_dtype = WORKLOADS[args.workload]
@@ -51,14 +51,17 @@ def main():
     print("plan:", op.plan_info(), "nnz", op.nnz, "U", op.n_used_src, file=sys.stderr)
 
     def flags_of(v):
-        kern, var, jpb = v.split(":")
-        f = {"sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE, "auto": 0}[kern]
-        return f | (int(var) << 16) | (int(jpb) << 20)
+        return {"sell": _lib.APPLY_KERNEL_SELL, "tile": _lib.APPLY_KERNEL_TILE, "auto": 0}[v.split(":")[0]]
+
+    def knobs_of(v):
+        spec = v.split(":", 1)[1] if ":" in v else ""
+        return _lib.tuning(**{k: int(n) for k, n in (kv.split("=") for kv in spec.split(",") if kv)})
 
     times = {v: [] for v in args.variants}
     ref = None
     for v in args.variants:   # warm-up + optional check
-        op.apply(x, y=y, remap_area_min=0.5, flags=flags_of(v))
+        with knobs_of(v):
+            op.apply(x, y=y, remap_area_min=0.5, flags=flags_of(v))
         synchronize()
         if args.check:
             h = y.rows(0, min(n_batch, 8)).to_host()
@@ -70,7 +73,8 @@ def main():
         for v in args.variants:
             a, b = Event(), Event()
             a.record()
-            op.apply(x, y=y, remap_area_min=0.5, flags=flags_of(v))
+            with knobs_of(v):
+                op.apply(x, y=y, remap_area_min=0.5, flags=flags_of(v))
             b.record()
             b.synchronize()
             times[v].append(a.elapsed_ms(b))
