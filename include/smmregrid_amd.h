@@ -47,7 +47,8 @@ enum {
   SMM_ERR_NO_DEVICE = 2,  /* no HIP device / device ordinal out of range            */
   SMM_ERR_HIP = 3,        /* a HIP runtime call failed (message has the hipError)    */
   SMM_ERR_ALLOC = 4,      /* host allocation failed                                  */
-  SMM_ERR_UNSUPPORTED = 5 /* dtype / flag combination not built                      */
+  SMM_ERR_UNSUPPORTED = 5,/* dtype / flag combination not built                      */
+  SMM_ERR_INTERNAL = 6    /* an unexpected failure inside the library (message says what) */
 };
 
 /* element types of the dense field buffers */

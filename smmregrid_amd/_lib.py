@@ -16,6 +16,7 @@ SMM_ERR_NO_DEVICE = 2
 SMM_ERR_HIP = 3
 SMM_ERR_ALLOC = 4
 SMM_ERR_UNSUPPORTED = 5
+SMM_ERR_INTERNAL = 6
 
 SMM_F32 = 0
 SMM_F64 = 1

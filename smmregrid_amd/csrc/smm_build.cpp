@@ -9,12 +9,22 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <exception>
+#include <mutex>
+#include <new>
 #include <thread>
 
 namespace smm {
 
 static std::atomic<int> g_host_threads{0};      // 0 = automatic
 static std::atomic<int> g_active_builders{0};   // builders inside a parallel section right now
+static std::atomic<bool> g_debug_no_threads{false};   // test hook: behave as if no thread could be started
+static std::atomic<int64_t> g_debug_throw_in_task{-1};   // test hook: the n-th task body from now throws bad_alloc
+
+void debug_builder_faults(bool no_threads, int64_t throw_in_task) {
+  g_debug_no_threads.store(no_threads);
+  g_debug_throw_in_task.store(throw_in_task);
+}
 
 int set_host_threads(int n) { return g_host_threads.exchange(n < 0 ? 0 : n); }
 
@@ -34,6 +44,55 @@ struct BuilderScope {   // counts this builder among the active ones for the aut
   ~BuilderScope() { g_active_builders.fetch_sub(1); }
 };
 
+// task(i) for i in [0, n): task 0 on the calling thread, the others on threads of their own.  Nothing a task
+// throws (std::bad_alloc from a worker's scratch vectors) may leave its thread -- that would be std::terminate --
+// so every body is wrapped, every started thread is joined, and the first exception is rethrown on the caller
+// (create_operator maps it to a status).  A thread that cannot be started (std::system_error: EAGAIN under a
+// pids / thread limit) costs parallelism, not the build: its task runs on the caller.
+template <typename F>
+void run_tasks(int n, F task) {
+  if (n <= 0) return;
+  std::exception_ptr first;
+  std::mutex mu;
+  auto guarded = [&](int i) {
+    try {
+      if (g_debug_throw_in_task.load(std::memory_order_relaxed) >= 0 && g_debug_throw_in_task.fetch_sub(1) == 0)
+        throw std::bad_alloc();
+      task(i);
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(mu);
+      if (!first) first = std::current_exception();
+    }
+  };
+  std::vector<std::thread> pool;
+  std::vector<int> on_caller;
+  try {
+    pool.reserve((size_t)n - 1);
+  } catch (...) {   // not even the handles: everything runs here
+  }
+  for (int i = 1; i < n; ++i) {
+    bool started = false;
+    if (pool.size() < pool.capacity() && !g_debug_no_threads.load(std::memory_order_relaxed)) {
+      try {
+        pool.emplace_back(guarded, i);
+        started = true;
+      } catch (...) {
+      }
+    }
+    if (!started) {
+      try {
+        on_caller.push_back(i);
+      } catch (...) {
+        guarded(i);   // run it right away rather than lose it
+      }
+    }
+  }
+  guarded(0);
+  for (int i : on_caller) guarded(i);
+  for (auto& th : pool) th.join();
+  if (first) std::rethrow_exception(first);
+}
+
 // fn(t, lo, hi) over [0, n) cut into `nt` contiguous ranges; the calling thread takes range 0.
 template <typename F>
 void parallel_ranges(int64_t n, int nt, F fn) {
@@ -42,11 +101,7 @@ void parallel_ranges(int64_t n, int nt, F fn) {
     fn(0, (int64_t)0, n);
     return;
   }
-  std::vector<std::thread> pool;
-  pool.reserve((size_t)nt - 1);
-  for (int t = 1; t < nt; ++t) pool.emplace_back([=, &fn] { fn(t, n * t / nt, n * (t + 1) / nt); });
-  fn(0, (int64_t)0, n / nt);
-  for (auto& th : pool) th.join();
+  run_tasks(nt, [&](int t) { fn(t, n * t / nt, n * (t + 1) / nt); });
 }
 
 }  // namespace
@@ -147,16 +202,12 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
     }
     for (int t = nt - 1; t > 0; --t) lo_of[(size_t)t] = std::max(lo_of[(size_t)t], lo_of[(size_t)t - 1]);
     lo_of[0] = 0;
-    std::vector<std::thread> pool;
     auto count = [&](int t) {
       int64_t n = 0;
       for (int64_t k = lo_of[(size_t)t]; k < lo_of[(size_t)t + 1]; ++k) n += (k == lo_of[(size_t)t] || !same(k, k - 1));
       kept[(size_t)t + 1] = n;
     };
-    for (int t = 1; t < nt; ++t) pool.emplace_back(count, t);
-    count(0);
-    for (auto& th : pool) th.join();
-    pool.clear();
+    run_tasks(nt, count);
     for (int t = 0; t < nt; ++t) kept[(size_t)t + 1] += kept[(size_t)t];
     const int64_t total = kept[(size_t)nt];
     out.col.resize((size_t)total);
@@ -179,9 +230,7 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
         }
       }
     };
-    for (int t = 1; t < nt; ++t) pool.emplace_back(fill, t);
-    fill(0);
-    for (auto& th : pool) th.join();
+    run_tasks(nt, fill);
     for (int64_t r = (nnz > 0 ? (int64_t)dst1[nnz - 1] : 0); r <= n_dst; ++r) out.rowptr[(size_t)r] = total;  // rows after the last link
     out.nnz = total;
     finish_csr_stats(out, nt);
@@ -216,7 +265,6 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
   std::vector<std::vector<int32_t>> loc_col((size_t)nb);
   std::vector<std::vector<double>> loc_val((size_t)nb);
   {
-    std::vector<std::thread> pool;
     auto work = [&](int b) {
       // rows of this bucket: floor(d * nb / n_dst) == b  <=>  ceil(b * n_dst / nb) <= d < ceil((b + 1) * n_dst / nb)
       const int64_t r0 = (n_dst * b + nb - 1) / nb, r1 = (n_dst * (b + 1) + nb - 1) / nb;
@@ -267,9 +315,7 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
         out.rowptr[(size_t)(r0 + r) + 1] = (int64_t)(lc.size() - row_start);   // row length for now
       }
     };
-    for (int b = 1; b < nb; ++b) pool.emplace_back(work, b);
-    work(0);
-    for (auto& th : pool) th.join();
+    run_tasks(nb, work);
   }
   idx.clear();
   idx.shrink_to_fit();
@@ -282,15 +328,12 @@ bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,
   {
     std::vector<int64_t> at((size_t)nb + 1, 0);
     for (int b = 0; b < nb; ++b) at[(size_t)b + 1] = at[(size_t)b] + (int64_t)loc_col[(size_t)b].size();
-    std::vector<std::thread> pool;
     auto copy = [&](int b) {
       if (loc_col[(size_t)b].empty()) return;
       memcpy(&out.col[(size_t)at[(size_t)b]], loc_col[(size_t)b].data(), loc_col[(size_t)b].size() * sizeof(int32_t));
       memcpy(&out.val[(size_t)at[(size_t)b]], loc_val[(size_t)b].data(), loc_val[(size_t)b].size() * sizeof(double));
     };
-    for (int b = 1; b < nb; ++b) pool.emplace_back(copy, b);
-    copy(0);
-    for (auto& th : pool) th.join();
+    run_tasks(nb, copy);
   }
   finish_csr_stats(out, nt);
   return true;

@@ -865,6 +865,12 @@ static int create_operator(int device, smm_operator_t* out, F fill_csr, unsigned
   } catch (const std::bad_alloc&) {
     release(op);
     return fail(SMM_ERR_ALLOC, "out of host memory while building the operator");
+  } catch (const std::exception& e) {   // nothing may cross the extern "C" boundary
+    release(op);
+    return fail(SMM_ERR_INTERNAL, std::string("operator build failed: ") + e.what());
+  } catch (...) {
+    release(op);
+    return fail(SMM_ERR_INTERNAL, "operator build failed");
   }
   *out = op;
   return SMM_OK;

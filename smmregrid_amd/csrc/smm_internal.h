@@ -40,6 +40,11 @@ struct HostSell {
 // than the work is worth); returns the previous setting.  The results do not depend on the count.
 int set_host_threads(int n);
 int host_threads(int64_t work_items, int64_t min_items_per_thread);
+// Test hook of the builders' worker pools (tests/cpp/build_harness.cpp): no_threads = behave as if no thread could
+// be started (every task then runs on the caller); throw_in_task >= 0 = the task body started after that many
+// others throws std::bad_alloc (-1 = off).  Whatever a worker throws is rethrown on the calling thread after
+// every started thread has been joined.
+void debug_builder_faults(bool no_threads, int64_t throw_in_task);
 
 // Returns false and fills err on invalid input.
 bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <new>
 #include <vector>
 
 #include "../../smmregrid_amd/csrc/smm_internal.h"
@@ -223,6 +224,43 @@ int main(int argc, char** argv) {
                          [&](int64_t, int64_t, int64_t, int64_t) { return ++calls == 3 ? 7 : 0; }) != 7 || calls != 3)
       ++sbad;
     printf("SPLITBAD %lld\n", sbad);
+  }
+  // worker pools of the builders: a task that throws (std::bad_alloc from a worker's scratch vectors) must come
+  // back as an exception on the calling thread after every started thread has been joined -- never
+  // std::terminate --, and a thread that cannot be started costs parallelism, not the result
+  {
+    long long fbad = 0, thrown = 0;
+    auto same_csr = [&](const smm::HostCsr& a) {
+      return a.rowptr == csr.rowptr && a.col == csr.col && a.val == csr.val && a.n_used_src == csr.n_used_src;
+    };
+    smm::debug_builder_faults(true, -1);            // no thread can be started: every task runs on the caller
+    {
+      smm::HostCsr again;
+      std::string e3;
+      if (!smm::build_csr(n_src, n_dst, nnz, src.data(), dst.data(), w.data(), again, e3) || !same_csr(again)) ++fbad;
+    }
+    for (int no_threads = 0; no_threads < 2; ++no_threads) {
+      for (int64_t at = 0; at < 40; ++at) {
+        smm::debug_builder_faults(no_threads != 0, at);
+        try {
+          smm::HostCsr again;
+          std::string e3;
+          smm::HostSell sell2;
+          smm::HostTilePlan plan2;
+          if (!smm::build_csr(n_src, n_dst, nnz, src.data(), dst.data(), w.data(), again, e3)) ++fbad;
+          smm::build_sell(again, sell2);
+          smm::build_tile_plan(again, sell2, 256, 16, 512, plan2);
+          if (!same_csr(again)) ++fbad;             // the fault counter ran past every task: a clean build
+        } catch (const std::bad_alloc&) {
+          ++thrown;
+        }
+      }
+    }
+    smm::debug_builder_faults(false, -1);
+    smm::HostCsr again;
+    std::string e3;
+    if (!smm::build_csr(n_src, n_dst, nnz, src.data(), dst.data(), w.data(), again, e3) || !same_csr(again)) ++fbad;
+    printf("FAULTBAD %lld %lld\n", fbad, thrown);
   }
   printf("SELLBAD %lld\n", bad);
   return 0;

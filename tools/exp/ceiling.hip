@@ -4,13 +4,16 @@
 // read : write mix?  The kernels' PMC traffic rates are held against these numbers in DESIGN.md.
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/exp/ceiling.hip -o tools/exp/ceiling
-//   tools/exp/ceiling <read_run_B> <read_B_per_unit> <write_seg_B> <write_B_per_unit> <write_stride_B> [units] [wg_per_cu] [reps]
+//   tools/exp/ceiling <read_run_B> <read_B_per_unit> <write_seg_B> <write_B_per_unit> <write_stride_B> [units] [wg_per_cu] [reps] [read_pitch_B]
 //
 // One wave = one "unit" at a time: it reads read_B_per_unit bytes as 1-KiB wave loads (16 B per lane,
 // eight in flight) whose bytes are cut into runs of read_run_B at pseudo-random 128-B-aligned places
 // of an 8-GiB buffer (beyond the 256-MiB Infinity Cache), and writes write_B_per_unit bytes as 1-KiB
 // wave stores (non-temporal) cut into segments of write_seg_B placed write_stride_B apart, neighbouring
 // units writing neighbouring segments of the same rows (the Y tiles of the regrid kernels).
+// With read_pitch_B > 0 the reads are not scattered but TILES of a row-major array of that pitch, as a tile plan
+// lists them: unit u reads read_B_per_unit / read_run_B runs of read_run_B, one per array row, at the same column,
+// and neighbouring units read neighbouring columns of the same rows (every byte still read once: no L2 reuse).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -39,6 +42,9 @@ struct Args {
   uint64_t write_stride;
   uint64_t n_units;
   uint32_t cols;           // segments per row of the write pattern
+  uint64_t read_pitch;     // > 0: reads are tiles of a row-major array of this pitch (bytes)
+  uint32_t rcols;          // tiles per row band of that array
+  uint64_t src_mask;       // buffer size - 1
 };
 
 __device__ __forceinline__ uint64_t mix(uint64_t z) {
@@ -63,8 +69,15 @@ __global__ __launch_bounds__(256) void ceiling_kernel(Args a) {
         const uint32_t p = p0 + q < n_rp ? p0 + q : n_rp - 1;
         const uint32_t o = p * 1024 + lane * 16;
         const uint32_t run = o >> a.run_shift, within = o & (a.read_run - 1);
-        const uint64_t slot = mix(u * runs_per_unit + run + 0x9E3779B97F4A7C15ull) & a.slot_mask;
-        v[q] = __builtin_nontemporal_load((const u32x4*)(a.src + (slot << a.slot_shift) + within));
+        uint64_t at;
+        if (a.read_pitch) {
+          const uint64_t band = u / a.rcols, col = u - band * a.rcols;
+          at = ((band * runs_per_unit + run) * a.read_pitch + col * a.read_run + within) & a.src_mask;
+        } else {
+          const uint64_t slot = mix(u * runs_per_unit + run + 0x9E3779B97F4A7C15ull) & a.slot_mask;
+          at = (slot << a.slot_shift) + within;
+        }
+        v[q] = __builtin_nontemporal_load((const u32x4*)(a.src + at));
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc ^= v[q];
@@ -96,6 +109,7 @@ int main(int argc, char** argv) {
   a.n_units = argc > 6 ? (uint64_t)atoll(argv[6]) : 400000;
   const int wg_per_cu = argc > 7 ? atoi(argv[7]) : 8;
   const int reps = argc > 8 ? atoi(argv[8]) : 5;
+  a.read_pitch = argc > 9 ? (uint64_t)atoll(argv[9]) : 0;
   auto pow2 = [](uint32_t v) { return v >= 16 && (v & (v - 1)) == 0; };
   if (a.read_unit % 1024 || a.write_unit % 1024 || !pow2(a.read_run) || !pow2(a.write_seg) ||
       a.write_stride < a.write_seg || a.write_stride % a.write_seg) {
@@ -108,6 +122,12 @@ int main(int argc, char** argv) {
   a.seg_shift = lg(a.write_seg);
   a.slot_shift = a.run_shift < 7 ? 7 : a.run_shift;
   a.slot_mask = (src_bytes >> a.slot_shift) - 1;
+  a.src_mask = src_bytes - 1;
+  if (a.read_pitch && (a.read_pitch % a.read_run || a.read_pitch % 16)) {
+    fprintf(stderr, "read pitch: a multiple of the read run\n");
+    return 2;
+  }
+  a.rcols = a.read_pitch ? (uint32_t)(a.read_pitch / a.read_run) : 1;
   a.cols = a.write_unit ? (uint32_t)(a.write_stride / a.write_seg) : 1;
   const uint32_t segs_per_unit = a.write_unit ? (a.write_unit + a.write_seg - 1) / a.write_seg : 0;
   const uint64_t rows = (a.n_units + a.cols - 1) / a.cols;
@@ -144,10 +164,10 @@ int main(int argc, char** argv) {
   }
   const double rb = (double)a.n_units * a.read_unit, wb = (double)a.n_units * a.write_unit;
   printf("{\"read_run\": %u, \"read_unit\": %u, \"write_seg\": %u, \"write_unit\": %u, \"write_stride\": %llu, "
-         "\"units\": %llu, \"wg_per_cu\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, \"read_GBs\": %.1f, "
+         "\"read_pitch\": %llu, \"units\": %llu, \"wg_per_cu\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, \"read_GBs\": %.1f, "
          "\"write_GBs\": %.1f, \"total_GBs\": %.1f, \"write_share\": %.3f}\n",
          a.read_run, a.read_unit, a.write_seg, a.write_unit, (unsigned long long)a.write_stride,
-         (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
+         (unsigned long long)a.read_pitch, (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
          (rb + wb) / (sum / reps) / 1e6, wb / (rb + wb + 1e-30));
   CHECK(hipFree(src));
   CHECK(hipFree(dst));
