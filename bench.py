@@ -143,6 +143,11 @@ def parse_args():
     ap.add_argument("--config-gather-steps", type=int, default=2,
                     help="steps of the compute + gather loop of a BASELINE config (config 4 moves 110 GB per rank and step)")
     ap.add_argument("--config-batch", type=int, default=0, help="override the rows per GPU of --configs (tests)")
+    ap.add_argument("--user-path", default="default", choices=["default", "none"],
+                    help="N = 1: also time the user-visible paths host to host (tools/user_path_bench.py): smm_apply_host on "
+                         "config-2 rows (block `host_to_host`) and Regridder.regrid on the reference's own fields with the CPU "
+                         "oracle beside them (block `reference_sized`)")
+    ap.add_argument("--host-rows", type=int, default=512, help="batch rows of the host_to_host block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -843,16 +848,15 @@ def run_others(args, names, local_rank, flags, t_start):
 
 
 def layout_summary(entry):
-    """{ms, frac, traffic, traffic_ratio, spot_check} of one timed workload for `roofline.layouts / configs`."""
+    """{ms, frac, traffic_ratio, spot_check} of one timed workload for `roofline.layouts / configs` (the raw traffic
+    bytes and creation times stay in the `details` line)."""
     if not entry or "roofline" not in entry:
         return {"error": short((entry or {}).get("error") or (entry or {}).get("skipped") or "not run", 80)}
     r = entry["roofline"]
-    out = {"ms": round(r["kernel_ms"], 4), "frac": round(r["frac"], 4), "traffic": r.get("traffic"),
+    out = {"ms": round(r["kernel_ms"], 4), "frac": round(r["frac"], 4),
            "traffic_ratio": round(r["traffic"] / r["algorithmic_bytes"], 3) if r.get("traffic") else None}
     if "spot_check" in entry:
         out["spot_check"] = bool(entry["spot_check"].get("bit_equal_to_oracle"))
-    if entry.get("create_ms") is not None:
-        out["create_ms"] = round(entry["create_ms"], 1)
     return out
 
 
@@ -906,6 +910,40 @@ class Runner:
         return mine, [struct.unpack("<d", p)[0] for p in self.rdv.allgather(struct.pack("<d", mine))]
 
 
+def _grid_cells(name):
+    """Cells of a CDO grid name (r<nx>x<ny>, n<N> regular Gaussian, hp<nside>) without building the grid."""
+    import re
+    m = re.match(r"r(\d+)x(\d+)$", name)
+    if m:
+        return int(m.group(1)) * int(m.group(2))
+    m = re.match(r"n(\d+)$", name)
+    if m:
+        return 8 * int(m.group(1)) ** 2
+    m = re.match(r"hp(\d+)", name)
+    if m:
+        return 12 * int(m.group(1)) ** 2
+    raise ValueError(f"no size rule for grid {name!r}")
+
+
+def hbm_need(args, name, rows, world, with_ring):
+    """Device bytes one rank needs for its share of a 2-D workload (SURVEY 8e capacity note): X + Y shards, the
+    operator (SELL-64 + canonical CSR + tile plan, ~64 B per link with links per row estimated from the method) and --
+    on the rank that receives the gather -- the ring of two tile slots holding every rank's tile."""
+    method, sgrid, tgrid = WORKLOADS[name][:3]
+    S, D = _grid_cells(sgrid), _grid_cells(tgrid)
+    sx = 8 if WORKLOADS[name][4] == "f64" else 4
+    opts = WORKLOADS[name][5] if len(WORKLOADS[name]) > 5 else ""
+    sy = 4 if "y32" in opts else 8
+    per_row = {"bil": 4, "nn": 1}.get(method, max(4, -(-S // D) + 5))
+    need = {"x": rows * S * sx, "y": rows * D * sy, "operator": 64 * per_row * D, "ring": 0}
+    if with_ring and world > 1:
+        shard = rows * D * sy
+        tiles = max(1, min(rows, max(args.gather_tiles, -(-world * shard // RING_SLOT_BYTES))))
+        need["ring"] = 2 * world * (-(-rows // tiles)) * D * sy
+    need["total"] = sum(need.values())
+    return need
+
+
 def gather_tiles_for(args, prob, world):
     """Row tiles of the overlapped gather: at least --gather-tiles, and enough of them that one ring slot on
     the root (every rank's tile) stays within RING_SLOT_BYTES (config 4: 8 x 110 GB of Y shards)."""
@@ -941,41 +979,55 @@ def compact(obj, digits=6):
     return obj
 
 
+ROOFLINE_SCALARS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes",
+                    "traffic_ratio", "traffic_fresh", "line_granular_frac", "traffic_GBs", "stream_copy_GBs")
+
+
 def final_line(out, details):
     """The compact last line (driver contract + roofline + cpu_baseline + the per-config blocks): scalars in
-    their own keys, strings short, nested blocks small.  Everything bulky went to the `details` line."""
+    their own keys, strings short, nested blocks small.  Everything bulky went to the `details` line.
+    The driver's record keeps the first two dozen scalar keys of a nested block and the last 2 kB of the output:
+    `roofline` therefore lists its scalars first (the headline's, then every other workload's fraction) and its
+    nested `layouts` / `configs` last, and the line ends with `baseline_configs`, `reference_sized`, `host_to_host`."""
     line = dict(out)
     others = details.get("others") or {}
-    roof = line.get("roofline") or {}
-    if roof.get("traffic") and roof.get("algorithmic_bytes"):
-        roof["traffic_ratio"] = round(roof["traffic"] / roof["algorithmic_bytes"], 3)
-    src = roof.pop("traffic_source", None)
+    full = line.get("roofline") or {}
+    if full.get("traffic") and full.get("algorithmic_bytes"):
+        full["traffic_ratio"] = round(full["traffic"] / full["algorithmic_bytes"], 3)
+    src = full.get("traffic_source")
     if src:
-        roof["traffic_fresh"] = bool(src.get("fresh"))
-        roof["traffic_file"] = short(src.get("file"), 60)
+        full["traffic_fresh"] = bool(src.get("fresh"))
+    roof = {k: full[k] for k in ROOFLINE_SCALARS if k in full}
+    for k in ("dry_run",):
+        if k in full:
+            roof[k] = full[k]
+    nested = {}
     if others:
-        native = {"ms": round(roof["kernel_ms"], 4), "frac": round(roof["frac"], 4), "traffic": roof.get("traffic"),
-                  "traffic_ratio": roof.get("traffic_ratio")}
+        native = {"ms": round(full["kernel_ms"], 4), "frac": round(full["frac"], 4),
+                  "traffic_ratio": full.get("traffic_ratio")}
         if "spot_check" in line:
             native["spot_check"] = bool(line["spot_check"].get("bit_equal_to_oracle"))
         sb = layout_summary(others.get("cfg2sb"))
-        roof["layouts"] = {"native": native, "batch_fastest": sb}
+        nested["layouts"] = {"native": native, "batch_fastest": sb}
         if "cfg2sbk" in others:
-            roof["layouts"]["batch_fastest_y_kept"] = layout_summary(others.get("cfg2sbk"))
+            nested["layouts"]["batch_fastest_y_kept"] = layout_summary(others.get("cfg2sbk"))
         # the same figures once more as plain scalars (a record that keeps only scalars still shows them)
-        for key in ("ms", "frac", "traffic_ratio"):
+        for key in ("frac", "ms", "traffic_ratio"):
             if key in sb:
                 roof[f"batch_fastest_{key}"] = sb[key]
-        roof["configs"] = {n: layout_summary(e) for n, e in others.items() if not n.startswith("cfg2sb")}
-        for n, e in roof["configs"].items():
+        nested["configs"] = {n: layout_summary(e) for n, e in others.items() if not n.startswith("cfg2sb")}
+        for n, e in nested["configs"].items():
             if "frac" in e:
                 roof[f"{n}_frac"] = e["frac"]
     for name, blk in (details.get("baseline_configs") or {}).items():
-        keep = {k: v for k, v in blk.items() if k not in ("workload", "steps", "warmup", "unit", "dtype", "algorithmic_bytes")}
-        if "with_gather" in keep and "value" in keep["with_gather"]:
-            g = keep["with_gather"]
-            keep["with_gather"] = {k: g[k] for k in ("value", "ms_per_step", "ranks", "gathered_bytes_per_step", "tiles", "steps")}
-        line.setdefault("baseline_configs", {})[name] = keep
+        if isinstance(blk, dict) and blk.get("frac") is not None:
+            roof[f"{name}_frac"] = round(blk["frac"], 4)
+    for k in ("kernel_ms_min_rank", "kernel_ms_max_rank"):
+        if k in full and line.get("n_gpus", 1) > 1:
+            roof[k] = full[k]
+    roof.update(nested)
+    if "roofline" in line:
+        line["roofline"] = roof
     cpu = line.get("cpu_baseline")
     if cpu:
         cpu.pop("legs", None)
@@ -985,9 +1037,35 @@ def final_line(out, details):
     for k, v in list(cfg.items()):
         if isinstance(v, str):
             cfg[k] = short(v)
-    for key in ("config", "roofline", "cpu_baseline", "with_gather", "baseline_configs", "spot_check"):
+    # the tail of the line: one GPU's share of BASELINE configs 4 / 5, then the user-visible paths
+    line.pop("baseline_configs", None)
+    for name, blk in (details.get("baseline_configs") or {}).items():
+        keep = {k: v for k, v in blk.items() if k not in ("workload", "steps", "warmup", "unit", "dtype", "algorithmic_bytes",
+                                                          "setup_and_run_s")}
+        if "with_gather" in keep and "value" in keep["with_gather"]:
+            g = keep["with_gather"]
+            keep["with_gather"] = {k: g[k] for k in ("value", "ms_per_step", "ranks", "gathered_bytes_per_step", "tiles", "steps")}
+        line.setdefault("baseline_configs", {})[name] = keep
+    ref = details.get("reference_sized")
+    if ref:
+        keys = ("in", "init_ms", "regrid_ms", "cpu_scipy_ms", "cpu_c1_ms", "bit_equal")
+        line["reference_sized"] = {n: ({k: e[k] for k in keys if k in e} if "regrid_ms" in e else
+                                       {"error": short(e.get("error") or e.get("skipped"), 60)}) for n, e in ref.items()}
+        line["reference_sized"]["unit"] = "ms per regrid() call, host to host; cpu = oracle, 1 core"
+    h2h = details.get("host_to_host")
+    if h2h:
+        blk = {"rows": h2h.get("rows"), "unit": "cells/s (host_GBs)"}
+        for k, e in h2h.items():
+            if isinstance(e, dict) and "cells_per_s" in e:
+                blk[k] = [float(f"{e['cells_per_s']:.4g}"), round(e["host_GBs"], 1)]
+        for k in ("pcie_bytes_per_row", "cpu_cells_per_s", "spot_check", "error"):
+            if k in h2h:
+                blk[k] = h2h[k]
+        line["host_to_host"] = blk
+    for key in ("config", "roofline", "cpu_baseline", "with_gather", "baseline_configs", "spot_check", "host_to_host",
+                "reference_sized"):
         if key in line:
-            line[key] = compact(line[key])
+            line[key] = compact(line[key], 5 if key in ("baseline_configs", "host_to_host") else 6)
     return line
 
 
@@ -997,6 +1075,28 @@ def baseline_config_block(args, name, runner, local_rank, rank, world, n_ranks, 
     from smmregrid_amd.device import DeviceArray
     steps, warmup = args.config_steps, args.config_warmup
     t0 = time.perf_counter()
+    # Does this rank's share fit its GPU?  Decided by all ranks together BEFORE anything is allocated: a config that
+    # does not fit is reported as skipped, it does not end the run in hipMalloc (rank 0 also holds the gather's ring).
+    rows = args.config_batch or WORKLOADS[name][3]
+    need = hbm_need(args, name, rows, world, with_ring=(comm is not None and args.gather == "root" and rank == 0))
+    free = None
+    if os.environ.get("SMM_BENCH_TEST_FREE_GB"):          # tests/test_bench_launch.py: a GPU with that much free memory
+        free = int(float(os.environ["SMM_BENCH_TEST_FREE_GB"]) * 1e9)
+        rows = WORKLOADS[name][3]
+        need = hbm_need(args, name, rows, world, with_ring=(args.gather == "root" and rank == 0))
+    elif not args.dry_run:
+        from smmregrid_amd.device import mem_info
+        free = mem_info()[0]
+    fits = free is None or need["total"] * 1.03 + (1 << 30) <= free
+    verdicts = [fits]
+    if runner.rdv:
+        verdicts = [v == b"1" for v in runner.rdv.allgather(b"1" if fits else b"0")]
+    if not all(verdicts):
+        if rank != 0:
+            return None
+        return {"skipped": short(f"needs {need['total'] / 1e9:.0f} GB per rank, {(free or 0) / 1e9:.0f} GB free on rank 0; "
+                                 f"ranks that fit: {sum(verdicts)} of {len(verdicts)}"),
+                "hbm_needed_gb": round(need["total"] / 1e9, 1)}
     if args.dry_run:
         prob = DryProblem(name, rank)
         y = np.zeros(prob.y_shape)
@@ -1013,7 +1113,10 @@ def baseline_config_block(args, name, runner, local_rank, rank, world, n_ranks, 
                "value": prob.cells() * n_ranks * steps / elapsed, "unit": "cells/s",
                "ms_per_step": elapsed / steps * 1e3, "kernel_ms": mine,
                "kernel_ms_min": min(per_rank), "kernel_ms_max": max(per_rank),
-               "create_ms": getattr(prob, "create_ms", None)}
+               "create_ms": getattr(prob, "create_ms", None),
+               # what the full share (not the dry run's stand-in) asks of one GPU: X + Y + operator (+ ring on rank 0)
+               "hbm_needed_gb": round(hbm_need(args, name, WORKLOADS[name][3], world,
+                                               with_ring=args.gather == "root")["total"] / 1e9, 1)}
         if not args.dry_run:
             alg = prob.alg_bytes()
             blk.update(algorithmic_bytes=alg, frac=alg / k_avg / 1e9 / HBM_PEAK_GBS)
@@ -1144,11 +1247,34 @@ def main():
     done = threading.Event()
 
     def give_up():
+        """Timer thread.  The main thread may still be filling `out` / `details` (a slow gather rather than a hung
+        one): the line is built from deep copies, any failure on the way falls back to the minimal contract line,
+        and the exit happens whatever the printing did (an exception here used to leave the rank
+        hanging with the launcher waiting for it)."""
         if done.is_set():
             return
-        if rank == 0:
-            out.setdefault("with_gather", {"error": f"gather phases exceeded {args.gather_timeout:.0f} s"})
-        emit(3)     # start nothing new: the line (with the compute value) is out, the status says what happened
+        try:
+            if rank == 0:
+                minimal = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                   "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+                minimal["with_gather"] = {"error": f"gather phases exceeded {args.gather_timeout:.0f} s"}
+                try:
+                    import copy
+                    snap_out, snap_details = None, None
+                    for _ in range(3):          # a dict changing size under the copy: try again
+                        try:
+                            snap_out, snap_details = copy.deepcopy(out), copy.deepcopy(details)
+                            break
+                        except RuntimeError:
+                            time.sleep(0.05)
+                    snap_out.setdefault("with_gather", minimal["with_gather"])
+                    snap_out["wall_s"] = time.perf_counter() - t_start
+                    text = "details: " + json.dumps(snap_details) + "\n" + json.dumps(final_line(snap_out, snap_details))
+                except Exception:
+                    text = json.dumps(minimal)
+                print(text, flush=True)
+        finally:
+            os._exit(3)     # start nothing new: the line (with the compute value) is out, the status says what happened
 
     dog = None
     if gather_wanted:
@@ -1191,6 +1317,19 @@ def main():
         y.free()
     if hasattr(prob, "free"):
         prob.free()
+    if rank == 0 and world == 1 and not args.dry_run and args.user_path != "none" and args.workload == "cfg2" \
+            and args.batch is None:
+        # the path a user of the drop-in sees: host buffers in, host buffers out (PCIe-inclusive; never `value`)
+        from tools.user_path_bench import host_to_host, reference_sized
+        for key, fn in (("reference_sized", lambda: reference_sized(local_rank)),
+                        ("host_to_host", lambda: host_to_host(local_rank, rows=args.host_rows,
+                                                              cpu_cells_per_s=(out.get("cpu_baseline") or {}).get("value")))):
+            t0 = time.perf_counter()
+            try:
+                details[key] = fn()
+            except Exception as exc:       # must not lose the headline
+                details[key] = {"error": short(repr(exc), 90)}
+            details[key]["seconds"] = round(time.perf_counter() - t0, 1)
     if rank == 0 and world == 1 and not args.dry_run:
         names = OTHERS_DEFAULT if args.others == "default" else [n for n in args.others.split(",") if n and n != "none"]
         if names and args.workload == "cfg2" and args.batch is None:

@@ -71,6 +71,37 @@ def test_n_rank_line_carries_baseline_configs_4_and_5():
     assert len(details) == 1 and "baseline_configs" in json.loads(details[0][len("details: "):])
 
 
+def test_eight_rank_dry_run_prints_the_hbm_need_and_skips_what_does_not_fit():
+    """before a BASELINE config allocates, every rank holds its need (X + Y shards, operator,
+    on rank 0 the gather's ring: config 4 = 57 + 110 + 3 + 35 GB) against the free device memory; the ranks decide
+    together, and a config that does not fit is reported as skipped instead of dying in hipMalloc.  The dry-run line
+    at --gpus 8 carries `hbm_needed_gb` per config."""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    a = argparse.Namespace(gather_tiles=8)
+    n4 = bench.hbm_need(a, "cfg4", 1095, 8, True)
+    assert round(n4["x"] / 1e9, 1) == 57.4 and round(n4["y"] / 1e9, 1) == 110.2 and 30e9 < n4["ring"] < 2.1 * bench.RING_SLOT_BYTES
+    assert n4["total"] < 288e9 and bench.hbm_need(a, "cfg4", 1095, 8, False)["ring"] == 0
+    n5 = bench.hbm_need(a, "cfg5", 12741, 8, True)
+    assert round(n5["x"] / 1e9, 1) == 105.8 and round(n5["y"] / 1e9, 1) == 26.4 and n5["total"] < 288e9
+    out = run([sys.executable, BENCH, "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--comm", "torch",
+               "--config-steps", "2"], timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json_line(out)
+    assert line["n_gpus"] == 8 and len(json.dumps(line)) < 4096
+    assert line["baseline_configs"]["cfg4"]["hbm_needed_gb"] == round(n4["total"] / 1e9, 1)
+    assert line["baseline_configs"]["cfg5"]["hbm_needed_gb"] == round(n5["total"] / 1e9, 1)
+    # a GPU with 180 GB free: config 4 (206 GB on rank 0, 171 GB elsewhere) is skipped by ALL ranks, config 5 runs
+    out = run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--comm", "torch",
+               "--config-steps", "2"], env={"SMM_BENCH_TEST_FREE_GB": "180"}, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json_line(out)
+    c4 = line["baseline_configs"]["cfg4"]
+    assert "needs" in c4["skipped"] and "value" not in c4 and c4["hbm_needed_gb"] > 170
+    assert line["baseline_configs"]["cfg5"]["value"] > 0 and line["value"] > 0
+
+
 def _strings(obj):
     if isinstance(obj, str):
         yield obj
@@ -102,11 +133,28 @@ def test_secondary_entries_keep_their_units():
              "spot_check": {"bit_equal_to_oracle": True}}
     assert entry["unit"] == "cells/s"
     lay = bench.layout_summary(entry)
-    assert lay == {"ms": 1.7, "frac": 0.68, "traffic": 9.35e9, "traffic_ratio": 1.002, "spot_check": True, "create_ms": 12.3}
+    assert lay == {"ms": 1.7, "frac": 0.68, "traffic_ratio": 1.002, "spot_check": True}
     out = {"roofline": {"kernel_ms": 2.75, "frac": 0.42, "traffic": 17.05e9, "algorithmic_bytes": 9.33e9},
            "spot_check": {"bit_equal_to_oracle": True}, "config": {"workload": "x" * 300, "plan": {"a": 1}}}
-    line = bench.final_line(out, {"others": {"cfg2sb": entry, "cfg3": {"error": "boom"}}})
+    details = {"others": {"cfg2sb": entry, "cfg3": {"error": "boom"}},
+               "baseline_configs": {"cfg4": {"value": 3.4e11, "kernel_ms": 39.6, "frac": 0.5172, "workload": "w", "steps": 3}},
+               "reference_sized": {"2t_era5": {"in": "12x73x144", "init_ms": 3.2, "regrid_ms": 0.41, "cpu_scipy_ms": 5.5,
+                                               "cpu_c1_ms": 2.2, "bit_equal": True, "cells": 777600, "calls": 25},
+                                   "tas_ecearth": {"error": "x" * 300}},
+               "host_to_host": {"rows": 512, "pinned_packed": {"cells_per_s": 9.87654e8, "host_GBs": 123.456, "ms": 33.0},
+                                "pcie_bytes_per_row": {"packed": 2592000, "whole_rows": 8824320}, "spot_check": True}}
+    line = bench.final_line(out, details)
     r = line["roofline"]
+    # the record keeps the first two dozen scalars of a nested block and the tail of the output: scalars first,
+    # nested summaries last, the per-config and user-path blocks at the end of the line
+    keys = list(r)
+    assert keys.index("cfg4_frac") < keys.index("layouts") < keys.index("configs") == len(keys) - 1
+    assert r["cfg4_frac"] == 0.5172 and all(not isinstance(r[k], dict) for k in keys[:-2])
+    assert list(line)[-3:] == ["baseline_configs", "reference_sized", "host_to_host"]
+    assert line["reference_sized"]["2t_era5"] == {"in": "12x73x144", "init_ms": 3.2, "regrid_ms": 0.41, "cpu_scipy_ms": 5.5,
+                                                  "cpu_c1_ms": 2.2, "bit_equal": True}
+    assert len(line["reference_sized"]["tas_ecearth"]["error"]) <= 60
+    assert line["host_to_host"]["pinned_packed"] == [9.877e8, 123.5] and line["host_to_host"]["spot_check"] is True
     assert r["layouts"]["batch_fastest"]["frac"] == 0.68 and r["batch_fastest_frac"] == 0.68
     assert r["layouts"]["native"]["traffic_ratio"] == 1.827 and r["configs"]["cfg3"] == {"error": "boom"}
     assert len(line["config"]["workload"]) <= 100 and "plan" not in line["config"]

@@ -7,6 +7,12 @@ These tests do: fields are generated on the device (a few rows get NaN / inf pok
 host), sampled batch rows are compared bit for bit with the CPU oracle
 (regrid.py:536-570, :387-418) and every row is compared bit for bit between the LDS-tile kernel
 and the independent SELL kernel.
+
+The oracle is fed ITS OWN matrix: `oracle.coo_to_csr_c` builds the CSR from the links (weights.py:31-39), the
+library's `export_csr()` must equal it bit for bit -- once for the links in CDO's (dst, src) order (the builder's
+sort-free path) and once for the same links shuffled (the bucketed-sort path, automatic thread count) -- before
+it is handed to `oracle.apply_c` (at these sizes the kernels used to be checked against
+the library's own matrix).
 """
 import numpy as np
 import pytest
@@ -24,6 +30,41 @@ def _operator(w, device=0):
                         w["dst_address"].values, w["remap_matrix"].values, device=device)
     op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
     return op
+
+
+def _links(w, lev=None):
+    """(src_address, dst_address, weight column 0) of a weights file, one level's `[:link_length]` of a 3-D one."""
+    src, dst, rm = w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values
+    if lev is not None:
+        n = int(w["link_length"].values[lev])
+        src, dst, rm = src[lev, :n], dst[lev, :n], rm[lev, :n]
+    return src, dst, np.ascontiguousarray(rm[:, 0] if rm.ndim == 2 else rm)
+
+
+def _assert_csr_bits(got, ref, what):
+    assert np.array_equal(got[0], ref[0]), f"{what}: rowptr differs from the oracle's"
+    assert np.array_equal(got[1], ref[1]), f"{what}: columns differ from the oracle's"
+    assert np.array_equal(got[2].view(np.uint64), ref[2].view(np.uint64)), f"{what}: weights differ from the oracle's"
+
+
+def _oracle_csr_checked(op, n_src, n_dst, src, dst, wgt, what, seed=0):
+    """The oracle's own CSR of these links; `op` (built from the links as given: CDO order, the sort-free path)
+    and a second operator built from the same links SHUFFLED (bucketed stable sort, automatic thread count)
+    must both export exactly it.  The links of these files hold no duplicate coordinate (asserted), so the
+    canonical CSR does not depend on the link order and one oracle build serves both."""
+    ordered = np.all((dst[1:] > dst[:-1]) | ((dst[1:] == dst[:-1]) & (src[1:] >= src[:-1])))
+    assert ordered, f"{what}: links are expected in (dst, src) order as cdo writes them"
+    ref = oracle.coo_to_csr_c(n_src, n_dst, src, dst, wgt)
+    assert ref[1].size == src.size, f"{what}: duplicate coordinates"
+    _assert_csr_bits(op.export_csr(), ref, what + " (links in CDO order)")
+    perm = np.random.default_rng(20260723 + seed).permutation(src.size)
+    _lib.call("smm_set_host_threads", 0, None)                 # automatic thread count
+    shuffled = SparseOperator(n_src, n_dst, src[perm], dst[perm], wgt[perm], device=0)
+    try:
+        _assert_csr_bits(shuffled.export_csr(), ref, what + " (links shuffled)")
+    finally:
+        shuffled.close()
+    return ref
 
 
 def _device_field(n_batch, n_src, dtype, seed, poke_rows):
@@ -57,13 +98,13 @@ def _assert_device_equal(ya, yb, chunk=32):
         assert np.array_equal(a, b), f"tile and SELL kernels differ in batch rows {r0}..{r1 - 1}"
 
 
-def _check_2d(op, x, host_rows, sample, masked, amin, imask, frac):
-    """default (tile) kernel vs oracle on `sample` rows, vs SELL kernel on every row."""
+def _check_2d(op, csr, x, host_rows, sample, masked, amin, imask, frac):
+    """default (tile) kernel vs oracle (on the oracle's own CSR `csr`) on `sample` rows, vs SELL kernel on every row."""
     y = op.apply(x, masked=masked, remap_area_min=amin)
     ys = op.apply(x, masked=masked, remap_area_min=amin, flags=_lib.APPLY_KERNEL_SELL)
     _assert_device_equal(y, ys)
     xs = np.stack([host_rows[r] if r in host_rows else x.rows(r, r + 1).to_host()[0] for r in sample])
-    ref = oracle.apply_c(op.export_csr(), xs, masked, imask, frac, amin, threads=8)
+    ref = oracle.apply_c(csr, xs, masked, imask, frac, amin, threads=8)
     assert_same(_rows(y, sample), ref, exact=True)
     return y
 
@@ -73,12 +114,13 @@ def _check_2d(op, x, host_rows, sample, masked, amin, imask, frac):
 def test_config2_production_walk(hip):
     w = gridgen.bilinear_weights("r1440x721", "r360x180")
     op = _operator(w)
+    csr = _oracle_csr_checked(op, op.n_src, op.n_dst, *_links(w), "config 2", seed=2)
     B = 522                                                    # 131 batch tiles of 4 rows, last one ragged
     info = op.launch_info(B, np.float64)
     assert info["kernel"] == "tile" and info["j_per_block"] == 4 and info["rows_per_block"] == 256
     assert info["n_blocks"] == ((64800 + 255) // 256) * ((B + 3) // 4)
     x, host = _device_field(B, op.n_src, np.float64, 11, poke_rows=[1, 257, B - 1])
-    _check_2d(op, x, host, [0, 1, 2, 3, 4, 257, 300, B - 2, B - 1], False, 0.5, None, w["dst_grid_frac"].values)
+    _check_2d(op, csr, x, host, [0, 1, 2, 3, 4, 257, 300, B - 2, B - 1], False, 0.5, None, w["dst_grid_frac"].values)
 
 
 # ----------------------------------------------------------------- config 5: r1440x721 -> r720x360 conservative, f64
@@ -86,11 +128,12 @@ def test_config2_production_walk(hip):
 def test_config5_production_walk(hip):
     w = gridgen.conservative_weights("r1440x721", "r720x360")
     op = _operator(w)
+    csr = _oracle_csr_checked(op, op.n_src, op.n_dst, *_links(w), "config 5", seed=5)
     B = 520                                                    # 9 batch tiles of 64 rows, last one 8
     info = op.launch_info(B, np.float64)
     assert info["kernel"] == "tile" and info["j_per_block"] == 64
     x, host = _device_field(B, op.n_src, np.float64, 12, poke_rows=[63, 64, B - 1])
-    _check_2d(op, x, host, [0, 63, 64, 65, 127, 128, 300, 511, 512, B - 1], False, 0.5, None,
+    _check_2d(op, csr, x, host, [0, 63, 64, 65, 127, 128, 300, 511, 512, B - 1], False, 0.5, None,
               w["dst_grid_frac"].values)
 
 
@@ -105,6 +148,8 @@ def test_config4_geometry_f32(hip):
     assert (w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w.sizes["num_links"]) == \
         (13107200, 12582912, 50331648)
     op = _operator(w)
+    # all 50 M links: the oracle's own CSR against the sort-free build and against the bucketed sort of the shuffled links
+    csr = _oracle_csr_checked(op, op.n_src, op.n_dst, *_links(w), "config 4", seed=4)
     plan = op.plan_info()
     assert plan["tile_plan"] and plan["tile_preferred"] and plan["rows_per_block"] == 256
     # tighten_tile_plan shrank the tile below half of the 64-KiB chunk budget (polar caps -> direct)
@@ -115,7 +160,7 @@ def test_config4_geometry_f32(hip):
     assert info["kernel"] == "tile-dma" and info["big_operator"] and info["j_per_block"] == 128
     assert info["rows_per_step"] == 1 and info["lds_bytes"] <= 16384
     x, host = _device_field(B, op.n_src, np.float32, 13, poke_rows=[1, 129])
-    y = _check_2d(op, x, host, [0, 1, 127, 128, 129], False, 0.0, None, None)
+    y = _check_2d(op, csr, x, host, [0, 1, 127, 128, 129], False, 0.0, None, None)
     assert y.dtype == np.float64                               # result_type(f32, f64), regrid.py:550
     # register staging with multi-row steps (R = 2 or 4) serves fields that are not 16-B aligned and is
     # what the tuning knob tile_staging = 1 forces: same bits
@@ -145,7 +190,14 @@ def config3():
         op = SparseOperator(src.size, 64800, w3["src_address"].values[i, :ll[i]],
                             w3["dst_address"].values[i, :ll[i]], w3["remap_matrix"].values[i, :ll[i], 0], device=0)
         imask[i] = op.mask_apply(masks[i])
-        csrs.append(op.export_csr())
+        # every level's CSR is the oracle's own, built from that level's links (weights.py:7-23); levels 0, 37, 74
+        # are also rebuilt from shuffled links
+        lk = _links(w3, i)
+        if i in (0, 37, 74):
+            csrs.append(_oracle_csr_checked(op, src.size, 64800, *lk, f"config 3 level {i}", seed=300 + i))
+        else:
+            csrs.append(oracle.coo_to_csr_c(src.size, 64800, *lk))
+            _assert_csr_bits(op.export_csr(), csrs[i], f"config 3 level {i}")
         assert np.array_equal(imask[i], oracle.mask_apply_c(csrs[i], masks[i]))    # weights.py:47-52
         op.set_epilogue(imask[i], w3["dst_grid_frac"].values[i])
         ops.append(op)

@@ -4,7 +4,8 @@
 // read : write mix?  The kernels' PMC traffic rates are held against these numbers in DESIGN.md.
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/exp/ceiling.hip -o tools/exp/ceiling
-//   tools/exp/ceiling <read_run_B> <read_B_per_unit> <write_seg_B> <write_B_per_unit> <write_stride_B> [units] [wg_per_cu] [reps] [read_pitch_B]
+//   tools/exp/ceiling <read_run_B> <read_B_per_unit> <write_seg_B> <write_B_per_unit> <write_stride_B> [units] [wg_per_cu] [reps]
+//                     [read_pitch_B] [rows_per_tile] [slab_pitch_B]
 //
 // One wave = one "unit" at a time: it reads read_B_per_unit bytes as 1-KiB wave loads (16 B per lane,
 // eight in flight) whose bytes are cut into runs of read_run_B at pseudo-random 128-B-aligned places
@@ -14,6 +15,11 @@
 // With read_pitch_B > 0 the reads are not scattered but TILES of a row-major array of that pitch, as a tile plan
 // lists them: unit u reads read_B_per_unit / read_run_B runs of read_run_B, one per array row, at the same column,
 // and neighbouring units read neighbouring columns of the same rows (every byte still read once: no L2 reuse).
+// rows_per_tile < runs per unit cuts a unit's runs into several tiles; with slab_pitch_B > 0 they are the SAME tile of
+// consecutive slabs (batch rows) that far apart -- a workgroup walking the batch -- else consecutive tiles of one slab.
+// (Units should read a multiple of 8 KiB: the load loop issues eight 1-KiB wave loads at a time and repeats the last
+// piece to fill a short round, which costs issue slots without counting as bytes -- the round-3/4 "config-4 shape" line
+// with its 2-KiB units measured that loop, not the chip.)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -45,6 +51,8 @@ struct Args {
   uint64_t read_pitch;     // > 0: reads are tiles of a row-major array of this pitch (bytes)
   uint32_t rcols;          // tiles per row band of that array
   uint64_t src_mask;       // buffer size - 1
+  uint32_t rows_per_tile;  // runs of one tile (<= runs per unit)
+  uint64_t slab_pitch;     // > 0: a unit's tiles are one tile position in consecutive slabs this far apart
 };
 
 __device__ __forceinline__ uint64_t mix(uint64_t z) {
@@ -71,8 +79,12 @@ __global__ __launch_bounds__(256) void ceiling_kernel(Args a) {
         const uint32_t run = o >> a.run_shift, within = o & (a.read_run - 1);
         uint64_t at;
         if (a.read_pitch) {
-          const uint64_t band = u / a.rcols, col = u - band * a.rcols;
-          at = ((band * runs_per_unit + run) * a.read_pitch + col * a.read_run + within) & a.src_mask;
+          const uint32_t k = run / a.rows_per_tile, row = run - k * a.rows_per_tile;   // k-th tile of the unit
+          const uint32_t tiles_per_unit = (runs_per_unit + a.rows_per_tile - 1) / a.rows_per_tile;
+          const uint64_t tile = a.slab_pitch ? u : u * tiles_per_unit + k;
+          const uint64_t band = tile / a.rcols, col = tile - band * a.rcols;
+          at = ((a.slab_pitch ? k * a.slab_pitch : 0) + (band * a.rows_per_tile + row) * a.read_pitch + col * a.read_run +
+                within) & a.src_mask;
         } else {
           const uint64_t slot = mix(u * runs_per_unit + run + 0x9E3779B97F4A7C15ull) & a.slot_mask;
           at = (slot << a.slot_shift) + within;
@@ -110,6 +122,8 @@ int main(int argc, char** argv) {
   const int wg_per_cu = argc > 7 ? atoi(argv[7]) : 8;
   const int reps = argc > 8 ? atoi(argv[8]) : 5;
   a.read_pitch = argc > 9 ? (uint64_t)atoll(argv[9]) : 0;
+  a.rows_per_tile = argc > 10 ? (uint32_t)atoll(argv[10]) : 0;
+  a.slab_pitch = argc > 11 ? (uint64_t)atoll(argv[11]) : 0;
   auto pow2 = [](uint32_t v) { return v >= 16 && (v & (v - 1)) == 0; };
   if (a.read_unit % 1024 || a.write_unit % 1024 || !pow2(a.read_run) || !pow2(a.write_seg) ||
       a.write_stride < a.write_seg || a.write_stride % a.write_seg) {
@@ -128,6 +142,10 @@ int main(int argc, char** argv) {
     return 2;
   }
   a.rcols = a.read_pitch ? (uint32_t)(a.read_pitch / a.read_run) : 1;
+  {
+    const uint32_t runs = (a.read_unit + a.read_run - 1) / a.read_run;
+    if (a.rows_per_tile == 0 || a.rows_per_tile > runs) a.rows_per_tile = runs ? runs : 1;
+  }
   a.cols = a.write_unit ? (uint32_t)(a.write_stride / a.write_seg) : 1;
   const uint32_t segs_per_unit = a.write_unit ? (a.write_unit + a.write_seg - 1) / a.write_seg : 0;
   const uint64_t rows = (a.n_units + a.cols - 1) / a.cols;
@@ -164,10 +182,10 @@ int main(int argc, char** argv) {
   }
   const double rb = (double)a.n_units * a.read_unit, wb = (double)a.n_units * a.write_unit;
   printf("{\"read_run\": %u, \"read_unit\": %u, \"write_seg\": %u, \"write_unit\": %u, \"write_stride\": %llu, "
-         "\"read_pitch\": %llu, \"units\": %llu, \"wg_per_cu\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, \"read_GBs\": %.1f, "
+         "\"read_pitch\": %llu, \"rows_per_tile\": %u, \"slab_pitch\": %llu, \"units\": %llu, \"wg_per_cu\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, \"read_GBs\": %.1f, "
          "\"write_GBs\": %.1f, \"total_GBs\": %.1f, \"write_share\": %.3f}\n",
          a.read_run, a.read_unit, a.write_seg, a.write_unit, (unsigned long long)a.write_stride,
-         (unsigned long long)a.read_pitch, (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
+         (unsigned long long)a.read_pitch, a.rows_per_tile, (unsigned long long)a.slab_pitch, (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
          (rb + wb) / (sum / reps) / 1e6, wb / (rb + wb + 1e-30));
   CHECK(hipFree(src));
   CHECK(hipFree(dst));

@@ -11,15 +11,22 @@ bin=$(dirname "$0")/ceiling
 : > $out/ceilings.jsonl
 run() { local label=$1; shift; line=$("$bin" "$@") || { echo "FAILED $label" >&2; return 1; }; echo "{\"shape\": \"$label\", ${line#\{}" >> $out/ceilings.jsonl; }
 for wg in 8 16; do
-#    label                                                       run  rd/unit seg  wr/unit stride     units   wg  reps pitch
-run "copy 1:1, 64-KiB runs / segments"                           65536 65536 65536 65536  65536      200000  $wg 5
-run "write only, 2-KiB segs on 96 MiB"                           1024  0     2048  2048   100663296  2000000 $wg 5
-run "read only, tiles of 8 rows x 256 B (pitch 20480)"           256   2048  2048  0      100663296  2000000 $wg 5  20480
-run "cfg4 1:1, tiles 8 rows x 256 B, 2-KiB segs on 96 MiB"       256   2048  2048  2048   100663296  2000000 $wg 5  20480
-run "cfg4 1:1, tiles 16 rows x 128 B, 2-KiB segs on 96 MiB"      128   2048  2048  2048   100663296  2000000 $wg 5  20480
-run "cfg4 1:1, tiles 4 rows x 512 B, 2-KiB segs on 96 MiB"       512   2048  2048  2048   100663296  2000000 $wg 5  20480
-run "cfg4 1:1, scattered 128-B lines (the round-3/4 line)"       128   2048  2048  2048   100663296  2000000 $wg 5
-run "cfg4 1:1, tiles 8 rows x 256 B, 2-KiB segs contiguous"      256   2048  2048  2048   2048       2000000 $wg 5  20480
+# a unit = a workgroup walking 8 batch rows: the same tile (8 source rows x 256 B = 2 x 8 neighbouring 128-B lines, row
+# pitch 20 480 B) of 8 consecutive X rows 52 428 800 B apart, and a 2-KiB f64 segment into 8 Y rows 100 663 296 B apart
+#    label                                                         run  rd/unit seg  wr/unit stride     units   wg  reps pitch rows slab
+run "copy 1:1, 64-KiB runs / segments"                             65536 65536 65536 65536  65536      200000  $wg 5
+run "write only, 2-KiB segs of 8 rows on 96 MiB"                   1024  0     2048  16384  100663296  400000  $wg 5
+run "write only, 64-KiB segments"                                  1024  0     65536 65536  65536      200000  $wg 5
+run "read only, walk of 8 slabs, tile 8 rows x 256 B"              256   16384 2048  0      100663296  400000  $wg 5  20480 8 52428800
+run "read only, walk of 8 slabs, tile 16 rows x 128 B"             128   16384 2048  0      100663296  400000  $wg 5  20480 16 52428800
+run "read only, scattered 128-B lines, 16-KiB units"               128   16384 2048  0      100663296  400000  $wg 5
+run "read only, 64-KiB runs"                                       65536 65536 1024  0      1024       200000  $wg 5
+run "cfg4 1:1, walk of 8 slabs, tile 8 x 256 B, 2-KiB segs/96 MiB" 256   16384 2048  16384  100663296  400000  $wg 5  20480 8 52428800
+run "cfg4 1:1, walk of 8 slabs, tile 16 x 128 B, 2-KiB segs"       128   16384 2048  16384  100663296  400000  $wg 5  20480 16 52428800
+run "cfg4 1:1, walk of 8 slabs, tile 4 x 512 B, 2-KiB segs"        512   16384 2048  16384  100663296  400000  $wg 5  20480 4 52428800
+run "cfg4 1:1, 8 tiles of one slab, tile 8 x 256 B, 2-KiB segs"    256   16384 2048  16384  100663296  400000  $wg 5  20480 8
+run "cfg4 1:1, scattered 128-B lines, 16-KiB units, 2-KiB segs"    128   16384 2048  16384  100663296  400000  $wg 5
+run "cfg4 1:1, walk of 8 slabs, tile 8 x 256 B, 8-KiB segs"        256   16384 8192  16384  100663296  400000  $wg 5  20480 8 52428800
 done
 cat $out/ceilings.jsonl
 export TMPDIR=/tmp
