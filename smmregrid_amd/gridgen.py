@@ -854,16 +854,21 @@ def healpix_ring_index(nside, lon, lat):
 
 
 def _regular_cell_index(grid, lon, lat):
-    """Address (lon fastest) of the regular grid's cell that holds each direction."""
+    """Address (lon fastest) of the regular grid's cell that holds each direction; -1 for a direction the grid does
+    not cover (a regional grid: beyond its first / last cell edge in longitude or latitude)."""
     nx, ny = grid.lon.size, grid.lat.size
     span = grid.lon_b[-1] - grid.lon_b[0]
+    lat = np.asarray(lat)
     u = (np.asarray(lon) - grid.lon_b[0]) % 360.0
+    outside = (lat < grid.lat_b[0] - 1e-12) | (lat > grid.lat_b[-1] + 1e-12)
     if abs(span - 360.0) < 1e-9 and np.allclose(np.diff(grid.lon_b), span / nx):
         i = np.minimum((u / (span / nx)).astype(np.int64), nx - 1)
     else:
+        if span < 360.0 - 1e-9:
+            outside |= u > span + 1e-12
         i = np.clip(np.searchsorted(grid.lon_b - grid.lon_b[0], u, side="right") - 1, 0, nx - 1)
-    j = np.clip(np.searchsorted(grid.lat_b, np.asarray(lat), side="right") - 1, 0, ny - 1)
-    return j * nx + i
+    j = np.clip(np.searchsorted(grid.lat_b, lat, side="right") - 1, 0, ny - 1)
+    return np.where(outside, -1, j * nx + i)
 
 
 def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", samples=None, chunk=1 << 22):
@@ -907,6 +912,8 @@ def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", sampl
         flon, flat = _healpix_centers_range(fine, lo, hi)
         parent = np.arange(lo, hi, dtype=np.int64) >> (2 * k)                   # nested index of the coarse pixel
         cell_idx = _regular_cell_index(reg, flon, flat)
+        inside = cell_idx >= 0                     # a regional lon/lat grid: sub-pixels beyond its edges belong to no cell
+        parent, cell_idx = parent[inside], cell_idx[inside]
         key = parent * n_reg + cell_idx
         uk, uc = np.unique(key, return_counts=True)
         keys.append(uk)
@@ -916,7 +923,8 @@ def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", sampl
     uk, inv = np.unique(key, return_inverse=True)                               # chunks may split a pixel's sub-pixels
     cnt = np.bincount(inv, weights=cnt)
     hp_idx, reg_idx = uk // n_reg, uk % n_reg
-    if not hp_is_dst:
+    reg_global = abs((reg.lon_b[-1] - reg.lon_b[0]) - 360.0) < 1e-9 and reg.lat_b[0] <= -90.0 + 1e-9 and reg.lat_b[-1] >= 90.0 - 1e-9
+    if not hp_is_dst and reg_global:
         # a lon/lat target cell too small to catch a sub-pixel centre (the last rows before a pole) takes the
         # pixel that holds its own centre
         empty = np.flatnonzero(np.bincount(reg_idx, minlength=n_reg) == 0)
@@ -1437,6 +1445,14 @@ def generate_weights(src, dst, method="con", src_mask=None, norm="fracarea", ext
             for name in ("src_address", "dst_address"):
                 ds[name] = (("num_links",), ds[name].values[keep])
             ds["remap_matrix"] = (("num_links", "num_wgts"), ds["remap_matrix"].values[keep])
+            # a destination that lost all its links is not covered: its fraction is 0 (and the destination mask says
+            # so), as a consumer of `dst_grid_frac` / remap_area_min expects -- not the extrapolating case's 1
+            linked = np.bincount(ds["dst_address"].values - 1, minlength=dst.size) > 0
+            for name, zero in (("dst_grid_frac", 0.0), ("dst_grid_imask", 0)):
+                if name in ds:
+                    v = ds[name].values.copy()
+                    v[~linked] = zero
+                    ds[name] = (ds[name].dims, v, ds[name].attrs)
     if not (flip_s or flip_d):
         return ds
     src_addr, dst_addr = ds["src_address"].values, ds["dst_address"].values

@@ -122,6 +122,11 @@ def test_without_cdo_the_native_generator_says_so(monkeypatch, caplog):
         assert np.array_equal(np.flatnonzero(want) + 1, linked_off)
         sel = np.isin(on["dst_address"].values, linked_off)        # inside, the weights are the same
         assert np.array_equal(on["remap_matrix"].values[sel], off["remap_matrix"].values)
+        # the weights Dataset itself says which cells are covered -- a destination that lost its
+        # links has fraction 0 and mask 0, not the extrapolating case's 1
+        frac, imask = off["dst_grid_frac"].values, off["dst_grid_imask"].values
+        assert np.array_equal(np.flatnonzero(frac > 0) + 1, linked_off) and np.array_equal(np.flatnonzero(imask) + 1, linked_off)
+        assert (on["dst_grid_frac"].values > 0).all()
     # ... and a global one only loses the bilinear rows beyond its first / last row of centres
     off = gridgen.generate_weights("r32x16", "r16x30", method="bil", extrapolate=False)     # rows at +-87 > +-84.4
     assert np.unique(off["dst_address"].values).size == 16 * 28

@@ -406,6 +406,41 @@ def test_regional_lonlat_sources_do_not_wrap():
     assert frac[:, 10:].max() == 0.0 and np.allclose(frac[8:15, 1:5], 1.0)
 
 
+def test_regional_lonlat_grid_and_healpix_conservative():
+    """a REGIONAL lon/lat grid against a HEALPix grid, either side.  Sub-pixels outside the
+    region used to be clipped into its border cells, so every pixel of the sphere got links (dst_grid_frac == 1
+    everywhere) and edge cells piled up dozens of links.  Now only what the region covers is linked."""
+    lon, lat = np.arange(0.5, 40.0), np.arange(30.5, 60.0)                 # 0-40 E, 30-60 N, one-degree cells
+    reg = gridgen.regular_grid_from_centers(lon, lat)
+    region_area = np.radians(40.0) * (np.sin(np.radians(60.0)) - np.sin(np.radians(30.0)))
+    hp_lon, hp_lat = gridgen.healpix_centers(8, nested=True)
+    pix_area = 4 * np.pi / 768
+    # regional -> hp8: only pixels that overlap the region are linked, their fraction is the covered share
+    w = gridgen.generate_weights(reg, "hp8", method="con")
+    frac = w["dst_grid_frac"].values
+    linked = np.unique(w["dst_address"].values - 1)
+    assert 8 <= linked.size <= 40 and np.array_equal(np.flatnonzero(frac > 0), linked)
+    assert abs((frac * pix_area).sum() - region_area) < 6e-3 * region_area          # the region's area, no more
+    inside = (hp_lon > 4) & (hp_lon < 36) & (hp_lat > 36) & (hp_lat < 54)
+    assert inside.sum() >= 3 and np.allclose(frac[inside], 1.0, atol=1e-3)          # deep inside: fully covered
+    far = (hp_lon > 90) & (hp_lon < 300)
+    assert frac[far].max() == 0.0
+    rows = np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0], minlength=768)
+    assert np.allclose(rows[linked], 1.0)
+    # hp8 -> regional: every cell of the region is covered by the pixels over it, edge cells hold no pile of links
+    w = gridgen.generate_weights("hp8", reg, method="con")
+    assert np.allclose(w["dst_grid_frac"].values, 1.0)
+    used = np.unique(w["src_address"].values - 1)
+    assert used.size <= 45 and not (set(used) & set(np.flatnonzero(far)))           # only pixels over the region
+    per_cell = np.bincount(w["dst_address"].values - 1, minlength=reg.size).reshape(lat.size, lon.size)
+    assert per_cell.max() <= 6 and per_cell[0, 0] <= 4 and per_cell[-1, -1] <= 4
+    # the integral of a smooth field over the region is kept (first order, cells of 1 degree under pixels of 7)
+    field = 280.0 + 20.0 * np.cos(np.radians(hp_lat)) * np.cos(np.radians(hp_lon))
+    y = np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0] * field[w["src_address"].values - 1],
+                    minlength=reg.size)
+    assert field.min() - 1e-9 <= y.min() and y.max() <= field.max() + 1e-9
+
+
 def test_curvilinear_centres_feed_nn_and_dis():
     """A NEMO-style field (2-D nav_lon / nav_lat on (y, x); the reference's so3d-nemo.nc / onlytos-ipsl.nc layout):
     the native generator takes the cell centres in storage order for `nn` and `dis`, reports (nx, ny) as
