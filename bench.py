@@ -1329,7 +1329,7 @@ def main():
                 details[key] = fn()
             except Exception as exc:       # must not lose the headline
                 details[key] = {"error": short(repr(exc), 90)}
-            details[key]["seconds"] = round(time.perf_counter() - t0, 1)
+            details.setdefault("user_path_seconds", {})[key] = round(time.perf_counter() - t0, 1)
     if rank == 0 and world == 1 and not args.dry_run:
         names = OTHERS_DEFAULT if args.others == "default" else [n for n in args.others.split(",") if n and n != "none"]
         if names and args.workload == "cfg2" and args.batch is None:

@@ -78,6 +78,34 @@ struct SbArgs {
   int b_fastest;           // > 0: width (destination tiles) of the strips the tiles are ordered in
 };
 
+// Arguments of the batch-fastest kernel over a whole level group in ONE launch (smm_group_apply_sb).  The levels'
+// CSR / epilogue pointers travel BY VALUE in the kernel argument segment: a workgroup picks its level's five
+// pointers with a wave-uniform index -- scalar loads from the kernarg segment -- and reads the CSR through
+// constant-address-space views of them, so the column / weight / row-pointer streams stay scalar loads exactly as
+// in the single-operator kernel (a pointer table in device memory turned them into vector loads: 162 instead of
+// 88 VGPRs).  kSbGroupLevels * 40 B + the rest stays below the 4-KiB kernarg limit; longer groups take several launches.
+constexpr int kSbGroupLevels = 88;
+struct SbLevelPtrs {
+  const int64_t* rowptr;
+  const int32_t* col;
+  const double* val;
+  const uint8_t* imask;   // null = no mask applied on this level
+  const double* frac;
+};
+struct SbGroupArgs {
+  const void* x;             // level l's (S, ldx) slab at x + l * xs_lev elements
+  void* y;                   // level l's results at y + l * ys_lev elements
+  int64_t xs_lev, ys_lev;
+  int64_t ldx, ldy, n_batch, n_dst;
+  int64_t n_dtiles, n_btiles;
+  int64_t blocks_per_level;  // n_dtiles * n_btiles
+  double area_min;
+  int xcd_remap, b_fastest;
+  int n_lev;
+  SbLevelPtrs lev[kSbGroupLevels];
+};
+static_assert(sizeof(SbGroupArgs) <= 4096, "kernel arguments are limited to 4 KiB");
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-B staging piece
@@ -970,8 +998,27 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
 // (Workgroups of 2 / 4 waves sharing one tile -- 18 / 20 instead of 9 waves per CU -- were built and
 // measured level with single-wave workgroups, 1.69 / 1.59 vs 1.62 ms on config 2: the kernel runs at
 // the rate the chip sustains for this read : write mix, occupancy is not what bounds it.)
-template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
-__global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
+// The CSR and epilogue vectors of one operator as the kernel body reads them: plain kernel-argument pointers
+// (single operator) or constant-address-space views (level group, see SbGroupArgs).
+template <typename I64P, typename I32P, typename F64P, typename U8P>
+struct SbMatrix {
+  I64P rowptr;
+  I32P col;
+  F64P val;
+  U8P imask;
+  F64P frac;
+};
+struct SbTile {   // what does not depend on the level
+  const void* x;
+  void* y;
+  int64_t ldx, ldy, n_batch, n_dst, n_dtiles, n_btiles;
+  uint32_t n_blocks;   // blocks of this operator's grid (for the XCD remap)
+  double area_min;
+  int masked, xcd_remap, b_fastest;
+};
+
+template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB, typename M>
+__device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32_t bid) {
   constexpr int VEC = 2;                    // batch entries per lane
   constexpr int BT = 64 * VEC;              // batch entries per tile
   constexpr int PAD = 16 / (int)sizeof(YT); // LDS row padding: one 16-B slot (conflict-free transposed reads)
@@ -982,10 +1029,10 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   typedef xvec xvec_u __attribute__((aligned(sizeof(XT))));   // element-aligned (any ldx / base)
 
   const int lane = threadIdx.x;
-  uint32_t bid = blockIdx.x;   // grids stay below 2^31 blocks: 32-bit index arithmetic
+  // grids stay below 2^31 blocks: 32-bit index arithmetic
   if (a.xcd_remap > 0) {   // runs of consecutive tiles (neighbours in space) share one XCD's L2
     const uint32_t C = (uint32_t)a.xcd_remap, round = 8 * C;
-    if (bid < ((uint32_t)a.n_blocks / round) * round) {
+    if (bid < (a.n_blocks / round) * round) {
       const uint32_t xcd = bid & 7, slot = bid >> 3;
       bid = (slot / C) * round + xcd * C + (slot % C);
     }
@@ -1019,10 +1066,10 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   if (bl > b_last) bl = b_last;
   const XT* __restrict__ xl = (const XT*)a.x + bl;
 
-  const int64_t p0 = a.rowptr[d0], p1 = a.rowptr[d0 + rows];
+  const int64_t p0 = m.rowptr[d0], p1 = m.rowptr[d0 + rows];
   int d_local = 0;
-  int64_t row_end = a.rowptr[d0 + 1];
-  int64_t row_end_next = a.rowptr[d0 + (rows > 1 ? 2 : 1)];   // scalar prefetch, one row ahead
+  int64_t row_end = m.rowptr[d0 + 1];
+  int64_t row_end_next = m.rowptr[d0 + (rows > 1 ? 2 : 1)];   // scalar prefetch, one row ahead
   double acc[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.0;
@@ -1032,8 +1079,8 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   // outstanding X loads
   bool dead_lane = false;
   if (lane < rows) {
-    if (a.masked && a.imask) dead_lane = a.imask[d0 + lane] == 0;
-    if (a.area_min > 0.0 && a.frac) dead_lane = dead_lane || (a.frac[d0 + lane] < a.area_min);
+    if (a.masked && m.imask) dead_lane = m.imask[d0 + lane] == 0;
+    if (a.area_min > 0.0 && m.frac) dead_lane = dead_lane || (m.frac[d0 + lane] < a.area_min);
   }
   const unsigned long long dead_mask = __ballot(dead_lane);
 
@@ -1053,7 +1100,7 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
     ++d_local;
     row_end = row_end_next;
     const int nxt = d_local + 2 <= rows ? d_local + 2 : rows;
-    row_end_next = a.rowptr[d0 + nxt];
+    row_end_next = m.rowptr[d0 + nxt];
   };
 
   xvec xv[2][U];
@@ -1063,8 +1110,8 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
     for (int u = 0; u < U; ++u) {
       int64_t p = base + u;
       if (p > p1 - 1) p = p1 - 1;            // padding repeats the tile's last link (valid address)
-      const int64_t c = a.col[p];
-      w[buf][u] = a.val[p];
+      const int64_t c = m.col[p];
+      w[buf][u] = m.val[p];
       xv[buf][u] = *(const xvec_u*)(xl + c * a.ldx);
     }
   };
@@ -1097,8 +1144,8 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
     // fewer batch entries than one lane's vector: element-wise walk (never on a hot path)
     for (int64_t p = p0; p < p1; ++p) {
       while (row_end <= p) flush_row();
-      const int64_t c = a.col[p];
-      const double wv = a.val[p];
+      const int64_t c = m.col[p];
+      const double wv = m.val[p];
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         const int64_t b = b0 + (int64_t)lane * VEC + v;
@@ -1156,6 +1203,34 @@ __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
       }
     }
   }
+}
+
+template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
+__global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
+  const SbMatrix<const int64_t*, const int32_t*, const double*, const uint8_t*> m{a.rowptr, a.col, a.val, a.imask, a.frac};
+  const SbTile t{a.x, a.y, a.ldx, a.ldy, a.n_batch, a.n_dst, a.n_dtiles, a.n_btiles, (uint32_t)a.n_blocks,
+                 a.area_min, a.masked, a.xcd_remap, a.b_fastest};
+  sb_tile_body<XT, YT, TD, U, FILL, YSB>(m, t, blockIdx.x);
+}
+
+// The same tiles for every data level of a group in one launch: workgroup -> (level, tile of that level's grid).
+// Levels are independent, so the dispatcher backfills the thin deep levels' tails with the next level's tiles -- no
+// ramp-up and tail per level as with one launch each.
+template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
+__global__ __launch_bounds__(64) void smm_group_apply_sb_kernel(SbGroupArgs a) {
+  typedef const __attribute__((address_space(4))) int64_t* k_i64;
+  typedef const __attribute__((address_space(4))) int32_t* k_i32;
+  typedef const __attribute__((address_space(4))) double* k_f64;
+  typedef const __attribute__((address_space(4))) uint8_t* k_u8;
+  const uint32_t per = (uint32_t)a.blocks_per_level;
+  const uint32_t lvl = blockIdx.x / per;          // wave-uniform: the level's pointers come through scalar loads
+  const uint32_t bid = blockIdx.x - lvl * per;
+  const SbLevelPtrs L = a.lev[lvl];
+  // the operator's arrays are immutable while a kernel runs: constant address space keeps their loads scalar
+  const SbMatrix<k_i64, k_i32, k_f64, k_u8> m{(k_i64)L.rowptr, (k_i32)L.col, (k_f64)L.val, (k_u8)L.imask, (k_f64)L.frac};
+  const SbTile t{(const XT*)a.x + (int64_t)lvl * a.xs_lev, (YT*)a.y + (int64_t)lvl * a.ys_lev, a.ldx, a.ldy, a.n_batch,
+                 a.n_dst, a.n_dtiles, a.n_btiles, per, a.area_min, L.imask != nullptr, a.xcd_remap, a.b_fastest};
+  sb_tile_body<XT, YT, TD, U, FILL, YSB>(m, t, bid);
 }
 
 // counter-based synthetic field: splitmix64 -> two uniforms -> Box-Muller
