@@ -295,13 +295,11 @@ int smm_group_apply(smm_group_t g,
  * y + l * ys_lev + b * ys_batch + d.  Y as regrid3d lays it out with transpose (B, L, D):
  * ys_lev = D, ys_batch = L * D; without (L, B, D): ys_lev = B * D, ys_batch = D.  With SMM_APPLY_SB_Y_SB
  * the result stays batch-fastest per level, Y (L, D, ys_batch >= B): ys_lev = D * ys_batch.  Same level_index /
- * masked_levels semantics and the same bits as smm_group_apply.  One kernel launch per data level: the
- * levels are independent, so they are dealt over a pool of streams owned by the group that is forked from
- * `stream` and joined back to it by events -- for the caller everything is ordered on `stream` as before,
- * while the ramp-up and tail of the per-level launches overlap (BASELINE config 3 kept batch-fastest:
- * 14.4 -> 9.9 ms).  Captured into a hipGraph the call is a fork / join sub-graph (after one warm-up call, which
- * creates the pool and uploads the CSR copies).  smm_group_prepare_sb uploads the members' CSRs ahead of time
- * (else done by the first call).
+ * masked_levels semantics and the same bits as smm_group_apply.  All data levels run in ONE kernel launch (the
+ * levels' CSR pointers travel in the kernel arguments; groups of more than 88 data levels take several launches),
+ * ordered on `stream` and capturable into a hipGraph after one warm-up call, which uploads the members' CSR copies
+ * (smm_group_prepare_sb does that ahead of time).  BASELINE config 3 kept batch-fastest: 14.4 ms with one launch per
+ * level, 9.5 ms grouped.
  */
 int smm_group_prepare_sb(smm_group_t g);
 int smm_group_apply_sb(smm_group_t g,
@@ -349,7 +347,7 @@ enum {
   SMM_TUNE_XCD_RUN,             /* tile + batch-fastest kernels: consecutive blocks per XCD (-1 = dispatcher order) */
   SMM_TUNE_SB_STRIP,            /* batch-fastest kernel: destination tiles per strip (-1 = whole-grid order)   */
   SMM_TUNE_SB_LOADS,            /* batch-fastest kernel: loads per batch of the link walk (4, 8)               */
-  SMM_TUNE_SB_POOL_STREAMS,     /* smm_group_apply_sb: streams of the level pool (-1 = the caller's stream only) */
+  SMM_TUNE_SB_LEVEL_LAUNCHES,   /* smm_group_apply_sb: 1 = one launch per data level instead of one grouped launch */
   SMM_TUNE_COUNT
 };
 int smm_debug_set_tuning(int knob, int value, int* previous);

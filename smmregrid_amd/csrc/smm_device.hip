@@ -42,7 +42,8 @@ namespace smm_launch {
   extern template int launch_sell<XT, YT>(const ApplyArgs&, int64_t, bool, unsigned, hipStream_t);      \
   extern template int launch_tile<XT, YT>(const ApplyArgs&, int64_t, int, int64_t, int64_t, int, bool, \
                                           unsigned, hipStream_t);                                       \
-  extern template int launch_sb<XT, YT>(const SbArgs&, bool, unsigned, hipStream_t);
+  extern template int launch_sb<XT, YT>(const SbArgs&, bool, unsigned, hipStream_t);                   \
+  extern template int launch_sb_group<XT, YT>(const SbGroupArgs&, bool, unsigned, hipStream_t);
 SMM_EXTERN_PAIR(double, double)
 SMM_EXTERN_PAIR(double, float)
 SMM_EXTERN_PAIR(float, double)
@@ -221,14 +222,6 @@ struct smm_group {
   std::map<std::string, void*> cfg_cache;
   std::mutex pipe_mu;  // smm_group_apply_host calls on one group take turns
   HostPipe pipe;
-  // smm_group_apply_sb launches one kernel per data level.  The levels are independent, so they are dealt
-  // over a pool of streams forked from and joined to the caller's stream by events: the ramp-up and the
-  // tail of 75 launches overlap instead of adding up (config 3 batch-fastest: 14.4 -> 9.9 ms).
-  static constexpr int kSbStreams = 16;
-  std::mutex sb_mu;     // enqueueing calls on one group take turns (the fork / join events are shared)
-  bool sb_pool_ready = false;
-  hipStream_t sb_stream[kSbStreams] = {};
-  hipEvent_t sb_fork = nullptr, sb_join[kSbStreams] = {};
 };
 
 namespace {
@@ -325,6 +318,7 @@ int ensure_plan(smm_operator* op, int which) {
 using smm_launch::launch_sell;
 using smm_launch::launch_tile;
 using smm_launch::launch_sb;
+using smm_launch::launch_sb_group;
 
 // Device copy of the canonical CSR (+ packed column ranks) for the batch-fastest kernel.
 int ensure_sb(smm_operator* op) {
@@ -1322,11 +1316,6 @@ int smm_group_destroy(smm_group_t g) {
   DeviceGuard guard(g->device);
   for (auto& kv : g->cfg_cache) (void)hipFree(kv.second);
   (void)hipFree(g->d_descs);
-  for (int i = 0; i < smm_group::kSbStreams; ++i) {   // queued work finishes before the runtime lets go of them
-    if (g->sb_stream[i]) (void)hipStreamDestroy(g->sb_stream[i]);
-    if (g->sb_join[i]) (void)hipEventDestroy(g->sb_join[i]);
-  }
-  if (g->sb_fork) (void)hipEventDestroy(g->sb_fork);
   for (smm_operator_t op : g->ops) op->group_refs.fetch_sub(1);
   delete g;
   return SMM_OK;
@@ -1453,10 +1442,14 @@ int smm_group_prepare_sb(smm_group_t g) {
   return SMM_OK;
 }
 
-// One launch of the batch-fastest kernel per data level: the kernel reads its column / weight /
-// row-pointer streams through scalar loads only when those pointers are kernel arguments (a level
-// table on the device turned them into vector loads: 162 instead of 88 VGPRs, 15 % slower), and a
-// level's grid (D / 16 x B / 128 workgroups) fills the chip on its own.
+// All data levels in ONE launch of the batch-fastest kernel (smm_group_apply_sb_kernel): the levels' CSR / epilogue
+// pointers travel by value in the kernel arguments (a pointer table in device memory made the column / weight /
+// row-pointer streams vector loads, 162 instead of 88 VGPRs; through kernarg + constant-address-space views they
+// stay scalar), so the dispatcher balances thin deep levels against the surface ones and there is no ramp-up and
+// tail per level.  Groups of more than kSbGroupLevels data levels take several launches on the caller's stream.
+// BASELINE config 3 kept batch-fastest, same box: 9.51 ms against 10.24 ms for one launch per level dealt over a
+// pool of 8 streams (round 4's form, removed: profiles/r05_cfg3sb_grouped_vs_stream_pool.txt) and 14.4 ms for one
+// launch per level on one stream (still there: SMM_TUNE_SB_LEVEL_LAUNCHES, and for levels beyond the grid limit).
 int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev, int64_t ldx, void* y,
                        int y_dtype, int64_t ys_lev, int64_t ys_batch, int64_t n_batch, int64_t n_lev,
                        const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min,
@@ -1486,65 +1479,56 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
     int vrc = check_sb_levels(g, n_lev, level_index, masked_levels, remap_area_min, flags);
     if (vrc) return vrc;
   }
-  // One launch per data level (see smm_group: the stream pool).  SMM_TUNE_SB_POOL_STREAMS: -1 = all levels on
-  // the caller's stream (the round-3 form), n = that many pool streams instead of 8.
-  const int pool_knob = smm::tuning(SMM_TUNE_SB_POOL_STREAMS);
-  const int n_pool = (n_lev < 2 || pool_knob < 0)
-                         ? 0
-                         : (int)std::min<int64_t>(n_lev, std::min(pool_knob > 0 ? pool_knob : 8, (int)smm_group::kSbStreams));
+  const bool per_level_launches = smm::tuning(SMM_TUNE_SB_LEVEL_LAUNCHES) == 1;
   hipStream_t caller = (hipStream_t)stream;
   DeviceGuard guard(g->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
-  std::unique_lock<std::mutex> pool_lock(g->sb_mu, std::defer_lock);
-  if (n_pool > 0) {
-    pool_lock.lock();
-    if (!g->sb_pool_ready) {
-      // every stream / event is created once: a call that failed half-way leaves what it made for the next one
-      for (int i = 0; i < smm_group::kSbStreams; ++i) {
-        if (!g->sb_stream[i]) SMM_HIP(hipStreamCreateWithFlags(&g->sb_stream[i], hipStreamNonBlocking));
-        if (!g->sb_join[i]) SMM_HIP(hipEventCreateWithFlags(&g->sb_join[i], hipEventDisableTiming));
+  const int64_t n_dst = g->ops[0]->csr.n_dst;
+  const int64_t per_level = ((n_dst + (ysz == 8 ? 16 : 32) - 1) / (ysz == 8 ? 16 : 32)) * ((n_batch + 127) / 128);
+  if (!per_level_launches && per_level <= grid_limit()) {
+    // grouped launches of as many levels as the kernel arguments (and the launch grid) hold
+    for (smm_operator* op : g->ops) {          // the canonical CSR copies the kernel reads (uploaded once)
+      int erc = ensure_sb(op);
+      if (erc) return erc;
+    }
+    const int64_t max_lev = std::max<int64_t>(1, std::min<int64_t>(kSbGroupLevels, grid_limit() / per_level));
+    const bool fill = !(flags & SMM_APPLY_NO_FILL);
+    for (int64_t l0 = 0; l0 < n_lev; l0 += max_lev) {
+      SbGroupArgs a{};
+      a.n_lev = (int)std::min<int64_t>(max_lev, n_lev - l0);
+      a.x = (const char*)x + (size_t)l0 * xs_lev * xsz;
+      a.y = (char*)y + (size_t)l0 * ys_lev * ysz;
+      a.xs_lev = xs_lev;
+      a.ys_lev = ys_lev;
+      a.ldx = ldx;
+      a.ldy = ys_batch;
+      a.n_batch = n_batch;
+      a.n_dst = n_dst;
+      a.area_min = remap_area_min;
+      for (int i = 0; i < a.n_lev; ++i) {
+        const int w = level_index[l0 + i];
+        const smm_operator* op = g->ops[(size_t)w];
+        const bool m = (flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w]);   // regrid.py:405
+        a.lev[i] = SbLevelPtrs{op->d_csr_rowptr, op->d_csr_col, op->d_csr_val, m ? op->d_imask : nullptr, op->d_frac};
       }
-      if (!g->sb_fork) SMM_HIP(hipEventCreateWithFlags(&g->sb_fork, hipEventDisableTiming));
-      g->sb_pool_ready = true;
+      const int rc = x_dtype == SMM_F64
+                         ? (y_dtype == SMM_F64 ? launch_sb_group<double, double>(a, fill, flags, caller)
+                                               : launch_sb_group<double, float>(a, fill, flags, caller))
+                         : (y_dtype == SMM_F64 ? launch_sb_group<float, double>(a, fill, flags, caller)
+                                               : launch_sb_group<float, float>(a, fill, flags, caller));
+      if (rc) return rc;
     }
+    return SMM_OK;
   }
+  // A level whose own grid exceeds the launch limit (smm_apply_sb cuts its batch into parts), or the tuning knob
+  // SMM_TUNE_SB_LEVEL_LAUNCHES: one launch per data level on the caller's stream.
   int status = SMM_OK;
-  hipError_t herr = hipSuccess;
-  const char* hwhat = "";
-  auto note = [&](hipError_t e, const char* what) {
-    if (e != hipSuccess && herr == hipSuccess) {
-      herr = e;
-      hwhat = what;
-    }
-    return e == hipSuccess;
-  };
-  int n_forked = 0;   // pool streams that wait for the fork event: exactly these are joined below
-  if (n_pool > 0 && note(hipEventRecord(g->sb_fork, caller), "hipEventRecord(fork)")) {   // the pool starts after the caller's queue
-    for (; n_forked < n_pool; ++n_forked)
-      if (!note(hipStreamWaitEvent(g->sb_stream[n_forked], g->sb_fork, 0), "hipStreamWaitEvent(fork)")) break;
-  }
-  const bool fork_failed = n_pool > 0 && n_forked < n_pool;
-  if (fork_failed) status = SMM_ERR_HIP;     // nothing is launched on a half-forked pool
   for (int64_t l = 0; l < n_lev && status == SMM_OK; ++l) {
     const int w = level_index[l];
     unsigned fl = flags & ~(unsigned)SMM_APPLY_MASKED;
     if ((flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w])) fl |= SMM_APPLY_MASKED;   // regrid.py:405
     status = smm_apply_sb(g->ops[(size_t)w], (const char*)x + (size_t)l * xs_lev * xsz, x_dtype, ldx,
-                          (char*)y + (size_t)l * ys_lev * ysz, y_dtype, ys_batch, n_batch, remap_area_min, fl,
-                          n_pool > 0 ? g->sb_stream[l % n_pool] : caller);
-  }
-  // join: whatever was queued on the pool -- also after a failing level or a failing HIP call -- is waited for by
-  // the caller's stream; a stream that cannot be joined by an event is drained on the host instead, so nothing
-  // is still writing Y when the call returns an error
-  for (int i = 0; i < n_forked; ++i) {
-    const bool joined = note(hipEventRecord(g->sb_join[i], g->sb_stream[i]), "hipEventRecord(join)") &&
-                        note(hipStreamWaitEvent(caller, g->sb_join[i], 0), "hipStreamWaitEvent(join)");
-    if (!joined) (void)hipStreamSynchronize(g->sb_stream[i]);
-  }
-  if (herr != hipSuccess) {
-    (void)hipGetLastError();
-    // a level's own failure keeps its status and message; a fork / join failure is reported as such
-    if (status == SMM_OK || fork_failed) return fail(SMM_ERR_HIP, std::string(hwhat) + ": " + hipGetErrorString(herr));
+                          (char*)y + (size_t)l * ys_lev * ysz, y_dtype, ys_batch, n_batch, remap_area_min, fl, caller);
   }
   return status;
 }

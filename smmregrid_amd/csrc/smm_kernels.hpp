@@ -599,6 +599,9 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
           if (slice_live) {
             const char* lds_b = smem + (size_t)(group * R + r) * tile_bytes;
             double acc = 0.0;
+#ifdef SMM_EXP_SKIP_COMPUTE   // timing-only ablation (tools/exp/build_exp.sh): stage and store, no link loop
+            acc = w[0] + (double)(lds_b - smem);
+#else
 #pragma unroll
             for (int k0 = 0; k0 < KREG; k0 += 4) {
               if (k0 < wmax) {
@@ -619,6 +622,7 @@ __global__ __launch_bounds__(tile_waves(MAXK) * 64, 2) void smm_apply_tile2_kern
                 }
               }
             }
+#endif
             acc = len > 0 ? acc : 0.0;
             pend_out[r] = (YT)epilogue(acc, dead);
             pend_off[r] = yw.off;

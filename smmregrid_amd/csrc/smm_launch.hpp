@@ -285,4 +285,39 @@ int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
   return SMM_OK;
 }
 
+// The batch-fastest kernel over the data levels of a group in ONE launch (smm_group_apply_sb): grid = levels x
+// (destination tiles x batch tiles); the caller has filled a.lev[0 .. n_lev) and the per-level strides.
+template <typename XT, typename YT>
+int launch_sb_group(const SbGroupArgs& a, bool fill, unsigned flags, hipStream_t s) {
+  SbGroupArgs args = a;
+  constexpr int TD = sizeof(YT) == 8 ? 16 : 32;
+  constexpr int BT = 128;
+  args.n_dtiles = (a.n_dst + TD - 1) / TD;
+  args.n_btiles = (a.n_batch + BT - 1) / BT;
+  args.blocks_per_level = args.n_dtiles * args.n_btiles;
+  const int64_t total = args.blocks_per_level * a.n_lev;
+  if (total <= 0) return SMM_OK;
+  if (total > 0x7fffffffLL) return smm::fail_msg(SMM_ERR_INVALID, "launch grid exceeds 2^31-1 blocks");
+  args.xcd_remap = xcd_run_length();
+  const int strip = smm::tuning(SMM_TUNE_SB_STRIP);
+  args.b_fastest = strip < 0 ? 0 : (strip > 0 ? strip : 2);
+  const bool ysb = (flags & SMM_APPLY_SB_Y_SB) != 0;
+  auto go = [&](auto u_tag, auto fill_tag) {
+    constexpr int UU = decltype(u_tag)::value;
+    constexpr bool FF = decltype(fill_tag)::value;
+    if (ysb)
+      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), 0, s, args);
+    else
+      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), 0, s, args);
+  };
+  auto with_fill = [&](auto u_tag) {
+    if (fill) go(u_tag, std::true_type());
+    else go(u_tag, std::false_type());
+  };
+  if (smm::tuning(SMM_TUNE_SB_LOADS) == 4) with_fill(std::integral_constant<int, 4>());
+  else with_fill(std::integral_constant<int, 8>());
+  SMM_LAUNCH_HIP(hipGetLastError());
+  return SMM_OK;
+}
+
 }  // namespace smm_launch

@@ -6,4 +6,5 @@ template int launch_sell<SMM_XT, SMM_YT>(const ApplyArgs&, int64_t, bool, unsign
 template int launch_tile<SMM_XT, SMM_YT>(const ApplyArgs&, int64_t, int, int64_t, int64_t, int, bool, unsigned,
                                          hipStream_t);
 template int launch_sb<SMM_XT, SMM_YT>(const SbArgs&, bool, unsigned, hipStream_t);
+template int launch_sb_group<SMM_XT, SMM_YT>(const SbGroupArgs&, bool, unsigned, hipStream_t);
 }  // namespace smm_launch

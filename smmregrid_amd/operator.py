@@ -362,8 +362,7 @@ class OperatorGroup:
         per data level the B batch values of each source cell contiguous.  Returns (B, n_lev, D) when
         transpose (regrid.py:420-427) else (n_lev, B, D); bit-identical to `apply` on the transposed field.
         keep_batch_fastest: the result stays batch-fastest per level, (n_lev, D, B) tagged "sb".
-        One launch per data level: the library deals them over the group's stream pool (forked from and joined
-        back to `stream`), so the levels' ramp-ups and tails overlap.
+        All data levels run in one grouped launch (several for more than 88 levels), ordered on `stream`.
         n_batch: batch entries when the last axis of x is a padded pitch (see SparseOperator.apply_sb)."""
         if not isinstance(x, DeviceArray) or x.ndim != 3 or x.shape[1] != self.n_src:
             raise ValueError(f"X must be a DeviceArray (n_lev, {self.n_src}, B)")

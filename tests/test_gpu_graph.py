@@ -38,10 +38,10 @@ def test_apply_is_graph_capturable(hip, rng):
     hiprt.hipGraphDestroy(graph)
 
 
-def test_group_apply_sb_with_its_stream_pool_is_graph_capturable(hip, rng):
-    """smm_group_apply_sb forks its per-level launches onto the group's stream pool and joins them back with
-    events: captured on the caller's stream that is an ordinary fork / join sub-graph (the pool and the CSR
-    copies exist after the warm-up call, so the capture allocates nothing)."""
+def test_group_apply_sb_is_graph_capturable(hip, rng):
+    """smm_group_apply_sb is one grouped kernel launch on the caller's stream (round 5; round 4 forked per-level
+    launches onto a pool of streams): captured it is a single kernel node (the CSR copies exist after the warm-up
+    call, so the capture allocates nothing)."""
     from smmregrid_amd import OperatorGroup
     from tests.helpers import ragged_links, random_links
     hiprt = ctypes.CDLL("libamdhip64.so.7")
@@ -64,7 +64,7 @@ def test_group_apply_sb_with_its_stream_pool_is_graph_capturable(hip, rng):
     xd = to_device(np.ascontiguousarray(np.transpose(x[:, :, 0, :], (1, 2, 0))))
     dy = DeviceArray((B, L, D), np.float64)
     s = Stream()
-    grp.apply_sb(xd, level_index, ml, y=dy, masked=True, remap_area_min=0.4, stream=s)   # warm-up: pool, CSR copies
+    grp.apply_sb(xd, level_index, ml, y=dy, masked=True, remap_area_min=0.4, stream=s)   # warm-up: CSR copies
     s.synchronize()
     dy.fill_bytes(0)
     graph, gexec = ctypes.c_void_p(), ctypes.c_void_p()

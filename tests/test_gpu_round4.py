@@ -182,11 +182,13 @@ def test_dma_request_on_unaligned_fields_falls_back_bit_equal(hip, rng, dtype):
         buf.free()
 
 
-def test_group_sb_levels_over_the_stream_pool(hip, rng):
-    """smm_group_apply_sb deals its per-level launches over a pool of streams forked from / joined to the
-    caller's stream.  Same bits with 4 / 8 / 16 pool streams and with all levels on the caller's stream
-    (tuning knob sb_pool_streams = 4 / default / 16 / -1); on a caller stream of its own the call is ordered between the
-    upload queued before it and the download queued after it; repeated calls reuse the pool."""
+def test_group_sb_levels_in_one_grouped_launch(hip, rng):
+    """smm_group_apply_sb runs every data level in ONE grouped launch (round 5: the levels' pointers travel in the
+    kernel arguments; round 4's stream pool of per-level launches is gone); the tuning knob sb_level_launches selects
+    one launch per level on the caller's stream.  Same bits either way; on a caller stream of its own the call is
+    ordered between the upload queued before it and the download queued after it.  More data levels than one launch's
+    arguments hold (88) -- and a forced launch-grid limit -- cut the grouped form into several launches with the
+    same bits."""
     from smmregrid_amd.device import Stream
     S, D, n_ops, B = 1100, 260, 7, 50
     ops, csrs = [], []
@@ -206,11 +208,33 @@ def test_group_sb_levels_over_the_stream_pool(hip, rng):
     ref = oracle.apply_levels(csrs, x, 1, level_index, ml.astype(bool), imask, frac, 0.4, True)   # (B, 1, L, D)
     x_sb = np.ascontiguousarray(np.transpose(x[:, :, 0, :], (1, 2, 0)))                            # (L, S, B)
     xd = to_device(x_sb)
-    for pool in (0, 4, 16, -1):
+    for per_level in (0, 1):
         for _ in range(2):
-            with _lib.tuning(sb_pool_streams=pool):
+            with _lib.tuning(sb_level_launches=per_level):
                 y = grp.apply_sb(xd, level_index, ml, masked=True, remap_area_min=0.4).to_host()
             assert_same(y.reshape(ref.shape), ref, exact=True)
+    # 200 data levels cycling through the 7 members: three grouped launches (88 + 88 + 24); then a launch-grid limit
+    # that lets only a few levels into one launch
+    many = np.tile(level_index, 11)[:200].astype(np.int32)
+    xm = np.ascontiguousarray(np.tile(x_sb, (11, 1, 1))[:200])
+    xmd = to_device(xm)
+    ym = grp.apply_sb(xmd, many, ml, masked=True, remap_area_min=0.4).to_host()
+    for rep in range(11):
+        n = min(L, 200 - rep * L)
+        assert_same(ym[:, rep * L:rep * L + n], ref[:, 0, :n], exact=True)
+    per_level = -(-D // 16) * -(-B // 128)
+    for limit in (per_level, 3 * per_level + 1):
+        _lib.call("smm_debug_set_grid_limit", limit)
+        try:
+            y2 = grp.apply_sb(xmd, many, ml, masked=True, remap_area_min=0.4).to_host()
+        finally:
+            _lib.call("smm_debug_set_grid_limit", 0)
+        assert np.array_equal(y2.view(np.uint64), ym.view(np.uint64))
+    # kept batch-fastest (Y (L, D, B)) through the grouped launch against one launch per level
+    yk = grp.apply_sb(xd, level_index, ml, masked=True, remap_area_min=0.4, keep_batch_fastest=True).to_host()
+    with _lib.tuning(sb_level_launches=1):
+        yk4 = grp.apply_sb(xd, level_index, ml, masked=True, remap_area_min=0.4, keep_batch_fastest=True).to_host()
+    assert np.array_equal(yk.view(np.uint64), yk4.view(np.uint64))
     # a caller stream of its own: H2D, apply, D2H all queued on it, one synchronisation at the end
     st = Stream()
     xs = DeviceArray(x_sb.shape, np.float64)
