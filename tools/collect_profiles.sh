@@ -26,7 +26,7 @@ for wl in $wls; do
         --steps 5 --warmup 1 --no-cpu-baseline --others none --configs none > /dev/null)
     (cd /tmp && rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $d/rdreq -- python3 \
         $root/bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --others none --configs none > /dev/null)
-    lps=1; case $wl in cfg3sb*) lps=75;; esac   # batch-fastest level groups: one launch per data level
+    lps=1   # launches per bench step (the batch-fastest level groups are one grouped launch since round 5)
     python3 tools/summarize_pmc.py --launches-per-step $lps --fetch $d/fetch --write $d/write --rdreq $d/rdreq --key $wl/default/auto/0 \
         --out $out/${tag}_${wl}_pmc_summary.json --traffic $out/traffic.json --git-head "${SMM_GIT_HEAD:-unknown}" > /dev/null
   fi

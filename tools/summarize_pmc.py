@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
     ap.add_argument("--rdreq")
-    ap.add_argument("--kernel", default="smm_apply")
+    ap.add_argument("--kernel", default="_apply_")
     ap.add_argument("--wide-loads", type=int, default=1, help="1: double FETCH_SIZE (16 B/lane streams)")
     ap.add_argument("--key", required=True)
     ap.add_argument("--out", required=True)
