@@ -6,12 +6,12 @@
 One "step" = one pass of the hot path over the whole batch of the workload.
 Default workload = config 2 of BASELINE.json (the configuration the metric is
 quoted on): r1440x721 -> r360x180 bilinear, 3600 time steps, f64, X and Y
-resident in HBM.  Other workloads (--workload): cfg3 (masked ocean levels,
-grouped launch), cfg5tile (config-5 geometry, one GPU's share of rows), cfg1,
-cfg2sb / cfg2sbp (config 2 with the field kept batch-fastest, X (S, B) or packed
-(U, B), Y still (B, D): the opt-in operand layout for device-resident producers),
-cfg4 / cfg5 (one GPU's share of BASELINE configs 4 / 5: with --gpus 8 these are the
-fixed-total-batch lines of BASELINE.json).
+resident in HBM.  Other workloads (--workload, see WORKLOADS): cfg3 / cfg3c / cfg3sb (masked ocean
+levels, one grouped launch; rows on 128-B lines / packed / every level kept batch-fastest), cfg2sb /
+cfg2sbk (config 2 with the field kept batch-fastest: the opt-in operand layout for device-resident
+producers), cfg4s / cfg5tile (config-4 / config-5 geometry, reduced batch), cfg4 / cfg5 (one GPU's
+share of BASELINE configs 4 / 5: with --gpus 8 these are the fixed-total-batch lines of BASELINE.json),
+cfg1, upsample, conhi.
 
 For N > 1 there is one rank per GPU: either the caller started them (torch.distributed.run /
 any launcher that exports RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT), or -- when
@@ -54,55 +54,33 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
-    # name: (method, source grid, target grid, batch rows, x dtype)
+    # name: (method, source grid, target grid, batch rows, x dtype[, layout])
+    # the driver's line: config 2 (headline) ...
     "cfg2": ("bil", "r1440x721", "r360x180", 3600, "f64"),
-    # config 2 with the operand kept batch-fastest by a device-resident producer (smm_apply_sb):
-    # "sb" = X (S, B), "sbp" = X (U, B) holding only the used source cells
+    # ... config 2 with the operand kept batch-fastest by a device-resident producer (smm_apply_sb): "sb" = X (S, B),
+    # "sbk" = the result kept batch-fastest too, Y (D, B): what a chain of regrids passes on (SMM_APPLY_SB_Y_SB)
     "cfg2sb": ("bil", "r1440x721", "r360x180", 3600, "f64", "sb"),
-    "cfg2sbp": ("bil", "r1440x721", "r360x180", 3600, "f64", "sbp"),
-    # ... and the result kept batch-fastest too, Y (D, B): what a chain of regrids passes on (SMM_APPLY_SB_Y_SB)
     "cfg2sbk": ("bil", "r1440x721", "r360x180", 3600, "f64", "sbk"),
-    # config 2 with the exact-zero links dropped at operator creation (SMM_CREATE_PRUNE_ZEROS: the grids are
-    # aligned, 3 of the 4 bilinear links of every row weigh exactly 0) -- same results, a quarter of the links
-    "cfg2z": ("bil", "r1440x721", "r360x180", 3600, "f64", "bs+z"),
-    "cfg2zsb": ("bil", "r1440x721", "r360x180", 3600, "f64", "sb+z"),
-    "cfg5sb": ("con", "r1440x721", "r720x360", 1024, "f64", "sb"),
-    "conmidsb": ("con", "r1440x720", "r360x180", 1024, "f64", "sb"),
-    "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
-    "upsample": ("bil", "r360x180", "r1440x721", 1024, "f64"),    # coarse -> fine: Y-write bound
-    "nnhi": ("nn", "r3600x1800", "r360x180", 256, "f64"),          # 1 link per row, 1 of 100 source cells used
-    "hpsrc": ("nn", "hp512_nested", "r1440x721", 256, "f32"),       # HEALPix (nested) source, nearest neighbour
-    "bilhi": ("bil", "r3600x1800", "r360x180", 256, "f64"),        # 4 links per row, pairs 80 B apart
-    "conhi": ("con", "r3600x1800", "r360x180", 256, "f64"),       # 0.1 deg -> 1 deg: ~120 links per row
-    "conmid": ("con", "r1440x720", "r360x180", 1024, "f64"),      # 0.25 deg -> 1 deg: 16-25 links per row
-    "cfg5": ("con", "r1440x721", "r720x360", 12741, "f64"),      # one GPU's share of config 5 (137 x 744 / 8)
-    "cfg1": ("bil", "r180x90", "r90x45", 1, "f64"),
-    # odd source size: f64 batch rows start on 8-byte boundaries only
-    "cfg2odd": ("bil", "r1441x721", "r360x180", 1024, "f64"),
-    # config-2 links with the source cells randomly renumbered (unstructured source, no locality): SELL path
-    "scatter": ("bilperm", "r1440x721", "r360x180", 1024, "f64"),
-    # config-4 geometry (regular Gaussian n1280 = 5120x2560 -> HEALPix nside 1024, f32 in), reduced batch
-    "cfg4s": ("bil", "n1280", "hp1024", 128, "f32"),
-    # the same with the opt-in narrowing store (y_dtype = SMM_F32; the reference always yields f64, regrid.py:550)
-    "cfg4sf32": ("bil", "n1280", "hp1024", 128, "f32", "bs+y32"),
-    "cfg4": ("bil", "n1280", "hp1024", 1095, "f32"),              # one GPU's share of config 4 (8760 / 8)
-    # one masked level of config 3 as a 2-D problem (ocean fraction in the name), for kernel tuning
-    "cfg3L66": ("conmask", (1442, 1021, 0.66), "r360x180", 1024, "f64"),
-    "cfg3L35": ("conmask", (1442, 1021, 0.35), "r360x180", 1024, "f64"),
-    "cfg3L05": ("conmask", (1442, 1021, 0.05), "r360x180", 1024, "f64"),
-    # masked levels: (method, source nx x ny, target, (time steps, levels), x dtype)
-    # "pad": field rows start on 128-B lines (row pitch rounded up to 16 doubles) -- the pitch the
-    # library's own H2D staging uses (smm_group_apply_host); "cfg3c": rows packed back to back, every
-    # row of the 1442x1021 grid then starts mid-line (S * 8 B = 80 mod 128)
+    # ... BASELINE config 3, masked levels: (method, source nx x ny, target, (time steps, levels), x dtype, layout).
+    # "pad": field rows start on 128-B lines (row pitch rounded up to 16 doubles: the pitch the library's own H2D
+    # staging uses); "cfg3c": rows packed back to back, every row of the 1442x1021 grid then starts mid-line
+    # (S * 8 B = 80 mod 128); "cfg3sb": the field kept batch-fastest per level, X (L, S, T) (smm_group_apply_sb)
     "cfg3": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "pad"),
     "cfg3c": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64"),
-    # config 3 with the field kept batch-fastest per level, X (L, S, T) (smm_group_apply_sb)
-    # (cells start on 128-B lines with the pitch T rounded up to 16;
-    # "cfg3sbc": pitch T itself -- 120 entries = 960 B, every other run straddles a line)
     "cfg3sb": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "sb"),
-    "cfg3sbc": ("con3d", (1442, 1021), "r360x180", (120, 75), "f64", "sbc"),
-    "cfg3sbs": ("con3d", (1442, 1021), "r360x180", (120, 6), "f64", "sb"),      # six levels of it: quick runs
+    # ... config-4 geometry (regular Gaussian n1280 = 5120x2560 -> HEALPix nside 1024, f32 in) with a reduced batch and
+    # one GPU's share of BASELINE configs 4 / 5 (8760 / 8 rows of f32; 137 x 744 / 8 rows of f64)
+    "cfg4s": ("bil", "n1280", "hp1024", 128, "f32"),
+    "cfg4": ("bil", "n1280", "hp1024", 1095, "f32"),
+    "cfg5tile": ("con", "r1440x721", "r720x360", 1024, "f64"),
+    "cfg5": ("con", "r1440x721", "r720x360", 12741, "f64"),
+    # not in the driver's line: config 1 (plumbing), a quick level group, and the two kernel forms the BASELINE configs
+    # do not reach -- coarse -> fine (4-KB tiles, two batch rows per LDS-DMA step; Y-write bound) and 0.1 -> 1 degree
+    # conservative (~120 links per row: rows split over lane groups)
+    "cfg1": ("bil", "r180x90", "r90x45", 1, "f64"),
     "cfg3s": ("con3d", (1442, 1021), "r360x180", (16, 8), "f64"),
+    "upsample": ("bil", "r360x180", "r1440x721", 1024, "f64"),
+    "conhi": ("con", "r3600x1800", "r360x180", 256, "f64"),
 }
 
 
@@ -169,52 +147,30 @@ class Problem2D:
         from smmregrid_amd.device import DeviceArray
         method, sgrid, tgrid, n_batch, self.x_dtype = WORKLOADS[name][:5]
         self.layout = WORKLOADS[name][5] if len(WORKLOADS[name]) > 5 else "bs"
-        opts = self.layout.split("+")[1:]
-        self.prune = "z" in opts
-        self.y_dt = np.float32 if "y32" in opts else np.float64     # f64 = the reference's result_type(x, f64)
-        self.layout = self.layout.split("+")[0]
+        self.y_dt = np.float64     # the reference's result_type(x, f64), regrid.py:550
         self.n_batch = batch or n_batch
-        if method == "conmask":
-            nx, ny, frac = sgrid
-            mask = gridgen.synthetic_ocean_masks(nx, ny, 1, top=frac)[0]
-            self.weights = gridgen.conservative_weights(gridgen.regular_grid(nx, ny), tgrid, src_mask=mask)
-            sgrid = f"{nx}x{ny} ocean {frac}"
-        elif method == "bilperm":
-            self.weights = gridgen.generate_weights(sgrid, tgrid, method="bil")
-            perm = np.random.default_rng(7).permutation(self.weights.sizes["src_grid_size"]).astype(np.int32)
-            self.weights["src_address"].data = perm[self.weights["src_address"].values - 1] + 1
-        else:
-            self.weights = gridgen.generate_weights(sgrid, tgrid, method=method)
+        self.weights = gridgen.generate_weights(sgrid, tgrid, method=method)
         w = self.weights
         self.n_src, self.n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
         self.op = SparseOperator(self.n_src, self.n_dst, w["src_address"].values,
                                  w["dst_address"].values, w["remap_matrix"].values, device=device,
-                                 dst_dims=w["dst_grid_dims"].values, prune_zeros=self.prune)
+                                 dst_dims=w["dst_grid_dims"].values)
         self.op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
         self.create_ms = self.op.create_ms     # smm_operator_create: sort + duplicate sum + layouts + upload
         self.np_dt = np.float64 if self.x_dtype == "f64" else np.float32
         x_shape = {"bs": (self.n_batch, self.n_src), "sb": (self.n_src, self.n_batch),
-                   "sbp": (self.op.n_used_src, self.n_batch), "sbk": (self.n_src, self.n_batch)}[self.layout]
+                   "sbk": (self.n_src, self.n_batch)}[self.layout]
         self.x = DeviceArray(x_shape, self.np_dt)
         self.x.fill_random(seed=20260723 + 1000003 * rank, mean=250.0, sigma=30.0)
         if self.layout != "bs":
             self.op.prepare_sb()
         self.y_shape = (self.n_dst, self.n_batch) if self.layout == "sbk" else (self.n_batch, self.n_dst)
-        lay = {"bs": "X (B, S) native layout", "sb": "X (S, B) batch-fastest", "sbp": "X (U, B) batch-fastest, used cells only",
-               "sbk": "X (S, B) batch-fastest"}
+        lay = {"bs": "X (B, S) native layout", "sb": "X (S, B) batch-fastest", "sbk": "X (S, B) batch-fastest"}
         self.desc = (f"{name}: {sgrid}->{tgrid} {method}, {self.n_batch} batch rows per GPU, "
                      f"{self.x_dtype} in / {'f32' if self.y_dt == np.float32 else 'f64'} out, {lay[self.layout]}, "
                      f"{'Y (D, B) kept batch-fastest' if self.layout == 'sbk' else 'Y (B, D)'}, X and Y resident in HBM")
         self.meta = {"S": self.n_src, "D": self.n_dst, "nnz": self.op.nnz, "U": self.op.n_used_src,
                      "plan": self.op.plan_info()}
-        if self.prune:
-            links = w.sizes["num_links"]
-            u_file = int(np.unique(w["src_address"].values).size)
-            isz = np.dtype(self.np_dt).itemsize
-            self.meta.update(zero_links_pruned=int(links - self.op.nnz), links_as_given=int(links), U_as_given=u_file,
-                             algorithmic_bytes_as_given=int(self.n_batch * (u_file * isz + self.n_dst * 8)
-                                                            + links * 12 + (self.n_dst + 1) * 4))
-            self.desc += f", {links - self.op.nnz} exact-zero links of {links} dropped at creation"
 
     def cells(self):
         return float(self.n_dst) * self.n_batch
@@ -241,8 +197,8 @@ class Problem2D:
         if self.layout == "bs":
             self.op.apply(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags)
         else:
-            self.op.apply_sb(self.x, y=y, masked=False, remap_area_min=0.5, packed=self.layout == "sbp",
-                             flags=flags, keep_batch_fastest=self.layout == "sbk")
+            self.op.apply_sb(self.x, y=y, masked=False, remap_area_min=0.5, flags=flags,
+                             keep_batch_fastest=self.layout == "sbk")
 
     def spot_check(self, y, max_dst=65536):
         """One batch row of the timed output against oracle/oracle.c (bit equality; NaN positions
@@ -260,11 +216,7 @@ class Problem2D:
             col = np.empty(n_rows, dtype=self.np_dt)
             _lib.call("smm_memcpy2d_d2h", col.ctypes.data_as(ctypes.c_void_p), isz,
                       ctypes.c_void_p(self.x.ptr + r * isz), self.n_batch * isz, isz, n_rows, None)
-            if self.layout == "sbp":
-                xrow = np.zeros(self.n_src, dtype=self.np_dt)
-                xrow[self.op.used_sources()] = col
-            else:
-                xrow = col
+            xrow = col
         if self.layout == "sbk":                # column r of the (D, B) result
             got = np.empty(self.n_dst, dtype=np.float64)
             _lib.call("smm_memcpy2d_d2h", got.ctypes.data_as(ctypes.c_void_p), 8, ctypes.c_void_p(y.ptr + r * 8),
@@ -299,7 +251,7 @@ class Problem2D:
         from smmregrid_amd import _lib
         from smmregrid_amd.device import dtype_code
         isz = np.dtype(self.np_dt).itemsize          # batch rows are a column range of the (S, B) field
-        fl = flags | (_lib.APPLY_SB_PACKED if self.layout == "sbp" else 0)
+        fl = flags
         _lib.call("smm_apply_sb", self.op.handle, ctypes.c_void_p(self.x.ptr + r0 * isz), dtype_code(self.x.dtype),
                   self.n_batch, ctypes.c_void_p(y.rows(r0, r1).ptr), dtype_code(y.dtype), self.n_dst, r1 - r0,
                   0.5, fl, None)
@@ -386,7 +338,7 @@ class ProblemLevels:
         slab = (10.0 + 5.0 * rng.standard_normal((n_lev, self.n_src), dtype=np.float32)).astype(np.float64)
         slab[masks == 0] = np.nan
         self.slab, self.masks = slab, masks
-        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] in ("sb", "sbc") else "bs"
+        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "sb" else "bs"
         self.nx, self.ny, self.tgrid = nx, ny, tgrid
         self.y_shape = (self.n_t, 1, n_lev, self.n_dst)
         self.np_dt = np.float64
@@ -405,14 +357,14 @@ class ProblemLevels:
         if self.x is not None:
             self.x.free()
         self.name, self.padded = name, bool(padded)
-        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] in ("sb", "sbc") else "bs"
+        self.layout = "sb" if len(WORKLOADS[name]) > 5 and WORKLOADS[name][5] == "sb" else "bs"
         self.y_shape = (self.n_t, 1, self.n_lev, self.n_dst)
         n_lev, slab = self.n_lev, self.slab
         nx, ny, tgrid = self.nx, self.ny, self.tgrid
         ldx = -(-self.n_src // 16) * 16 if self.padded else self.n_src
         if self.layout == "sb":
             # X (L, S, pitch >= T): every time step carries the same slab, so a cell's T values are one constant
-            self.ldt = self.n_t if WORKLOADS[name][5] == "sbc" else -(-self.n_t // 16) * 16
+            self.ldt = -(-self.n_t // 16) * 16          # cells start on 128-B lines
             self.x = DeviceArray((n_lev, self.n_src, self.ldt), np.float64)
             for lv in range(n_lev):
                 self.x.rows(lv, lv + 1).copy_from_host(np.repeat(slab[lv][:, None], self.ldt, axis=1)[None])
@@ -932,8 +884,7 @@ def hbm_need(args, name, rows, world, with_ring):
     method, sgrid, tgrid = WORKLOADS[name][:3]
     S, D = _grid_cells(sgrid), _grid_cells(tgrid)
     sx = 8 if WORKLOADS[name][4] == "f64" else 4
-    opts = WORKLOADS[name][5] if len(WORKLOADS[name]) > 5 else ""
-    sy = 4 if "y32" in opts else 8
+    sy = 8
     per_row = {"bil": 4, "nn": 1}.get(method, max(4, -(-S // D) + 5))
     need = {"x": rows * S * sx, "y": rows * D * sy, "operator": 64 * per_row * D, "ring": 0}
     if with_ring and world > 1:

@@ -8,7 +8,7 @@ from oracle import oracle
 from smmregrid_amd import SparseOperator, _lib, gridgen, to_device
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg4s"
-method, sgrid, tgrid, _, xd = WORKLOADS[name]
+method, sgrid, tgrid, _, xd = WORKLOADS[name][:5]
 t = time.time()
 w = gridgen.generate_weights(sgrid, tgrid, method=method)
 print("weights", time.time() - t, "s", dict(w.sizes))

@@ -29,18 +29,9 @@ def main():
     ap.add_argument("--variants", nargs="+", default=["sell", "tile", "tile:tile_walk=16", "tile:tile_x_loads=1"])
     ap.add_argument("--check", action="store_true", help="compare every variant's Y with the first one")
     args = ap.parse_args()
-    method, sgrid, tgrid, n_batch, x_dtype = WORKLOADS[args.workload]
+    method, sgrid, tgrid, n_batch, x_dtype = WORKLOADS[args.workload][:5]      # 2-D workloads, native layout
     n_batch = args.batch or n_batch
-    if method == "conmask":
-        nx, ny, frac = sgrid
-        mask = gridgen.synthetic_ocean_masks(nx, ny, 1, top=frac)[0]
-        w = gridgen.conservative_weights(gridgen.regular_grid(nx, ny), tgrid, src_mask=mask)
-    elif method == "bilperm":
-        w = gridgen.generate_weights(sgrid, tgrid, method="bil")
-        perm = np.random.default_rng(7).permutation(w.sizes["src_grid_size"]).astype(np.int32)
-        w["src_address"].data = perm[w["src_address"].values - 1] + 1
-    else:
-        w = gridgen.generate_weights(sgrid, tgrid, method=method)
+    w = gridgen.generate_weights(sgrid, tgrid, method=method)
     n_src, n_dst = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
     op = SparseOperator(n_src, n_dst, w["src_address"].values, w["dst_address"].values,
                         w["remap_matrix"].values, device=0)
