@@ -102,6 +102,25 @@ def test_eight_rank_dry_run_prints_the_hbm_need_and_skips_what_does_not_fit():
     assert line["baseline_configs"]["cfg5"]["value"] > 0 and line["value"] > 0
 
 
+def test_reference_sized_cases_of_the_bench_are_built_from_the_committed_fixtures():
+    """tools/user_path_bench.py (blocks `reference_sized` / `host_to_host` of the bench line) needs a GPU to run; what
+    can break without one -- the fixtures, their shapes, the record counts of speed-evaluation.ipynb cell 5 -- is
+    checked here."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import user_path_bench as u
+    cases = u._cases()
+    assert {n: f.shape for n, (_, f, _, _) in cases.items()} == {
+        "2t_era5": (12, 73, 144), "tas_healpix2": (12, 12288), "tas_ecearth": (12, 256, 512),
+        "temp3d_fesom": (12, 3, 3140), "ua_ipsl_nan": (2, 19, 143, 144)}
+    assert cases["ua_ipsl_nan"][2] == "r90x45" and cases["ua_ipsl_nan"][3] == {"check_nan": True}     # basic_test.py:95-102
+    assert all(t == "r360x180" for n, (_, _, t, _) in cases.items() if n != "ua_ipsl_nan")
+    ds = cases["temp3d_fesom"][0]
+    assert ds["lon_bnds"].shape == (3140, 16) and ds["temp"].coords["lon"].attrs["bounds"] == "lon_bnds"
+    import numpy as np
+    a = u._tile_time(np.arange(6, dtype=np.float32).reshape(2, 3), 5)
+    assert a.shape == (5, 3) and np.array_equal(a[2], a[0] + 1) and np.array_equal(a[4], a[0] + 2)
+
+
 def _strings(obj):
     if isinstance(obj, str):
         yield obj
