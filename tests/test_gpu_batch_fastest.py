@@ -151,10 +151,12 @@ def test_host_pipeline_packs_the_used_cells(hip, rng, dtype):
     assert_same(op.apply_host(x[:20], masked=True, remap_area_min=0.5), ref[:20], exact=True)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("transpose", [True, False])
-def test_group_apply_sb_matches_the_oracle(hip, rng, transpose):
+def test_group_apply_sb_matches_the_oracle(hip, rng, transpose, dtype):
     """Masked levels with the field kept batch-fastest per level, X (L, S, B): regrid.py:387-427 through the
-    batch-fastest kernel -- level sub-selection and repeats, per-level masks, odd batch sizes."""
+    batch-fastest kernel (one grouped launch) -- level sub-selection and repeats, per-level masks, odd batch sizes,
+    f32 fields (promoted to f64 as regrid.py:550 does) and the opt-in f32 store (the rounded f64 result)."""
     from smmregrid_amd import OperatorGroup
     S, D, n_ops = 900, 217, 4
     ops, csrs = [], []
@@ -170,13 +172,18 @@ def test_group_apply_sb_matches_the_oracle(hip, rng, transpose):
     masked_levels = np.array([1, 0, 1, 1], np.uint8)
     for level_index, B in [([0, 1, 2, 3], 130), ([2, 0, 2], 7), ([3], 1), ([1, 1, 0, 3, 2], 64)]:
         L = len(level_index)
-        x = field(rng, B * L, S, nan_frac=0.03).reshape(B, L, 1, S)           # native layout for the oracle
+        x = field(rng, B * L, S, dtype=dtype, nan_frac=0.03).reshape(B, L, 1, S)   # native layout for the oracle
         ref = oracle.apply_levels(csrs, x, 1, np.asarray(level_index), masked_levels.astype(bool), imask, frac,
                                   0.4, transpose)                            # (B, 1, L, D) / (L, B, 1, D)
         x_sb = np.ascontiguousarray(np.transpose(x[:, :, 0, :], (1, 2, 0)))   # (L, S, B)
         y = grp.apply_sb(to_device(x_sb), level_index, masked_levels, masked=True, remap_area_min=0.4,
                          transpose=transpose).to_host()
+        assert y.dtype == np.float64
         assert_same(y.reshape(ref.shape), ref, exact=True)
+        y32 = grp.apply_sb(to_device(x_sb), level_index, masked_levels, masked=True, remap_area_min=0.4,
+                           transpose=transpose, out_dtype=np.float32).to_host()
+        assert y32.dtype == np.float32
+        assert_same(y32.reshape(ref.shape), ref.astype(np.float32), exact=True)
         native = grp.apply(to_device(x), level_index, masked_levels, masked=True, remap_area_min=0.4,
                            transpose=transpose).to_host()
         assert_same(y.reshape(native.shape), native, exact=True)
