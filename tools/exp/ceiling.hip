@@ -5,7 +5,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/exp/ceiling.hip -o tools/exp/ceiling
 //   tools/exp/ceiling <read_run_B> <read_B_per_unit> <write_seg_B> <write_B_per_unit> <write_stride_B> [units] [wg_per_cu] [reps]
-//                     [read_pitch_B] [rows_per_tile] [slab_pitch_B]
+//                     [read_pitch_B] [rows_per_tile] [slab_pitch_B] [exact_rounds] [barrier]
 //
 // One wave = one "unit" at a time: it reads read_B_per_unit bytes as 1-KiB wave loads (16 B per lane,
 // eight in flight) whose bytes are cut into runs of read_run_B at pseudo-random 128-B-aligned places
@@ -53,6 +53,8 @@ struct Args {
   uint64_t src_mask;       // buffer size - 1
   uint32_t rows_per_tile;  // runs of one tile (<= runs per unit)
   uint64_t slab_pitch;     // > 0: a unit's tiles are one tile position in consecutive slabs this far apart
+  uint32_t exact_rounds;   // 0: rounds of eight loads (a short last round repeats its last piece); 2 / 4 / 8: loads per round
+  uint32_t barrier;        // 1: the four waves of a workgroup meet at a barrier after every unit (a kernel staging per batch row)
 };
 
 __device__ __forceinline__ uint64_t mix(uint64_t z) {
@@ -61,6 +63,9 @@ __device__ __forceinline__ uint64_t mix(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// Q = loads a wave issues per round before it waits (8 by default; exact_rounds = units whose read bytes are a multiple
+// of Q KiB issue exactly their own loads -- 2 or 4 for units of one or two batch rows of a small tile)
+template <int Q>
 __global__ __launch_bounds__(256) void ceiling_kernel(Args a) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -70,10 +75,10 @@ __global__ __launch_bounds__(256) void ceiling_kernel(Args a) {
   const uint32_t segs_per_unit = (a.write_unit + a.write_seg - 1) >> a.seg_shift;
   u32x4 acc = {0, 0, 0, 0};
   for (uint64_t u = wave; u < a.n_units; u += n_waves) {
-    for (uint32_t p0 = 0; p0 < n_rp; p0 += 8) {
-      u32x4 v[8];
+    for (uint32_t p0 = 0; p0 < n_rp; p0 += Q) {
+      u32x4 v[Q];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < Q; ++q) {
         const uint32_t p = p0 + q < n_rp ? p0 + q : n_rp - 1;
         const uint32_t o = p * 1024 + lane * 16;
         const uint32_t run = o >> a.run_shift, within = o & (a.read_run - 1);
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void ceiling_kernel(Args a) {
         v[q] = __builtin_nontemporal_load((const u32x4*)(a.src + at));
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc ^= v[q];
+      for (int q = 0; q < Q; ++q) acc ^= v[q];
     }
     const uint64_t urow = u / a.cols, ucol = u - urow * a.cols;   // once per unit
     for (uint32_t p = 0; p < n_wp; ++p) {
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(256) void ceiling_kernel(Args a) {
       out.x += p;
       __builtin_nontemporal_store(out, (u32x4*)d);
     }
+    if (a.barrier) __syncthreads();
   }
   if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u && n_wp == 0) a.dst[0] = 1;   // keeps the loads alive
 }
@@ -124,6 +130,8 @@ int main(int argc, char** argv) {
   a.read_pitch = argc > 9 ? (uint64_t)atoll(argv[9]) : 0;
   a.rows_per_tile = argc > 10 ? (uint32_t)atoll(argv[10]) : 0;
   a.slab_pitch = argc > 11 ? (uint64_t)atoll(argv[11]) : 0;
+  a.exact_rounds = argc > 12 ? (uint32_t)atoi(argv[12]) : 0;
+  a.barrier = argc > 13 ? (uint32_t)atoi(argv[13]) : 0;
   auto pow2 = [](uint32_t v) { return v >= 16 && (v & (v - 1)) == 0; };
   if (a.read_unit % 1024 || a.write_unit % 1024 || !pow2(a.read_run) || !pow2(a.write_seg) ||
       a.write_stride < a.write_seg || a.write_stride % a.write_seg) {
@@ -167,12 +175,22 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(ceiling_kernel, dim3(grid), dim3(256), 0, nullptr, a);
+  const int q_round = a.exact_rounds ? (int)a.exact_rounds : 8;
+  if ((q_round != 2 && q_round != 4 && q_round != 8) || (a.exact_rounds && (a.read_unit / 1024) % q_round)) {
+    fprintf(stderr, "exact_rounds: 2, 4 or 8 loads per round, dividing the unit's KiB\n");
+    return 2;
+  }
+  auto launch = [&]() {
+    if (q_round == 2) hipLaunchKernelGGL(ceiling_kernel<2>, dim3(grid), dim3(256), 0, nullptr, a);
+    else if (q_round == 4) hipLaunchKernelGGL(ceiling_kernel<4>, dim3(grid), dim3(256), 0, nullptr, a);
+    else hipLaunchKernelGGL(ceiling_kernel<8>, dim3(grid), dim3(256), 0, nullptr, a);
+  };
+  launch();
   CHECK(hipDeviceSynchronize());
   float best = 1e30f, sum = 0.f;
   for (int r = 0; r < reps; ++r) {
     CHECK(hipEventRecord(e0, nullptr));
-    hipLaunchKernelGGL(ceiling_kernel, dim3(grid), dim3(256), 0, nullptr, a);
+    launch();
     CHECK(hipEventRecord(e1, nullptr));
     CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -182,10 +200,10 @@ int main(int argc, char** argv) {
   }
   const double rb = (double)a.n_units * a.read_unit, wb = (double)a.n_units * a.write_unit;
   printf("{\"read_run\": %u, \"read_unit\": %u, \"write_seg\": %u, \"write_unit\": %u, \"write_stride\": %llu, "
-         "\"read_pitch\": %llu, \"rows_per_tile\": %u, \"slab_pitch\": %llu, \"units\": %llu, \"wg_per_cu\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, \"read_GBs\": %.1f, "
+         "\"read_pitch\": %llu, \"rows_per_tile\": %u, \"slab_pitch\": %llu, \"exact_rounds\": %u, \"barrier\": %u, \"units\": %llu, \"wg_per_cu\": %d, \"ms_mean\": %.4f, \"ms_best\": %.4f, \"read_GBs\": %.1f, "
          "\"write_GBs\": %.1f, \"total_GBs\": %.1f, \"write_share\": %.3f}\n",
          a.read_run, a.read_unit, a.write_seg, a.write_unit, (unsigned long long)a.write_stride,
-         (unsigned long long)a.read_pitch, a.rows_per_tile, (unsigned long long)a.slab_pitch, (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
+         (unsigned long long)a.read_pitch, a.rows_per_tile, (unsigned long long)a.slab_pitch, a.exact_rounds, a.barrier, (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
          (rb + wb) / (sum / reps) / 1e6, wb / (rb + wb + 1e-30));
   CHECK(hipFree(src));
   CHECK(hipFree(dst));
