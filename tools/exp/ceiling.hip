@@ -162,11 +162,20 @@ int main(int argc, char** argv) {
     fprintf(stderr, "write pattern needs %.1f GB\n", dst_bytes / 1e9);
     return 2;
   }
+  // placement sweep (argv[14] = largest offset in bytes): ONE allocation holds both buffers, the write buffer starts at
+  // (end of the read buffer) + delta for a list of deltas -- does the rate follow the relative placement of the two streams?
+  const uint64_t sweep = argc > 14 ? (uint64_t)atoll(argv[14]) : 0;
   char *src = nullptr, *dst = nullptr;
-  CHECK(hipMalloc((void**)&src, src_bytes));
-  CHECK(hipMalloc((void**)&dst, dst_bytes));
-  CHECK(hipMemset(src, 1, src_bytes));
-  CHECK(hipMemset(dst, 0, dst_bytes));
+  if (sweep) {
+    CHECK(hipMalloc((void**)&src, src_bytes + dst_bytes + sweep + 4096));
+    CHECK(hipMemset(src, 1, src_bytes + dst_bytes + sweep + 4096));
+    dst = src + src_bytes;
+  } else {
+    CHECK(hipMalloc((void**)&src, src_bytes));
+    CHECK(hipMalloc((void**)&dst, dst_bytes));
+    CHECK(hipMemset(src, 1, src_bytes));
+    CHECK(hipMemset(dst, 0, dst_bytes));
+  }
   a.src = src;
   a.dst = dst;
   hipDeviceProp_t prop;
@@ -187,6 +196,28 @@ int main(int argc, char** argv) {
   };
   launch();
   CHECK(hipDeviceSynchronize());
+  if (sweep) {
+    const double bytes = (double)a.n_units * a.read_unit + (double)a.n_units * a.write_unit;
+    printf("src %p\n", (void*)src);
+    for (uint64_t delta = 0; delta <= sweep; delta = delta ? delta * 2 : 256) {
+      a.dst = src + src_bytes + delta;
+      launch();
+      CHECK(hipDeviceSynchronize());
+      float sum2 = 0.f;
+      for (int r = 0; r < reps; ++r) {
+        CHECK(hipEventRecord(e0, nullptr));
+        launch();
+        CHECK(hipEventRecord(e1, nullptr));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        sum2 += ms;
+      }
+      printf("delta %12llu  %.0f GB/s\n", (unsigned long long)delta, bytes / (sum2 / reps) / 1e6);
+    }
+    CHECK(hipFree(src));
+    return 0;
+  }
   float best = 1e30f, sum = 0.f;
   for (int r = 0; r < reps; ++r) {
     CHECK(hipEventRecord(e0, nullptr));
