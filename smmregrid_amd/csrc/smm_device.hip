@@ -343,7 +343,7 @@ int ensure_sb(smm_operator* op) {
   // reuse plan: source cells that a later row of the same 16-row tile needs again wait in LDS slots (conservative
   // stencils); operators without such cells (bilinear, nearest) keep the plain kernel and carry no code array
   std::vector<int32_t> code;
-  op->sb_takes = smm::build_sb_reuse_codes(c, 16, kSbCacheSlots, 1, code);
+  op->sb_takes = smm::build_sb_reuse_codes(c, 16, kSbCacheSlots, 16, code);
   if (op->sb_takes * 50 < c.nnz) {     // under 2 % of the links: not worth the second kernel form
     op->sb_takes = 0;
     code.clear();

@@ -1119,11 +1119,6 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
   xvec xv[2][U];
   double w[2][U];
   int cd[2][U];   // reuse codes of the round (wave-uniform)
-  // Every link issues exactly one global load, so the rounds keep their counted s_waitcnt vmcnt(N) (loads under a
-  // branch made hipcc wait vmcnt(0) everywhere: the two rounds in flight collapsed, config 3 +22 %).  A link whose run
-  // waits in an LDS slot re-requests the run of the link before it -- a line that is in flight or in L1, no new fetch --
-  // and reads the slot when it is consumed.
-  int64_t last_off = 0;   // element offset of the previous link's run (wave-uniform)
   auto load_batch = [&](int buf, int64_t base) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1131,16 +1126,15 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
       if (p > p1 - 1) p = p1 - 1;            // padding repeats the tile's last link (valid address)
       const int64_t c = m.col[p];
       w[buf][u] = m.val[p];
-      int64_t off = c * a.ldx;
       if (CACHE) {
         cd[buf][u] = m.code[p];
-        off = (cd[buf][u] & 0x80) ? last_off : off;   // scalar select
-        // opaque to the optimiser: knowing that the address repeats, hipcc replaced the load by a copy of the previous
-        // link's registers under a branch -- and waited for every load right behind its issue
-        asm volatile("" : "+s"(off));
-        last_off = off;
+        if (cd[buf][u] & 0x80)               // wave-uniform: the run waits in an LDS slot
+          xv[buf][u] = cache[(cd[buf][u] & 15) * 64 + lane];
+        else
+          xv[buf][u] = *(const xvec_u*)(xl + c * a.ldx);
+      } else {
+        xv[buf][u] = *(const xvec_u*)(xl + c * a.ldx);
       }
-      xv[buf][u] = *(const xvec_u*)(xl + off);
     }
   };
   auto consume = [&](int buf, int64_t base) {
@@ -1149,14 +1143,10 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
       const int64_t p = base + u;
       if (p < p1) {                           // wave-uniform
         while (row_end <= p) flush_row();     // rows ending before this link (empty rows included)
-        xvec val = xv[buf][u];
-        if (CACHE) {
-          if (cd[buf][u] & 0x80) val = cache[(cd[buf][u] & 15) * 64 + lane];          // the run kept by an earlier row
-          else if (cd[buf][u] & 0x40) cache[(cd[buf][u] & 15) * 64 + lane] = val;     // a later row takes it from here
-        }
+        if (CACHE && (cd[buf][u] & 0x40)) cache[(cd[buf][u] & 15) * 64 + lane] = xv[buf][u];   // a later row takes it from here
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-          XT e = (v == 0 && shift1) ? val[1] : val[v];
+          XT e = (v == 0 && shift1) ? xv[buf][u][1] : xv[buf][u][v];
           if (FILL) e = __builtin_isfinite(e) ? e : (XT)1e20;   // regrid.py:545-547, dtype's own 1e20
           const double prod = w[buf][u] * (double)e;
           acc[v] = acc[v] + prod;
@@ -1240,21 +1230,10 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
 
 template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false, bool CACHE = false>
 __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
+  const SbMatrix<const int64_t*, const int32_t*, const double*, const uint8_t*> m{a.rowptr, a.col, a.val, a.imask, a.frac, a.code};
   const SbTile t{a.x, a.y, a.ldx, a.ldy, a.n_batch, a.n_dst, a.n_dtiles, a.n_btiles, (uint32_t)a.n_blocks,
                  a.area_min, a.masked, a.xcd_remap, a.b_fastest};
-  if constexpr (CACHE) {
-    // the reuse codes steer a scalar select: constant-address-space views keep every stream of the operator a scalar load
-    typedef const __attribute__((address_space(4))) int64_t* k_i64;
-    typedef const __attribute__((address_space(4))) int32_t* k_i32;
-    typedef const __attribute__((address_space(4))) double* k_f64;
-    typedef const __attribute__((address_space(4))) uint8_t* k_u8;
-    const SbMatrix<k_i64, k_i32, k_f64, k_u8> m{(k_i64)a.rowptr, (k_i32)a.col, (k_f64)a.val, (k_u8)a.imask, (k_f64)a.frac,
-                                                (k_i32)a.code};
-    sb_tile_body<XT, YT, TD, U, FILL, YSB, CACHE>(m, t, blockIdx.x);
-  } else {
-    const SbMatrix<const int64_t*, const int32_t*, const double*, const uint8_t*> m{a.rowptr, a.col, a.val, a.imask, a.frac, a.code};
-    sb_tile_body<XT, YT, TD, U, FILL, YSB, CACHE>(m, t, blockIdx.x);
-  }
+  sb_tile_body<XT, YT, TD, U, FILL, YSB, CACHE>(m, t, blockIdx.x);
 }
 
 // The same tiles for every data level of a group in one launch: workgroup -> (level, tile of that level's grid).
