@@ -475,66 +475,6 @@ HostChunk host_chunk_units(int64_t n_units, size_t x_unit, size_t y_unit, size_t
   return c;
 }
 
-int64_t build_sb_reuse_codes(const HostCsr& csr, int tile_rows, int n_slots, int min_dist, std::vector<int32_t>& code) {
-  code.assign((size_t)csr.nnz, 0);
-  if (csr.nnz == 0 || tile_rows <= 0 || n_slots <= 0) return 0;
-  n_slots = std::min(n_slots, 16);
-  const int64_t n_tiles = (csr.n_dst + tile_rows - 1) / tile_rows;
-  const int nt = host_threads(csr.nnz, 1 << 16);
-  std::vector<int64_t> takes_of((size_t)std::max(nt, 1), 0);
-  BuilderScope scope;
-  parallel_ranges(n_tiles, nt, [&](int t, int64_t lo, int64_t hi) {
-    std::vector<int32_t> order, nxt;
-    std::vector<int8_t> take_slot;
-    int64_t takes = 0;
-    for (int64_t tile = lo; tile < hi; ++tile) {
-      const int64_t d0 = tile * tile_rows, d1 = std::min<int64_t>(csr.n_dst, d0 + tile_rows);
-      const int64_t p0 = csr.rowptr[(size_t)d0], p1 = csr.rowptr[(size_t)d1];
-      const int64_t n = p1 - p0;
-      if (n <= min_dist || n > 0x7fffffffLL) continue;
-      const int32_t* c = &csr.col[(size_t)p0];
-      // next link of the tile that names the same source cell
-      order.resize((size_t)n);
-      for (int64_t i = 0; i < n; ++i) order[(size_t)i] = (int32_t)i;
-      std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return c[a] < c[b]; });
-      nxt.assign((size_t)n, -1);
-      for (int64_t k = 0; k + 1 < n; ++k)
-        if (c[order[(size_t)k]] == c[order[(size_t)k + 1]]) nxt[(size_t)order[(size_t)k]] = order[(size_t)k + 1];
-      take_slot.assign((size_t)n, -1);
-      int64_t free_at[16];                 // link position from which a slot may be saved into again
-      for (int s = 0; s < 16; ++s) free_at[s] = 0;
-      constexpr int64_t kBusy = (int64_t)1 << 60;
-      for (int64_t i = 0; i < n; ++i) {
-        const int64_t j = nxt[(size_t)i];
-        const bool again = j >= 0 && j - i >= min_dist;
-        if (take_slot[(size_t)i] >= 0) {
-          const int s = take_slot[(size_t)i];
-          code[(size_t)(p0 + i)] = 0x80 | s;
-          ++takes;
-          if (again) {
-            take_slot[(size_t)j] = (int8_t)s;      // the run stays where it is for its next use
-          } else {
-            free_at[s] = i;                        // a SAVE consumed at or after this link comes after this TAKE was read
-          }
-        } else if (again) {
-          for (int s = 0; s < n_slots; ++s) {
-            if (free_at[s] <= i) {
-              code[(size_t)(p0 + i)] = 0x40 | s;
-              take_slot[(size_t)j] = (int8_t)s;
-              free_at[s] = kBusy;
-              break;
-            }
-          }
-        }
-      }
-    }
-    takes_of[(size_t)t] = takes;
-  });
-  int64_t total = 0;
-  for (int64_t v : takes_of) total += v;
-  return total;
-}
-
 void build_sell(const HostCsr& csr, HostSell& out) {
   BuilderScope scope;
   const int nt = host_threads(csr.nnz + csr.n_dst, (int64_t)1 << 17);

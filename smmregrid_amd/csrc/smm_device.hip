@@ -185,9 +185,6 @@ struct smm_operator {
   int32_t* d_csr_col = nullptr;       // source cell
   int32_t* d_csr_colp = nullptr;      // rank of the source cell among the used cells (packed X)
   double* d_csr_val = nullptr;
-  int32_t* d_csr_code = nullptr;      // reuse plan of the batch-fastest kernel (smm::build_sb_reuse_codes); null = no reuse found
-  int32_t* d_csr_code0 = nullptr;     // all zeros: this operator inside a group launch whose other members have a plan
-  int64_t sb_takes = 0;               // links that read their run from an LDS slot
   std::atomic<int> group_refs{0};  // groups borrowing this operator (their descriptors hold its device pointers)
   int native = 0;            // shape of the operator's own plan (choose_native_plan)
   int native_plan() const { return native; }
@@ -283,8 +280,6 @@ void release(smm_operator* op) {
   (void)hipFree(op->d_csr_col);
   (void)hipFree(op->d_csr_colp);
   (void)hipFree(op->d_csr_val);
-  (void)hipFree(op->d_csr_code);
-  (void)hipFree(op->d_csr_code0);
   delete op;
 }
 
@@ -340,39 +335,20 @@ int ensure_sb(smm_operator* op) {
   op->h_used.reserve((size_t)c.n_used_src);
   for (int64_t s = 0; s < c.n_src; ++s)
     if (rank[(size_t)s] >= 0) op->h_used.push_back((int32_t)s);
-  // reuse plan: source cells that a later row of the same 16-row tile needs again wait in LDS slots (conservative
-  // stencils); operators without such cells (bilinear, nearest) keep the plain kernel and carry no code array
-  std::vector<int32_t> code;
-  op->sb_takes = smm::build_sb_reuse_codes(c, 16, kSbCacheSlots, 16, code);
-  if (op->sb_takes * 50 < c.nnz) {     // under 2 % of the links: not worth the second kernel form
-    op->sb_takes = 0;
-    code.clear();
-  }
   int rc = SMM_OK;
   if ((rc = upload(&op->d_csr_rowptr, c.rowptr)) || (rc = upload(&op->d_csr_col, c.col)) ||
-      (rc = upload(&op->d_csr_colp, colp)) || (rc = upload(&op->d_csr_val, c.val)) ||
-      (op->sb_takes > 0 && (rc = upload(&op->d_csr_code, code)))) {
+      (rc = upload(&op->d_csr_colp, colp)) || (rc = upload(&op->d_csr_val, c.val))) {
     (void)hipFree(op->d_csr_rowptr);
     (void)hipFree(op->d_csr_col);
     (void)hipFree(op->d_csr_colp);
     (void)hipFree(op->d_csr_val);
-    (void)hipFree(op->d_csr_code);
     op->d_csr_rowptr = nullptr;
     op->d_csr_col = op->d_csr_colp = nullptr;
     op->d_csr_val = nullptr;
-    op->d_csr_code = nullptr;
     return rc;
   }
   op->sb_ready = true;
   return SMM_OK;
-}
-
-// The code array a member without a reuse plan contributes to a grouped launch that uses the cache: all zeros.
-int ensure_sb_zero_codes(smm_operator* op) {
-  std::lock_guard<std::mutex> lock(op->plan_mu);
-  if (op->d_csr_code0 || op->csr.nnz == 0) return SMM_OK;
-  std::vector<int32_t> zeros((size_t)op->csr.nnz, 0);
-  return upload(&op->d_csr_code0, zeros);
 }
 
 // largest 1-D launch grid (workgroups); smm_debug_set_grid_limit lowers it so that tests reach the split path
@@ -1070,7 +1046,6 @@ int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, voi
   a.val = op->d_csr_val;
   a.imask = op->d_imask;
   a.frac = op->d_frac;
-  a.code = smm::tuning(SMM_TUNE_SB_CELL_CACHE) == 1 ? nullptr : op->d_csr_code;   // reuse plan (tuning knob: off)
   a.x = x;
   a.y = y;
   a.ldx = ldx;
@@ -1518,18 +1493,6 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
     }
     const int64_t max_lev = std::max<int64_t>(1, std::min<int64_t>(kSbGroupLevels, grid_limit() / per_level));
     const bool fill = !(flags & SMM_APPLY_NO_FILL);
-    // the reuse plan is used by the whole launch or not at all: members without one contribute a code array of zeros
-    bool cache = false;
-    if (smm::tuning(SMM_TUNE_SB_CELL_CACHE) != 1)
-      for (int64_t l = 0; l < n_lev; ++l) cache = cache || g->ops[(size_t)level_index[l]]->d_csr_code != nullptr;
-    if (cache)
-      for (int64_t l = 0; l < n_lev; ++l) {
-        smm_operator* op = g->ops[(size_t)level_index[l]];
-        if (!op->d_csr_code && op->csr.nnz > 0) {
-          int zrc = ensure_sb_zero_codes(op);
-          if (zrc) return zrc;
-        }
-      }
     for (int64_t l0 = 0; l0 < n_lev; l0 += max_lev) {
       SbGroupArgs a{};
       a.n_lev = (int)std::min<int64_t>(max_lev, n_lev - l0);
@@ -1546,9 +1509,7 @@ int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev
         const int w = level_index[l0 + i];
         const smm_operator* op = g->ops[(size_t)w];
         const bool m = (flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w]);   // regrid.py:405
-        const int32_t* code = !cache ? nullptr : (op->d_csr_code ? op->d_csr_code : op->d_csr_code0);
-        if (cache && !code) code = op->d_csr_col;   // an operator without links: never read, but the launch's switch is lev[0]
-        a.lev[i] = SbLevelPtrs{op->d_csr_rowptr, op->d_csr_col, op->d_csr_val, m ? op->d_imask : nullptr, op->d_frac, code};
+        a.lev[i] = SbLevelPtrs{op->d_csr_rowptr, op->d_csr_col, op->d_csr_val, m ? op->d_imask : nullptr, op->d_frac};
       }
       const int rc = x_dtype == SMM_F64
                          ? (y_dtype == SMM_F64 ? launch_sb_group<double, double>(a, fill, flags, caller)

@@ -61,17 +61,6 @@ bool adopt_csr(int64_t n_src, int64_t n_dst, const int64_t* rowptr, const int32_
 int64_t prune_zero_links(HostCsr& csr);
 void build_sell(const HostCsr& csr, HostSell& out);
 
-// Reuse plan of the batch-fastest kernel.  That kernel walks the links of a tile of `tile_rows` destination rows as one
-// flat sequence and loads a source cell's batch run once per LINK; a cell that a later row of the same tile needs again
-// (conservative stencils: the column two neighbouring destination cells share) can be kept in one of `n_slots` LDS slots
-// instead.  code[p] of link p (CSR order): bit 6 = after the load, SAVE the run into slot (code & 15); bit 7 = TAKE the
-// run from that slot instead of loading it; 0 = plain load.  Rules that make this safe for the kernel's pipeline (two
-// batches of at most 8 loads in flight; a SAVE is written when its link is consumed, a TAKE is read when its batch of
-// loads is issued): a TAKE follows its SAVE (or the previous TAKE of the same run) by at least `min_dist` = 16 links; a
-// slot is saved into again only by a link at or after its last TAKE; nothing is kept across tiles.  Codes built for
-// tiles of 16 rows hold for tiles of 32 (two such tiles back to back).  Returns the number of TAKE links.
-int64_t build_sb_reuse_codes(const HostCsr& csr, int tile_rows, int n_slots, int min_dist, std::vector<int32_t>& code);
-
 // Source-tile plan for the LDS-staged kernel.  Destination rows are grouped in
 // blocks of `rows_per_block` consecutive rows (4 SELL slices, 1 slice, or 1/2, 1/4, 1/8 of a slice
 // for rows whose footprint is wide); the distinct source cells a block

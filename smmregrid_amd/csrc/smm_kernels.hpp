@@ -68,7 +68,6 @@ struct SbArgs {
   const double* val;       // [nnz]
   const uint8_t* imask;    // [n_dst] or null
   const double* frac;      // [n_dst] or null
-  const int32_t* code;     // [nnz] reuse plan (smm::build_sb_reuse_codes) or null
   const void* x;           // (n_rows_x, ldx): row = source cell, batch entry fastest
   void* y;                 // batch entry b of destination cell d at y + b * ldy + d  (YSB: at y + d * ldy + b)
   int64_t ldx, ldy, n_batch, n_dst;
@@ -85,15 +84,13 @@ struct SbArgs {
 // constant-address-space views of them, so the column / weight / row-pointer streams stay scalar loads exactly as
 // in the single-operator kernel (a pointer table in device memory turned them into vector loads: 162 instead of
 // 88 VGPRs).  kSbGroupLevels * 40 B + the rest stays below the 4-KiB kernarg limit; longer groups take several launches.
-constexpr int kSbGroupLevels = 80;
-constexpr int kSbCacheSlots = 6;   // LDS slots of the reuse plan: 6 x 1 KiB beside the 16.6-KiB tile still leave 7 waves per CU
+constexpr int kSbGroupLevels = 88;
 struct SbLevelPtrs {
   const int64_t* rowptr;
   const int32_t* col;
   const double* val;
   const uint8_t* imask;   // null = no mask applied on this level
   const double* frac;
-  const int32_t* code;    // reuse plan (all zeros for an operator without reuse when the launch uses the cache)
 };
 struct SbGroupArgs {
   const void* x;             // level l's (S, ldx) slab at x + l * xs_lev elements
@@ -1014,7 +1011,6 @@ struct SbMatrix {
   F64P val;
   U8P imask;
   F64P frac;
-  I32P code;
 };
 struct SbTile {   // what does not depend on the level
   const void* x;
@@ -1025,11 +1021,7 @@ struct SbTile {   // what does not depend on the level
   int masked, xcd_remap, b_fastest;
 };
 
-// CACHE: the operator has a reuse plan (SbMatrix::code, smm::build_sb_reuse_codes): a source cell's run that a later
-// row of the tile needs again is written to an LDS slot when its link is consumed and read back from there -- in the
-// round of loads, in place of the global load -- so a shared cell crosses the memory system once per tile instead of once
-// per link (conservative stencils: BASELINE config 3 fetches 16 % fewer runs).  The summation order does not change.
-template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB, bool CACHE, typename M>
+template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB, typename M>
 __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32_t bid) {
   constexpr int VEC = 2;                    // batch entries per lane
   constexpr int BT = 64 * VEC;              // batch entries per tile
@@ -1037,9 +1029,12 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
   constexpr int LROW = BT + PAD;
   static_assert(TD % 2 == 0 && 128 % TD == 0 && TD <= 64, "store phase: TD / 2 lanes per batch row");
   __shared__ __attribute__((aligned(16))) YT tile[TD * LROW];
+#ifdef SMM_EXP_SB_LDS_PAD   // timing experiment: extra LDS per wave (occupancy sensitivity of the batch-fastest kernel)
+  __shared__ char lds_pad[SMM_EXP_SB_LDS_PAD];
+  if (a.n_batch < 0) lds_pad[threadIdx.x] = 1;
+#endif
   typedef XT xvec __attribute__((ext_vector_type(VEC)));
   typedef xvec xvec_u __attribute__((aligned(sizeof(XT))));   // element-aligned (any ldx / base)
-  __shared__ __attribute__((aligned(16))) xvec cache[CACHE ? kSbCacheSlots * 64 : 1];
 
   const int lane = threadIdx.x;
   // grids stay below 2^31 blocks: 32-bit index arithmetic
@@ -1118,7 +1113,6 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
 
   xvec xv[2][U];
   double w[2][U];
-  int cd[2][U];   // reuse codes of the round (wave-uniform)
   auto load_batch = [&](int buf, int64_t base) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1126,15 +1120,7 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
       if (p > p1 - 1) p = p1 - 1;            // padding repeats the tile's last link (valid address)
       const int64_t c = m.col[p];
       w[buf][u] = m.val[p];
-      if (CACHE) {
-        cd[buf][u] = m.code[p];
-        if (cd[buf][u] & 0x80)               // wave-uniform: the run waits in an LDS slot
-          xv[buf][u] = cache[(cd[buf][u] & 15) * 64 + lane];
-        else
-          xv[buf][u] = *(const xvec_u*)(xl + c * a.ldx);
-      } else {
-        xv[buf][u] = *(const xvec_u*)(xl + c * a.ldx);
-      }
+      xv[buf][u] = *(const xvec_u*)(xl + c * a.ldx);
     }
   };
   auto consume = [&](int buf, int64_t base) {
@@ -1143,7 +1129,6 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
       const int64_t p = base + u;
       if (p < p1) {                           // wave-uniform
         while (row_end <= p) flush_row();     // rows ending before this link (empty rows included)
-        if (CACHE && (cd[buf][u] & 0x40)) cache[(cd[buf][u] & 15) * 64 + lane] = xv[buf][u];   // a later row takes it from here
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
           XT e = (v == 0 && shift1) ? xv[buf][u][1] : xv[buf][u][v];
@@ -1228,18 +1213,18 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
   }
 }
 
-template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false, bool CACHE = false>
+template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
 __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
-  const SbMatrix<const int64_t*, const int32_t*, const double*, const uint8_t*> m{a.rowptr, a.col, a.val, a.imask, a.frac, a.code};
+  const SbMatrix<const int64_t*, const int32_t*, const double*, const uint8_t*> m{a.rowptr, a.col, a.val, a.imask, a.frac};
   const SbTile t{a.x, a.y, a.ldx, a.ldy, a.n_batch, a.n_dst, a.n_dtiles, a.n_btiles, (uint32_t)a.n_blocks,
                  a.area_min, a.masked, a.xcd_remap, a.b_fastest};
-  sb_tile_body<XT, YT, TD, U, FILL, YSB, CACHE>(m, t, blockIdx.x);
+  sb_tile_body<XT, YT, TD, U, FILL, YSB>(m, t, blockIdx.x);
 }
 
 // The same tiles for every data level of a group in one launch: workgroup -> (level, tile of that level's grid).
 // Levels are independent, so the dispatcher backfills the thin deep levels' tails with the next level's tiles -- no
 // ramp-up and tail per level as with one launch each.
-template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false, bool CACHE = false>
+template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
 __global__ __launch_bounds__(64) void smm_group_apply_sb_kernel(SbGroupArgs a) {
   typedef const __attribute__((address_space(4))) int64_t* k_i64;
   typedef const __attribute__((address_space(4))) int32_t* k_i32;
@@ -1250,11 +1235,10 @@ __global__ __launch_bounds__(64) void smm_group_apply_sb_kernel(SbGroupArgs a) {
   const uint32_t bid = blockIdx.x - lvl * per;
   const SbLevelPtrs L = a.lev[lvl];
   // the operator's arrays are immutable while a kernel runs: constant address space keeps their loads scalar
-  const SbMatrix<k_i64, k_i32, k_f64, k_u8> m{(k_i64)L.rowptr, (k_i32)L.col, (k_f64)L.val, (k_u8)L.imask, (k_f64)L.frac,
-                                              (k_i32)L.code};
+  const SbMatrix<k_i64, k_i32, k_f64, k_u8> m{(k_i64)L.rowptr, (k_i32)L.col, (k_f64)L.val, (k_u8)L.imask, (k_f64)L.frac};
   const SbTile t{(const XT*)a.x + (int64_t)lvl * a.xs_lev, (YT*)a.y + (int64_t)lvl * a.ys_lev, a.ldx, a.ldy, a.n_batch,
                  a.n_dst, a.n_dtiles, a.n_btiles, per, a.area_min, L.imask != nullptr, a.xcd_remap, a.b_fastest};
-  sb_tile_body<XT, YT, TD, U, FILL, YSB, CACHE>(m, t, bid);
+  sb_tile_body<XT, YT, TD, U, FILL, YSB>(m, t, bid);
 }
 
 // counter-based synthetic field: splitmix64 -> two uniforms -> Box-Muller

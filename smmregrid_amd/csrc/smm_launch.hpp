@@ -22,8 +22,6 @@ int tuning(int knob);                             // smm_debug_set_tuning's curr
 
 namespace smm_launch {
 
-constexpr int kSbLdsPadDefault = 0;
-
 #define SMM_LAUNCH_HIP(call)                                                              \
   do {                                                                                    \
     hipError_t e_ = (call);                                                               \
@@ -39,13 +37,6 @@ inline int sell_batch_rows(int64_t n_j) {
   if (n_j >= 8 && want == 8) return 8;
   if (n_j >= 4 && want != 2) return 4;
   return n_j >= 2 ? 2 : 1;
-}
-
-// Extra dynamic LDS requested for every wave of the batch-fastest kernels: it caps the waves per CU (16.6 KB of tile
-// alone allow 9).  SMM_TUNE_SB_LDS_PAD: bytes (-1 = none).
-inline size_t sb_lds_pad() {
-  const int want = smm::tuning(SMM_TUNE_SB_LDS_PAD);
-  return want < 0 ? 0 : (want > 0 ? (size_t)want : (size_t)kSbLdsPadDefault);
 }
 
 // consecutive logical blocks given to one XCD (tile and batch-fastest kernels); 0 = dispatcher order
@@ -276,21 +267,13 @@ int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
   const int strip = smm::tuning(SMM_TUNE_SB_STRIP);
   args.b_fastest = strip < 0 ? 0 : (strip > 0 ? strip : 2);
   const bool ysb = (flags & SMM_APPLY_SB_Y_SB) != 0;   // result kept batch-fastest: Y (D, ldy >= B)
-  const bool cache = a.code != nullptr;     // the operator has a reuse plan (shared source cells kept in LDS slots)
   auto go = [&](auto u_tag, auto fill_tag) {
     constexpr int UU = decltype(u_tag)::value;
     constexpr bool FF = decltype(fill_tag)::value;
-    const dim3 grid((unsigned)total), block(64);
-    if (cache) {
-      if (ysb)
-        hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF, true, true>), grid, block, sb_lds_pad(), s, args);
-      else
-        hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF, false, true>), grid, block, sb_lds_pad(), s, args);
-    } else if (ysb) {
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF, true>), grid, block, sb_lds_pad(), s, args);
-    } else {
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF>), grid, block, sb_lds_pad(), s, args);
-    }
+    if (ysb)
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), 0, s, args);
+    else
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), 0, s, args);
   };
   auto with_fill = [&](auto u_tag) {
     if (fill) go(u_tag, std::true_type());
@@ -319,21 +302,13 @@ int launch_sb_group(const SbGroupArgs& a, bool fill, unsigned flags, hipStream_t
   const int strip = smm::tuning(SMM_TUNE_SB_STRIP);
   args.b_fastest = strip < 0 ? 0 : (strip > 0 ? strip : 2);
   const bool ysb = (flags & SMM_APPLY_SB_Y_SB) != 0;
-  const bool cache = a.lev[0].code != nullptr;   // the caller sets every level's code pointer, or none
   auto go = [&](auto u_tag, auto fill_tag) {
     constexpr int UU = decltype(u_tag)::value;
     constexpr bool FF = decltype(fill_tag)::value;
-    const dim3 grid((unsigned)total), block(64);
-    if (cache) {
-      if (ysb)
-        hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF, true, true>), grid, block, sb_lds_pad(), s, args);
-      else
-        hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF, false, true>), grid, block, sb_lds_pad(), s, args);
-    } else if (ysb) {
-      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF, true>), grid, block, sb_lds_pad(), s, args);
-    } else {
-      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF>), grid, block, sb_lds_pad(), s, args);
-    }
+    if (ysb)
+      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), 0, s, args);
+    else
+      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), 0, s, args);
   };
   auto with_fill = [&](auto u_tag) {
     if (fill) go(u_tag, std::true_type());

@@ -225,52 +225,6 @@ int main(int argc, char** argv) {
       ++sbad;
     printf("SPLITBAD %lld\n", sbad);
   }
-  // reuse plan of the batch-fastest kernel (smm::build_sb_reuse_codes): replay the kernel's schedule -- rounds of U loads, two
-  // rounds in flight, a SAVE written when its link is consumed, a TAKE read when its round of loads is issued -- for U = 4 / 8
-  // and tiles of 16 / 32 rows: every TAKE must find its own source cell in the slot
-  {
-    long long rbad = 0;
-    std::vector<int32_t> code;
-    const int64_t takes = smm::build_sb_reuse_codes(csr, 16, 6, 16, code);
-    int64_t counted = 0;
-    for (int32_t c : code) {
-      counted += (c & 0x80) != 0;
-      if ((c & 0x80) && (c & 0x40)) ++rbad;
-      if ((c & 15) >= 6 || (c & ~0xCF)) ++rbad;
-    }
-    if (counted != takes || (int64_t)code.size() != csr.nnz) ++rbad;
-    for (int U : {4, 8}) {
-      for (int td : {16, 32}) {
-        for (int64_t d0 = 0; d0 < csr.n_dst; d0 += td) {
-          const int64_t p0 = csr.rowptr[(size_t)d0], p1 = csr.rowptr[(size_t)std::min<int64_t>(csr.n_dst, d0 + td)];
-          if (p1 <= p0) continue;
-          int64_t slot[16];
-          for (auto& v : slot) v = -1;
-          auto load_round = [&](int64_t base) {
-            for (int u = 0; u < U; ++u) {
-              const int64_t p = base + u;
-              if (p >= p1) continue;                      // padding repeats the last link: read, never used
-              if ((code[(size_t)p] & 0x80) && slot[code[(size_t)p] & 15] != csr.col[(size_t)p]) ++rbad;
-            }
-          };
-          auto consume = [&](int64_t base) {
-            for (int u = 0; u < U; ++u) {
-              const int64_t p = base + u;
-              if (p < p1 && (code[(size_t)p] & 0x40)) slot[code[(size_t)p] & 15] = csr.col[(size_t)p];
-            }
-          };
-          load_round(p0);
-          for (int64_t base = p0; base < p1; base += 2 * U) {
-            if (base + U < p1) load_round(base + U);
-            consume(base);
-            if (base + 2 * U < p1) load_round(base + 2 * U);
-            if (base + U < p1) consume(base + U);
-          }
-        }
-      }
-    }
-    printf("REUSEBAD %lld %lld\n", rbad, (long long)takes);
-  }
   // worker pools of the builders: a task that throws (std::bad_alloc from a worker's scratch vectors) must come
   // back as an exception on the calling thread after every started thread has been joined -- never
   // std::terminate --, and a thread that cannot be started costs parallelism, not the result
