@@ -348,6 +348,7 @@ enum {
   SMM_TUNE_SB_STRIP,            /* batch-fastest kernel: destination tiles per strip (-1 = whole-grid order)   */
   SMM_TUNE_SB_LOADS,            /* batch-fastest kernel: loads per batch of the link walk (4, 8)               */
   SMM_TUNE_SB_LEVEL_LAUNCHES,   /* smm_group_apply_sb: 1 = one launch per data level instead of one grouped launch */
+  SMM_TUNE_SB_LDS_PAD,          /* batch-fastest kernels: extra LDS bytes per wave, capping the waves per CU    */
   SMM_TUNE_COUNT
 };
 int smm_debug_set_tuning(int knob, int value, int* previous);

@@ -1029,10 +1029,6 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
   constexpr int LROW = BT + PAD;
   static_assert(TD % 2 == 0 && 128 % TD == 0 && TD <= 64, "store phase: TD / 2 lanes per batch row");
   __shared__ __attribute__((aligned(16))) YT tile[TD * LROW];
-#ifdef SMM_EXP_SB_LDS_PAD   // timing experiment: extra LDS per wave (occupancy sensitivity of the batch-fastest kernel)
-  __shared__ char lds_pad[SMM_EXP_SB_LDS_PAD];
-  if (a.n_batch < 0) lds_pad[threadIdx.x] = 1;
-#endif
   typedef XT xvec __attribute__((ext_vector_type(VEC)));
   typedef xvec xvec_u __attribute__((aligned(sizeof(XT))));   // element-aligned (any ldx / base)
 

@@ -39,6 +39,11 @@ inline int sell_batch_rows(int64_t n_j) {
   return n_j >= 2 ? 2 : 1;
 }
 
+// Extra dynamic LDS requested for every wave of the batch-fastest kernels (tuning knob SMM_TUNE_SB_LDS_PAD, bytes): it
+// caps the waves per CU -- the 16.6-KB tile alone allows 9.  Measured (profiles/r05_sb_experiments.txt): config 3 is level
+// down to 7 waves per CU and loses below; config 2 gains 0 - 5 % at 6 - 8.  No pad by default.
+inline size_t sb_lds_pad() { return (size_t)std::max(smm::tuning(SMM_TUNE_SB_LDS_PAD), 0); }
+
 // consecutive logical blocks given to one XCD (tile and batch-fastest kernels); 0 = dispatcher order
 inline int xcd_run_length() {
   const int want = smm::tuning(SMM_TUNE_XCD_RUN);
@@ -271,9 +276,9 @@ int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
     constexpr int UU = decltype(u_tag)::value;
     constexpr bool FF = decltype(fill_tag)::value;
     if (ysb)
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), 0, s, args);
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), sb_lds_pad(), s, args);
     else
-      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), 0, s, args);
+      hipLaunchKernelGGL((smm_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), sb_lds_pad(), s, args);
   };
   auto with_fill = [&](auto u_tag) {
     if (fill) go(u_tag, std::true_type());
@@ -306,9 +311,9 @@ int launch_sb_group(const SbGroupArgs& a, bool fill, unsigned flags, hipStream_t
     constexpr int UU = decltype(u_tag)::value;
     constexpr bool FF = decltype(fill_tag)::value;
     if (ysb)
-      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), 0, s, args);
+      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF, true>), dim3((unsigned)total), dim3(64), sb_lds_pad(), s, args);
     else
-      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), 0, s, args);
+      hipLaunchKernelGGL((smm_group_apply_sb_kernel<XT, YT, TD, UU, FF>), dim3((unsigned)total), dim3(64), sb_lds_pad(), s, args);
   };
   auto with_fill = [&](auto u_tag) {
     if (fill) go(u_tag, std::true_type());
