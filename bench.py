@@ -805,8 +805,9 @@ def layout_summary(entry):
     if not entry or "roofline" not in entry:
         return {"error": short((entry or {}).get("error") or (entry or {}).get("skipped") or "not run", 80)}
     r = entry["roofline"]
-    out = {"ms": round(r["kernel_ms"], 4), "frac": round(r["frac"], 4),
-           "traffic_ratio": round(r["traffic"] / r["algorithmic_bytes"], 3) if r.get("traffic") else None}
+    out = {"ms": round(r["kernel_ms"], 3), "frac": round(r["frac"], 4)}
+    if r.get("traffic"):
+        out["traffic_ratio"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
     if "spot_check" in entry:
         out["spot_check"] = bool(entry["spot_check"].get("bit_equal_to_oracle"))
     return out
@@ -954,8 +955,9 @@ def final_line(out, details):
             roof[k] = full[k]
     nested = {}
     if others:
-        native = {"ms": round(full["kernel_ms"], 4), "frac": round(full["frac"], 4),
-                  "traffic_ratio": full.get("traffic_ratio")}
+        native = {"ms": round(full["kernel_ms"], 3), "frac": round(full["frac"], 4)}
+        if full.get("traffic_ratio"):
+            native["traffic_ratio"] = full["traffic_ratio"]
         if "spot_check" in line:
             native["spot_check"] = bool(line["spot_check"].get("bit_equal_to_oracle"))
         sb = layout_summary(others.get("cfg2sb"))
@@ -982,9 +984,12 @@ def final_line(out, details):
     cpu = line.get("cpu_baseline")
     if cpu:
         cpu.pop("legs", None)
-        cpu["sample"] = short(cpu["sample"])
+        cpu["sample"] = short(cpu["sample"], 60)
     cfg = line.get("config") or {}
     cfg.pop("plan", None)
+    for k in ("gather", "comm"):
+        if cfg.get(k) == "n/a":
+            cfg.pop(k)
     for k, v in list(cfg.items()):
         if isinstance(v, str):
             cfg[k] = short(v)
@@ -993,6 +998,9 @@ def final_line(out, details):
     for name, blk in (details.get("baseline_configs") or {}).items():
         keep = {k: v for k, v in blk.items() if k not in ("workload", "steps", "warmup", "unit", "dtype", "algorithmic_bytes",
                                                           "setup_and_run_s")}
+        if keep.get("n_gpus") == 1:          # one rank: the spread over ranks and the host-side step time say nothing new
+            for k in ("kernel_ms_min", "kernel_ms_max", "ms_per_step"):
+                keep.pop(k, None)
         if "with_gather" in keep and "value" in keep["with_gather"]:
             g = keep["with_gather"]
             keep["with_gather"] = {k: g[k] for k in ("value", "ms_per_step", "ranks", "gathered_bytes_per_step", "tiles", "steps")}
@@ -1002,7 +1010,7 @@ def final_line(out, details):
         keys = ("in", "init_ms", "regrid_ms", "cpu_scipy_ms", "cpu_c1_ms", "bit_equal")
         line["reference_sized"] = {n: ({k: e[k] for k in keys if k in e} if "regrid_ms" in e else
                                        {"error": short(e.get("error") or e.get("skipped"), 60)}) for n, e in ref.items()}
-        line["reference_sized"]["unit"] = "ms per regrid() call, host to host; cpu = oracle, 1 core"
+        line["reference_sized"]["unit"] = "ms per regrid() host->host; cpu: 1-core oracle"
     h2h = details.get("host_to_host")
     if h2h:
         blk = {"rows": h2h.get("rows"), "unit": "cells/s (host_GBs)"}
