@@ -16,7 +16,7 @@ fs=glob.glob(f"/tmp/pm_{i}/*/*_counter_collection.csv")
 if not fs: print("no output"); sys.exit(0)
 agg=collections.defaultdict(list)
 for r in csv.DictReader(open(fs[0])):
-    if "smm_apply_tile" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "_apply_tile" in r["Kernel_Name"] or "apply_sb_kernel" in r["Kernel_Name"]: agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items(): print(f"{k}: mean {sum(v)/len(v):.6g} (n={len(v)})")
 PY
 done
