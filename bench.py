@@ -139,6 +139,15 @@ def algorithmic_bytes(op, n_batch, sx, sy):
     return n_batch * (op.n_used_src * sx + op.n_dst * sy) + op.nnz * 12 + (op.n_dst + 1) * 4
 
 
+def distinct_lines(used_cells, itemsize, phases=(0,)):
+    """Distinct 128-B lines of one field row that hold a used source cell: the floor of what ANY kernel must fetch per
+    batch row in the native (B, S) layout (a union over the operator, so lines shared by neighbouring destination blocks
+    count once -- what a tile plan stages beyond it is halo re-fetch).  `phases` = byte offsets of the row's first cell
+    inside its line; rows packed back to back cycle through several, the mean is returned."""
+    cells = np.asarray(used_cells, dtype=np.int64) * itemsize
+    return float(np.mean([np.unique((cells + int(ph)) // 128).size for ph in phases]))
+
+
 class Problem2D:
     """One operator, X (B, S) -> Y (B, D)."""
 
@@ -192,6 +201,16 @@ class Problem2D:
             return None
         return (self.n_batch * (staged * np.dtype(self.np_dt).itemsize + self.n_dst * np.dtype(self.y_dt).itemsize)
                 + self.op.nnz * 12)
+
+    def distinct_line_bytes(self):
+        """Layout floor: the union of distinct 128-B lines of X that carry a used cell, + Y + the operator once."""
+        if self.layout != "bs":
+            return None
+        isz = np.dtype(self.np_dt).itemsize
+        row = self.n_src * isz
+        phases = sorted({(r * row) % 128 for r in range(32)})      # rows back to back: the start offsets they cycle through
+        lines = distinct_lines(self.op.used_sources(), isz, phases)
+        return self.n_batch * (lines * 128 + self.n_dst * np.dtype(self.y_dt).itemsize) + self.op.nnz * 12
 
     def run(self, y, flags):
         if self.layout == "bs":
@@ -422,12 +441,26 @@ class ProblemLevels:
         return self.n_t * self.n_lev * (self.n_src + self.n_dst) * 8 + sum(op.nnz for op in self.ops) * 12
 
     def line_bytes(self):
+        """What the members' own tile plans stage per time step (every block's distinct lines, halo lines shared by
+        neighbouring blocks counted per block); None when a level has no plan of its own (the group's shared block
+        shape then differs from it anyway)."""
         if self.layout == "sb":
             return None
         staged = [op.plan_info()["staged_src_elems"] for op in self.ops]
         if not all(op.plan_info()["tile_plan"] for op in self.ops):
             return None
         return self.n_t * (sum(staged) + self.n_lev * self.n_dst) * 8 + sum(op.nnz for op in self.ops) * 12
+
+    def distinct_line_bytes(self):
+        """Layout floor per launch: per level the UNION of distinct 128-B lines of a field row that carry a used cell
+        (rows on 128-B lines: every row starts a line; packed: S * 8 B = 80 mod 128, the rows cycle through 8 start
+        offsets), + Y + the operators once.  PMC traffic above it is halo re-fetch between blocks, below it cache hits."""
+        if self.layout == "sb":
+            return None
+        row = self.n_src * 8
+        phases = (0,) if self.padded else sorted({(r * row) % 128 for r in range(32)})
+        lines = sum(distinct_lines(op.used_sources(), 8, phases) for op in self.ops)
+        return self.n_t * (lines * 128 + self.n_lev * self.n_dst * 8) + sum(op.nnz for op in self.ops) * 12
 
     def run(self, y, flags):
         if self.layout == "sb":
@@ -717,11 +750,16 @@ def roofline_block(args, prob, k_avg, workload, batch, with_copy_rate=True):
     achieved = b_alg / k_avg / 1e9
     traffic, traffic_source = traffic_entry(args, workload, batch)
     line = prob.line_bytes()
+    floor = prob.distinct_line_bytes() if hasattr(prob, "distinct_line_bytes") else None
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
            "kernel_ms": k_avg * 1e3, "algorithmic_bytes": b_alg,
            "full_stream_bytes": prob.full_stream_bytes(), "line_granular_bytes": line,
            "line_granular_frac": (line / k_avg / 1e9 / HBM_PEAK_GBS) if line else None,
+           # the split of traffic / algorithmic: layout floor (distinct 128-B lines) x re-fetch between blocks
+           "distinct_line_bytes": floor,
+           "layout_floor_ratio": (floor / b_alg) if floor else None,
+           "refetch_ratio": (traffic / floor) if (floor and traffic) else None,
            "traffic_GBs": (traffic / k_avg / 1e9) if traffic else None}
     if with_copy_rate:
         out["stream_copy_GBs"] = stream_copy_gbs()
@@ -808,6 +846,10 @@ def layout_summary(entry):
     out = {"ms": round(r["kernel_ms"], 3), "frac": round(r["frac"], 4)}
     if r.get("traffic"):
         out["traffic_ratio"] = round(r["traffic"] / r["algorithmic_bytes"], 3)
+    if r.get("layout_floor_ratio"):       # traffic_ratio = floor (distinct 128-B lines / algorithmic) x refetch (traffic / floor)
+        out["floor"] = round(r["layout_floor_ratio"], 3)
+        if r.get("refetch_ratio"):
+            out["refetch"] = round(r["refetch_ratio"], 3)
     if "spot_check" in entry:
         out["spot_check"] = bool(entry["spot_check"].get("bit_equal_to_oracle"))
     return out
@@ -932,7 +974,8 @@ def compact(obj, digits=6):
 
 
 ROOFLINE_SCALARS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes",
-                    "traffic_ratio", "traffic_fresh", "line_granular_frac", "traffic_GBs", "stream_copy_GBs")
+                    "traffic_ratio", "traffic_fresh", "line_granular_frac", "layout_floor_ratio", "refetch_ratio", "traffic_GBs",
+                    "stream_copy_GBs")
 
 
 def final_line(out, details):
@@ -940,7 +983,7 @@ def final_line(out, details):
     their own keys, strings short, nested blocks small.  Everything bulky went to the `details` line.
     The driver's record keeps the first two dozen scalar keys of a nested block and the last 2 kB of the output:
     `roofline` therefore lists its scalars first (the headline's, then every other workload's fraction) and its
-    nested `layouts` / `configs` last, and the line ends with `baseline_configs`, `reference_sized`, `host_to_host`."""
+    nested `layouts` / `configs` last, and the line ends with `reference_sized`, `baseline_configs`, `host_to_host`."""
     line = dict(out)
     others = details.get("others") or {}
     full = line.get("roofline") or {}
@@ -968,13 +1011,9 @@ def final_line(out, details):
         for key in ("frac", "ms", "traffic_ratio"):
             if key in sb:
                 roof[f"batch_fastest_{key}"] = sb[key]
+        # (the per-workload fractions live in `roofline.configs` and `baseline_configs` only: round 5 repeated them as
+        # scalars here and the line came within 0.4 kB of its budget)
         nested["configs"] = {n: layout_summary(e) for n, e in others.items() if not n.startswith("cfg2sb")}
-        for n, e in nested["configs"].items():
-            if "frac" in e:
-                roof[f"{n}_frac"] = e["frac"]
-    for name, blk in (details.get("baseline_configs") or {}).items():
-        if isinstance(blk, dict) and blk.get("frac") is not None:
-            roof[f"{name}_frac"] = round(blk["frac"], 4)
     for k in ("kernel_ms_min_rank", "kernel_ms_max_rank"):
         if k in full and line.get("n_gpus", 1) > 1:
             roof[k] = full[k]
@@ -1004,6 +1043,12 @@ def final_line(out, details):
         if "with_gather" in keep and "value" in keep["with_gather"]:
             g = keep["with_gather"]
             keep["with_gather"] = {k: g[k] for k in ("value", "ms_per_step", "ranks", "gathered_bytes_per_step", "tiles", "steps")}
+        if "f32_out" in keep and "frac" in keep["f32_out"]:      # config 4 with the opt-in f32 store (SURVEY 8d's f32 / f32 bytes)
+            f = keep["f32_out"]
+            keep["f32_out"] = {"ms": round(f["kernel_ms"], 3), "frac": round(f["frac"], 4), "alg_GB": round(f["algorithmic_bytes"] / 1e9, 2),
+                               "spot_check": f["spot_check"]}
+        if "algorithmic_bytes" in blk:
+            keep["alg_GB"] = round(blk["algorithmic_bytes"] / 1e9, 2)
         line.setdefault("baseline_configs", {})[name] = keep
     ref = details.get("reference_sized")
     if ref:
@@ -1013,14 +1058,24 @@ def final_line(out, details):
         line["reference_sized"]["unit"] = "ms per regrid() host->host; cpu: 1-core oracle"
     h2h = details.get("host_to_host")
     if h2h:
-        blk = {"rows": h2h.get("rows"), "unit": "cells/s (host_GBs)"}
+        # per mode: median and best cells/s of `reps` calls, the fraction of the measured PCIe (H2D) and host-memory
+        # (2 x the staging pool's copy rate) ceilings it runs at, and the stage split of one call in ms
+        blk = {"rows": h2h.get("rows"), "reps": h2h.get("reps"),
+               "unit": "cells/s; st = ms/call: stage-in, h2d, kernel, d2h, copy-out, wait, total", "ceil_GBs": h2h.get("ceilings")}
         for k, e in h2h.items():
             if isinstance(e, dict) and "cells_per_s" in e:
-                blk[k] = [float(f"{e['cells_per_s']:.4g}"), round(e["host_GBs"], 1)]
-        for k in ("pcie_bytes_per_row", "cpu_cells_per_s", "spot_check", "error"):
+                st = e.get("stage_ms") or {}
+                blk[k] = {"v": float(f"{e['cells_per_s']:.4g}"), "best": float(f"{e.get('cells_per_s_best', 0):.4g}"),
+                          "pcie": round(e.get("pcie_frac", 0), 2), "mem": round(e.get("host_mem_frac", 0), 2),
+                          "st": [round(st.get(n, 0), 1) for n in ("stage_in", "h2d", "kernel", "d2h", "copy_out", "wait", "total")]}
+        for k in ("staging_threads", "cpu_cells_per_s", "spot_check", "bound", "error"):
             if k in h2h:
                 blk[k] = h2h[k]
         line["host_to_host"] = blk
+    # the record keeps the last 2 kB of the output whatever happens: the user-visible paths and the BASELINE configs go last
+    for key in ("reference_sized", "baseline_configs", "host_to_host"):
+        if key in line:
+            line[key] = line.pop(key)
     for key in ("config", "roofline", "cpu_baseline", "with_gather", "baseline_configs", "spot_check", "host_to_host",
                 "reference_sized"):
         if key in line:
@@ -1083,6 +1138,27 @@ def baseline_config_block(args, name, runner, local_rank, rank, world, n_ranks, 
             blk["spot_check"] = bool(chk["bit_equal_to_oracle"])
             if not blk["spot_check"]:
                 raise SystemExit(f"bench.py: {name}: the timed output differs from the CPU oracle: {chk}")
+    if name == "cfg4" and world == 1 and not args.dry_run:
+        # SURVEY 8d quotes config 4's algorithmic bytes f32 in / f32 out; the default above is the reference's dtype rule
+        # (result_type(x, f64) = f64, regrid.py:550).  The opt-in f32 store (y_dtype = SMM_F32: the rounded f64 result)
+        # on the same operator and field, timed the same way, with its own algorithmic bytes and spot check.
+        try:
+            y.free()
+            prob.y_dt = np.float32
+            y = DeviceArray(prob.y_shape, np.float32)
+            _, k32 = runner.timed(prob, y, flags, steps, warmup)
+            k32_avg = float(np.mean(k32)) * 1e-3
+            alg32 = prob.alg_bytes()
+            chk32 = prob.spot_check(y)
+            blk["f32_out"] = {"kernel_ms": k32_avg * 1e3, "algorithmic_bytes": alg32,
+                              "frac": alg32 / k32_avg / 1e9 / HBM_PEAK_GBS, "spot_check": bool(chk32["bit_equal_to_oracle"]),
+                              "value": prob.cells() / k32_avg}
+            if not blk["f32_out"]["spot_check"]:
+                raise SystemExit(f"bench.py: {name} f32 out: the timed output differs from the rounded oracle: {chk32}")
+        except SystemExit:
+            raise
+        except Exception as exc:
+            blk["f32_out"] = {"error": short(repr(exc), 80)}
     if comm is not None and args.gather == "root":
         try:
             g = gather_phase(args, runner, prob, y, flags, comm, world, n_ranks, args.config_gather_steps, 1)
@@ -1187,10 +1263,12 @@ def main():
             if hasattr(prob, "spot_check"):
                 out["spot_check"] = prob.spot_check(y)
                 if not out["spot_check"]["bit_equal_to_oracle"]:
-                    if not os.environ.get("SMM_LIB_PATH"):
+                    if os.environ.get("SMM_BENCH_ABLATION") != "1":
                         raise SystemExit(f"bench.py: the timed output differs from the CPU oracle: {out['spot_check']}")
-                    # a timing-only ablation build (tools/exp/build_exp.sh) computes wrong results by design
-                    out["spot_check"]["experiment_library"] = os.environ["SMM_LIB_PATH"]
+                    # a timing-only ablation build (tools/exp/build_exp.sh: -DSMM_EXP_*) computes wrong results by
+                    # design; the explicit opt-in keeps the line but marks it as no measurement of the product
+                    out["spot_check"]["experiment_library"] = os.environ.get("SMM_LIB_PATH", "in-tree")
+                    out["invalid"] = "ablation build: results differ from the oracle (SMM_BENCH_ABLATION=1)"
         out["roofline"]["kernel_ms_min_rank"] = min(k_ranks)
         out["roofline"]["kernel_ms_max_rank"] = max(k_ranks)
 

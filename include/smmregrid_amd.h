@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SMM_ABI_VERSION 5
+#define SMM_ABI_VERSION 6
 
 /* status codes */
 enum {
@@ -57,7 +57,8 @@ enum {
   SMM_F64 = 1
 };
 
-/* smm_apply flags */
+/* smm_apply flags.  Bits outside this set are refused with SMM_ERR_INVALID by every entry that takes `flags`
+ * (ABI <= 4 encoded kernel variants in bits 16..23: those are smm_debug_set_tuning knobs now). */
 enum {
   SMM_APPLY_MASKED = 1u << 0,   /* apply dst_imask (regrid.py:553-559); per level in a group */
   SMM_APPLY_NO_FILL = 1u << 1,  /* skip the 1e20 fill: the caller guarantees finite X (results are undefined otherwise) */
@@ -84,6 +85,9 @@ int smm_malloc(void** dptr, size_t bytes);
 int smm_free(void* dptr);
 int smm_host_alloc(void** hptr, size_t bytes); /* pinned host memory */
 int smm_host_free(void* hptr);
+/* host -> host copy on the library's staging threads (what the host pipelines use between the caller's arrays and
+ * their pinned staging): one thread tops out far below PCIe when it fills a pinned buffer.  The ranges must not overlap. */
+int smm_host_memcpy(void* dst_host, const void* src_host, size_t bytes);
 int smm_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 int smm_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
 int smm_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
@@ -325,6 +329,33 @@ int smm_group_apply_host(smm_group_t g,
  * smm_apply_host / smm_group_apply_host call fails with SMM_ERR_HIP before its copies are queued;
  * chunk < 0 (the initial state) switches it off.  Process-wide; for tests only. */
 int smm_debug_fail_at_chunk(int64_t chunk);
+/* Test hook of the staging pool behind the host pipelines (one persistent set of worker threads per process, started
+ * on first need): no_threads != 0 = behave as if no worker thread could be started (the calling thread then does the
+ * staging alone: same bits); throw_in_task >= 0 = the staging task started after that many others throws
+ * std::bad_alloc, which the pipeline must turn into SMM_ERR_ALLOC after draining the copies in flight; -1 = off.
+ * Process-wide; for tests only. */
+int smm_debug_staging_faults(int no_threads, int64_t throw_in_task);
+
+/* Where the host pipelines (smm_apply_host / smm_group_apply_host) spent their time, summed over the calls of this
+ * process since the last reset: out[i] for i < n receives entry i of the list below (ms unless said otherwise).
+ * STAGE_IN = pack / copy into the pinned staging (calling thread + the staging pool), COPY_OUT = pinned staging ->
+ * the caller's Y, WAIT = the calling thread blocked on a chunk's stream; H2D / KERNEL / D2H = per chunk from HIP
+ * events on the chunk's stream, summed (the two streams overlap, so the sums may exceed TOTAL, the wall time of the
+ * calls).  reset != 0 zeroes the sums afterwards.  For benchmarks and tests. */
+enum {
+  SMM_HOST_STAT_CALLS = 0, /* count */
+  SMM_HOST_STAT_CHUNKS,    /* count */
+  SMM_HOST_STAT_STAGE_IN_MS,
+  SMM_HOST_STAT_H2D_MS,
+  SMM_HOST_STAT_KERNEL_MS,
+  SMM_HOST_STAT_D2H_MS,
+  SMM_HOST_STAT_COPY_OUT_MS,
+  SMM_HOST_STAT_WAIT_MS,
+  SMM_HOST_STAT_TOTAL_MS,
+  SMM_HOST_STAT_THREADS,   /* staging threads in force at the last call (count) */
+  SMM_HOST_STAT_COUNT
+};
+int smm_debug_host_stats(double* out, int n, int reset);
 
 /* Launch grids are 1-D: a batch whose grid would exceed 2^31 - 1 workgroups is cut into parts that are
  * launched one after the other on the same stream (smm_apply / smm_group_apply: halves of the outer batch
@@ -349,14 +380,18 @@ enum {
   SMM_TUNE_SB_LOADS,            /* batch-fastest kernel: loads per batch of the link walk (4, 8)               */
   SMM_TUNE_SB_LEVEL_LAUNCHES,   /* smm_group_apply_sb: 1 = one launch per data level instead of one grouped launch */
   SMM_TUNE_SB_LDS_PAD,          /* batch-fastest kernels: extra LDS bytes per wave, capping the waves per CU    */
+  SMM_TUNE_SB_PAIR_TILES,       /* batch-fastest kernels: tiles per band of two destination-grid rows whose tiles are interleaved (0 = off) */
+  SMM_TUNE_HOST_PACK_STORES,    /* host pipelines: 1 = the pack writes its staging block with plain (not non-temporal) stores */
   SMM_TUNE_COUNT
 };
 int smm_debug_set_tuning(int knob, int value, int* previous);
 
 /* Host threads of operator creation (the sort / duplicate sum replacing weights.py:25-44, the SELL layout and
- * the tile plans are built on several cores): n > 0 fixes the count, 0 (the initial state) = automatic -- the
- * hardware threads, at most 16, shared between the creations running at that moment.  The operator does not
- * depend on the count.  *previous (may be NULL) receives the former setting.  Process-wide. */
+ * the tile plans are built on several cores) and of the host pipelines' staging copies (one persistent worker
+ * pool per process): n > 0 fixes the count, 0 (the initial state) = automatic -- the CPUs the process may really
+ * use (scheduler affinity capped by the cgroup CPU quota), at most 16, creations running at the same moment
+ * sharing them.  Results do not depend on the count.  *previous (may be NULL) receives the former setting.
+ * Process-wide. */
 int smm_set_host_threads(int n, int* previous);
 
 /* ------------------------------------------------- multi-GPU exchange (RCCL over xGMI) */

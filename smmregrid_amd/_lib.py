@@ -32,7 +32,8 @@ APPLY_KERNEL_TILE = 1 << 9
 
 # smm_debug_set_tuning knobs (tests, tools, benchmarks; the results do not depend on them)
 TUNE_KNOBS = ("sell_batch_rows", "tile_walk", "tile_staging", "tile_rows_per_step", "tile_x_loads",
-              "tile_split_rows", "tile_links", "xcd_run", "sb_strip", "sb_loads", "sb_level_launches", "sb_lds_pad")
+              "tile_split_rows", "tile_links", "xcd_run", "sb_strip", "sb_loads", "sb_level_launches", "sb_lds_pad",
+              "sb_pair_tiles", "host_pack_stores")
 TUNE = {name: i for i, name in enumerate(TUNE_KNOBS)}
 STAGING_REGISTERS, STAGING_DMA = 1, 2
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "smm_free": [_p],
     "smm_host_alloc": [_pp, _size],
     "smm_host_free": [_p],
+    "smm_host_memcpy": [_p, _p, _size],
     "smm_memcpy_h2d": [_p, _p, _size, _p],
     "smm_memcpy_d2h": [_p, _p, _size, _p],
     "smm_memcpy_d2d": [_p, _p, _size, _p],
@@ -115,6 +117,8 @@ SIGNATURES = {
     "smm_group_apply_sb": [_p, _p, _int, _i64, _i64, _p, _int, _i64, _i64, _i64, _i64, _p, _p, _dbl, _uint, _p],
     "smm_group_apply_host": [_p, _p, _int, _p, _int, _i64, _i64, _i64, _int, _p, _p, _dbl, _uint, _i64],
     "smm_debug_fail_at_chunk": [_i64],
+    "smm_debug_host_stats": [ctypes.POINTER(_dbl), _int, _int],
+    "smm_debug_staging_faults": [_int, _i64],
     "smm_debug_set_grid_limit": [_i64],
     "smm_debug_set_tuning": [_int, _int, ctypes.POINTER(_int)],
     "smm_set_host_threads": [_int, ctypes.POINTER(_int)],
@@ -188,6 +192,17 @@ def device_count():
         return 0
     check(status)
     return n.value
+
+
+HOST_STATS = ("calls", "chunks", "stage_in_ms", "h2d_ms", "kernel_ms", "d2h_ms", "copy_out_ms", "wait_ms", "total_ms",
+              "threads")
+
+
+def host_stats(reset=False):
+    """smm_debug_host_stats: where smm_apply_host / smm_group_apply_host spent their time since the last reset."""
+    buf = (_dbl * len(HOST_STATS))()
+    call("smm_debug_host_stats", buf, len(HOST_STATS), 1 if reset else 0)
+    return dict(zip(HOST_STATS, (float(v) for v in buf)))
 
 
 def set_tuning(knob, value):

@@ -27,11 +27,12 @@ void debug_builder_faults(bool no_threads, int64_t throw_in_task) {
 }
 
 int set_host_threads(int n) { return g_host_threads.exchange(n < 0 ? 0 : n); }
+int fixed_host_threads() { return g_host_threads.load(); }
 
 int host_threads(int64_t work_items, int64_t min_items_per_thread) {
   const int fixed = g_host_threads.load();
   if (fixed > 0) return fixed;   // the caller's count, whatever the work (tests force small inputs through every path)
-  const int hw = (int)std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+  const int hw = std::min(16, usable_cpus());   // affinity capped by the cgroup quota, not the host's thread count
   const int share = std::max(1, hw / std::max(1, g_active_builders.load()));
   const int64_t by_work = std::max<int64_t>(1, work_items / std::max<int64_t>(1, min_items_per_thread));
   return (int)std::min<int64_t>(share, by_work);
@@ -437,6 +438,8 @@ HostChunk host_chunk_units(int64_t n_units, size_t x_unit, size_t y_unit, size_t
                            size_t free_bytes) {
   constexpr size_t kTarget = (size_t)256 << 20;   // ~256 MiB of X + Y per chunk
   constexpr size_t kPackCap = (size_t)1 << 30;    // the shortest packed chunk may not exceed 1 GiB
+  constexpr size_t kMinChunk = (size_t)32 << 20;  // ... and no chunk is cut below 32 MiB to reach kMinChunks per call
+  constexpr int64_t kMinChunks = 8;
   HostChunk c;
   n_units = std::max<int64_t>(n_units, 1);
   min_pack_units = std::max<int64_t>(min_pack_units, 1);
@@ -457,9 +460,21 @@ HostChunk host_chunk_units(int64_t n_units, size_t x_unit, size_t y_unit, size_t
     }
     if (c.pack && pack_align > 1 && 2 * u >= pack_align)   // whole batch tiles of the kernel
       u = std::max<int64_t>(pack_align, u / pack_align * pack_align);
+    if (c.pack) {
+      // The first chunk's pack and the last chunk's D2H + copy-out overlap nothing: a call is cut into at least
+      // kMinChunks chunks while a chunk keeps kMinChunk bytes and the pack's minimum (config 2, 512 rows from host
+      // memory: 4 chunks of 128 rows 29.7 ms, 8 of 64 rows -- see profiles/r06_host_to_host.txt)
+      const int64_t floor_units = std::max<int64_t>(min_pack_units, (int64_t)(kMinChunk / unit_p));
+      const int64_t cap = std::max(floor_units, (n_units + kMinChunks - 1) / kMinChunks);
+      if (u > cap) u = cap >= 32 ? cap / 32 * 32 : cap;
+    }
     c.units = u;
   }
-  if (!c.pack) c.units = std::max<int64_t>(1, (int64_t)(kTarget / unit_w));
+  if (!c.pack) {
+    c.units = std::max<int64_t>(1, (int64_t)(kTarget / unit_w));
+    const int64_t floor_units = std::max<int64_t>(1, (int64_t)(kMinChunk / unit_w));
+    c.units = std::min(c.units, std::max(floor_units, (n_units + kMinChunks - 1) / kMinChunks));
+  }
   c.units = std::min(c.units, n_units);
   // the four device buffers of a chunk (2 x X, 2 x Y) may take a quarter of the free memory at most
   auto clamp = [&](size_t unit) {

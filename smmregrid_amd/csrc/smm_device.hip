@@ -20,11 +20,13 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -96,10 +98,16 @@ struct HostPipe {
   void* hx[2] = {nullptr, nullptr};
   void* hy[2] = {nullptr, nullptr};
   size_t cap_dx = 0, cap_dy = 0, cap_hx = 0, cap_hy = 0;
+  // per buffer: before the H2D, after it, after the kernel(s), after the D2H -- the stage times of a chunk
+  // (smm_debug_host_stats) are read from them once the chunk has been drained
+  hipEvent_t ev[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
   hipError_t ensure(size_t need_dx, size_t need_dy, size_t need_hx, size_t need_hy) {
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i)
       if (!stream[i]) e = hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking);
+    for (int i = 0; i < 2; ++i)
+      for (int k = 0; k < 4 && e == hipSuccess; ++k)
+        if (!ev[i][k]) e = hipEventCreate(&ev[i][k]);
     auto grow_dev = [&](void* (&buf)[2], size_t& cap, size_t need) {
       if (need <= cap || e != hipSuccess) return;
       for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -134,6 +142,8 @@ struct HostPipe {
   ~HostPipe() {
     for (int i = 0; i < 2; ++i) {
       if (stream[i]) (void)hipStreamDestroy(stream[i]);
+      for (int k = 0; k < 4; ++k)
+        if (ev[i][k]) (void)hipEventDestroy(ev[i][k]);
       (void)hipFree(dx[i]);
       (void)hipFree(dy[i]);
       if (hx[i]) (void)hipHostFree(hx[i]);
@@ -479,82 +489,66 @@ int run_apply(const LevelDesc* d_descs, const int32_t* d_lev_map, const uint8_t*
 
 namespace {
 
-// parallel host copy (pageable <-> pinned staging); a single thread tops out far below PCIe
-void host_copy(void* dst, const void* src, size_t bytes) {
-  const size_t kMin = 8u << 20;
-  unsigned nt = std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-  if (bytes < 2 * kMin) nt = 1;
-  if (nt == 1) {
-    memcpy(dst, src, bytes);
-    return;
-  }
-  std::vector<std::thread> pool;
-  const size_t per = (bytes / nt + 63) & ~(size_t)63;
-  for (unsigned t = 0; t < nt; ++t) {
-    const size_t lo = std::min(bytes, (size_t)t * per), hi = std::min(bytes, lo + per);
-    if (hi > lo) pool.emplace_back([=] { memcpy((char*)dst + lo, (const char*)src + lo, hi - lo); });
-  }
-  for (auto& th : pool) th.join();
-}
-
 // test hook for the pipelines' error path (smm_debug_fail_at_chunk): chunk c of the next host-pipeline
 // calls fails; -1 (the default) = off.  Set explicitly by the tests, never read from the environment.
 std::atomic<int64_t> g_fail_at_chunk{-1};
 int64_t test_fail_chunk() { return g_fail_at_chunk.load(std::memory_order_relaxed); }
 
-// Pack of the host pipeline: out[u * rows + r] = x[r * ldx + used[u]] -- the used source cells of a
-// chunk of batch rows, batch-fastest, ready for smm_apply_sb (SMM_APPLY_SB_PACKED).  Threads split
-// the used cells; rows go in blocks of 16 so that a block's 16 source lines stay in L1 while the
-// neighbouring cells of the same lines are picked up.
-// Batch entry r of the chunk is the source row at x + (r / n_inner) * stride_o + (r % n_inner) * stride_i
-// (elements): plain row blocks have n_inner = rows' worth of stride_i = ldx; one level of a
-// (outer, level, inner, S) field has stride_o = n_lev * n_inner * S, stride_i = S.
-template <typename T>
-void pack_rows_t(T* __restrict__ out, const T* __restrict__ x, int64_t n_inner, int64_t stride_o, int64_t stride_i,
-                 const int32_t* __restrict__ used, int64_t u0, int64_t u1, int64_t rows) {
-  constexpr int64_t RB = 16;
-  for (int64_t r0 = 0; r0 < rows; r0 += RB) {
-    const int64_t rn = std::min(RB, rows - r0);
-    const T* row[RB];
-    for (int64_t r = 0; r < rn; ++r) row[r] = x + (size_t)((r0 + r) / n_inner) * stride_o + (size_t)((r0 + r) % n_inner) * stride_i;
-    for (int64_t u = u0; u < u1; ++u) {
-      const int32_t c = used[u];
-      T* dst = out + (size_t)u * rows + r0;
-      for (int64_t r = 0; r < rn; ++r) dst[r] = row[r][c];
-    }
-  }
+// Staging stages of the two host pipelines (smm_hostpool.cpp: one persistent worker pool, nothing throws):
+// their int results become statuses here.
+int stage_status(int rc, const char* what) {
+  if (rc == 0) return SMM_OK;
+  return fail(rc == 1 ? SMM_ERR_ALLOC : SMM_ERR_INTERNAL,
+              std::string(what) + (rc == 1 ? ": out of host memory in a staging task" : ": a staging task failed"));
+}
+int host_copy(void* dst, const void* src, size_t bytes) { return stage_status(smm::host_copy(dst, src, bytes), "host copy"); }
+int host_pack(void* out, const void* x, size_t xsz, int64_t n_inner, int64_t stride_o, int64_t stride_i,
+              const std::vector<int32_t>& used, int64_t rows) {
+  return stage_status(smm::host_pack(out, x, xsz, n_inner, stride_o, stride_i, used.data(), (int64_t)used.size(), rows,
+                                     smm::tuning(SMM_TUNE_HOST_PACK_STORES) != 1),
+                      "host pack");
+}
+int host_pack(void* out, const void* x, size_t xsz, int64_t ldx, const std::vector<int32_t>& used, int64_t rows) {
+  return host_pack(out, x, xsz, std::max<int64_t>(rows, 1), 0, ldx, used, rows);
 }
 
-void host_pack(void* out, const void* x, size_t xsz, int64_t n_inner, int64_t stride_o, int64_t stride_i,
-               const std::vector<int32_t>& used, int64_t rows);
+// What the two host pipelines spent where, summed since the last reset (smm_debug_host_stats).
+struct HostStats {
+  std::mutex mu;
+  double v[SMM_HOST_STAT_COUNT] = {};
+} g_host_stats;
 
-void host_pack(void* out, const void* x, size_t xsz, int64_t ldx, const std::vector<int32_t>& used, int64_t rows) {
-  host_pack(out, x, xsz, std::max<int64_t>(rows, 1), 0, ldx, used, rows);
+inline double wall_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-void host_pack(void* out, const void* x, size_t xsz, int64_t n_inner, int64_t stride_o, int64_t stride_i,
-               const std::vector<int32_t>& used, int64_t rows) {
-  const int64_t U = (int64_t)used.size();
-  unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-  if ((size_t)U * rows * xsz < (4u << 20)) nt = 1;
-  auto work = [&](int64_t u0, int64_t u1) {
-    if (xsz == 8)
-      pack_rows_t((double*)out, (const double*)x, n_inner, stride_o, stride_i, used.data(), u0, u1, rows);
-    else
-      pack_rows_t((float*)out, (const float*)x, n_inner, stride_o, stride_i, used.data(), u0, u1, rows);
-  };
-  if (nt == 1) {
-    work(0, U);
-    return;
+// one call's share: host-side stages by the wall clock of the calling thread, device-side stages from the
+// chunk's four events once its stream has been synchronised
+struct CallStats {
+  double v[SMM_HOST_STAT_COUNT] = {};
+  double t_call = wall_ms();
+  void chunk_done(HostPipe& pipe, int b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pipe.ev[b][0], pipe.ev[b][1]) == hipSuccess) v[SMM_HOST_STAT_H2D_MS] += ms;
+    if (hipEventElapsedTime(&ms, pipe.ev[b][1], pipe.ev[b][2]) == hipSuccess) v[SMM_HOST_STAT_KERNEL_MS] += ms;
+    if (hipEventElapsedTime(&ms, pipe.ev[b][2], pipe.ev[b][3]) == hipSuccess) v[SMM_HOST_STAT_D2H_MS] += ms;
+    (void)hipGetLastError();
+    v[SMM_HOST_STAT_CHUNKS] += 1;
   }
-  std::vector<std::thread> pool;
-  const int64_t per = (U + nt - 1) / nt;
-  for (unsigned t = 0; t < nt; ++t) {
-    const int64_t lo = std::min(U, (int64_t)t * per), hi = std::min(U, lo + per);
-    if (hi > lo) pool.emplace_back(work, lo, hi);
+  ~CallStats() {
+    v[SMM_HOST_STAT_CALLS] = 1;
+    v[SMM_HOST_STAT_TOTAL_MS] = wall_ms() - t_call;
+    std::lock_guard<std::mutex> lock(g_host_stats.mu);
+    for (int i = 0; i < SMM_HOST_STAT_COUNT; ++i) g_host_stats.v[i] += v[i];
+    g_host_stats.v[SMM_HOST_STAT_THREADS] = (double)smm::staging_threads();
   }
-  for (auto& th : pool) th.join();
-}
+};
+struct StageTimer {   // adds the scope's wall time to one entry
+  double& acc;
+  double t0 = wall_ms();
+  explicit StageTimer(double& a) : acc(a) {}
+  ~StageTimer() { acc += wall_ms() - t0; }
+};
 
 bool is_pinned(const void* p) {
   hipPointerAttribute_t attr;
@@ -563,6 +557,51 @@ bool is_pinned(const void* p) {
     return false;
   }
   return attr.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+namespace {
+
+// Every extern "C" entry that can reach an allocation runs its body through this: the header promises an int
+// status, never an exception.  (fail() assigns a std::string and may itself run out of memory: then the status
+// alone has to do.)
+template <typename F>
+int guarded(F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    try {
+      return fail(SMM_ERR_ALLOC, "out of host memory");
+    } catch (...) {
+      return SMM_ERR_ALLOC;
+    }
+  } catch (const std::exception& e) {
+    try {
+      return fail(SMM_ERR_INTERNAL, std::string("unexpected failure: ") + e.what());
+    } catch (...) {
+      return SMM_ERR_INTERNAL;
+    }
+  } catch (...) {
+    try {
+      return fail(SMM_ERR_INTERNAL, "unexpected failure (unknown exception)");
+    } catch (...) {
+      return SMM_ERR_INTERNAL;
+    }
+  }
+}
+
+// apply flags the ABI defines; anything else (ABI v4 callers encoded kernel variants in bits 16..23) is refused
+constexpr unsigned kApplyFlagMask = SMM_APPLY_MASKED | SMM_APPLY_NO_FILL | SMM_APPLY_SB_PACKED | SMM_APPLY_HOST_NO_PACK |
+                                    SMM_APPLY_SB_Y_SB | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE;
+inline int check_flags(unsigned flags) {
+  if (flags & ~kApplyFlagMask)
+    return fail(SMM_ERR_INVALID, "unknown apply flag bits 0x" + [](unsigned v) {
+             char buf[16];
+             snprintf(buf, sizeof(buf), "%x", v);
+             return std::string(buf);
+           }(flags & ~kApplyFlagMask) + " (launch-shape knobs are smm_debug_set_tuning entries, not flags)");
+  return SMM_OK;
 }
 
 }  // namespace
@@ -629,6 +668,11 @@ int smm_host_free(void* hptr) {
   if (hptr) SMM_HIP(hipHostFree(hptr));
   return SMM_OK;
 }
+int smm_host_memcpy(void* dst_host, const void* src_host, size_t bytes) {
+  if (bytes == 0) return SMM_OK;
+  if (!dst_host || !src_host) return fail(SMM_ERR_INVALID, "null host pointer");
+  return host_copy(dst_host, src_host, bytes);
+}
 int smm_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
   if (bytes == 0) return SMM_OK;
   if (stream)
@@ -687,6 +731,20 @@ int smm_set_host_threads(int n, int* previous) {
   if (n < 0) return fail(SMM_ERR_INVALID, "negative thread count");
   const int prev = smm::set_host_threads(n);
   if (previous) *previous = prev;
+  return SMM_OK;
+}
+
+int smm_debug_host_stats(double* out, int n, int reset) {
+  if (n < 0 || (n > 0 && !out)) return fail(SMM_ERR_INVALID, "bad stats buffer");
+  std::lock_guard<std::mutex> lock(g_host_stats.mu);
+  for (int i = 0; i < n; ++i) out[i] = i < SMM_HOST_STAT_COUNT ? g_host_stats.v[i] : 0.0;
+  if (reset)
+    for (double& v : g_host_stats.v) v = 0.0;
+  return SMM_OK;
+}
+
+int smm_debug_staging_faults(int no_threads, int64_t throw_in_task) {
+  smm::debug_pool_faults(no_threads != 0, throw_in_task < 0 ? -1 : throw_in_task);
   return SMM_OK;
 }
 
@@ -914,7 +972,7 @@ int smm_operator_info(smm_operator_t op, int64_t* n_src, int64_t* n_dst, int64_t
   return SMM_OK;
 }
 
-int smm_operator_export_csr(smm_operator_t op, int64_t* rowptr, int32_t* col, double* val) {
+static int smm_operator_export_csr_impl(smm_operator_t op, int64_t* rowptr, int32_t* col, double* val) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   if (rowptr) memcpy(rowptr, op->csr.rowptr.data(), op->csr.rowptr.size() * sizeof(int64_t));
   if (col && op->csr.nnz) memcpy(col, op->csr.col.data(), (size_t)op->csr.nnz * sizeof(int32_t));
@@ -922,7 +980,7 @@ int smm_operator_export_csr(smm_operator_t op, int64_t* rowptr, int32_t* col, do
   return SMM_OK;
 }
 
-int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const double* dst_frac) {
+static int smm_operator_set_epilogue_impl(smm_operator_t op, const int32_t* dst_imask, const double* dst_frac) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   // a group's level descriptors hold this operator's imask / frac device pointers
   if (op->group_refs.load() > 0)
@@ -971,7 +1029,7 @@ int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const
   return SMM_OK;
 }
 
-int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
+static int smm_operator_plan_info_impl(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes,
                            int64_t* staged_src_elems) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   const smm_operator::TilePlan& pl = op->plan[op->native_plan()];
@@ -982,8 +1040,9 @@ int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_byt
   return SMM_OK;
 }
 
-int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype,
+static int smm_apply_impl(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype,
               int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags, void* stream) {
+  if (int frc = check_flags(flags)) return frc;
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   if (n_batch > 0 && (ldx < op->csr.n_src || ldy < op->csr.n_dst))
     return fail(SMM_ERR_INVALID, "ldx/ldy smaller than the grid size");
@@ -1000,14 +1059,14 @@ int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* 
                    0, 0, n_batch, 1, 1, remap_area_min, flags, (hipStream_t)stream);
 }
 
-int smm_operator_prepare_sb(smm_operator_t op) {
+static int smm_operator_prepare_sb_impl(smm_operator_t op) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   DeviceGuard guard(op->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
   return ensure_sb(op);
 }
 
-int smm_operator_used_sources(smm_operator_t op, int32_t* used) {
+static int smm_operator_used_sources_impl(smm_operator_t op, int32_t* used) {
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   if (!used && op->csr.n_used_src > 0) return fail(SMM_ERR_INVALID, "null output");
   std::vector<uint8_t> seen((size_t)std::max<int64_t>(op->csr.n_src, 1), 0);
@@ -1018,8 +1077,9 @@ int smm_operator_used_sources(smm_operator_t op, int32_t* used) {
   return SMM_OK;
 }
 
-int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype,
+static int smm_apply_sb_impl(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype,
                  int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags, void* stream) {
+  if (int frc = check_flags(flags)) return frc;
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   if (n_batch < 0) return fail(SMM_ERR_INVALID, "negative batch size");
   if (n_batch == 0 || op->csr.n_dst == 0) return SMM_OK;
@@ -1077,9 +1137,10 @@ int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, voi
 
 // ---- host-buffer path: chunked, double-buffered H2D -> kernel -> D2H pipeline
 
-int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t ldx, void* y_host,
+static int smm_apply_host_impl(smm_operator_t op, const void* x_host, int x_dtype, int64_t ldx, void* y_host,
                    int y_dtype, int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags,
                    int64_t chunk_rows) {
+  if (int frc = check_flags(flags)) return frc;
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   if (n_batch < 0) return fail(SMM_ERR_INVALID, "negative batch size");
   if (n_batch == 0 || op->csr.n_dst == 0) return SMM_OK;
@@ -1131,13 +1192,20 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
                       y_direct ? 0 : (size_t)chunk_rows * D * ysz));
 
   const int64_t n_chunks = (n_batch + chunk_rows - 1) / chunk_rows;
+  CallStats st;
   auto drain = [&](int64_t c) -> int {  // results of chunk c: wait, then pinned -> user rows
     const int b = (int)(c & 1);
-    SMM_HIP(hipStreamSynchronize(pipe.stream[b]));
+    {
+      StageTimer t(st.v[SMM_HOST_STAT_WAIT_MS]);
+      SMM_HIP(hipStreamSynchronize(pipe.stream[b]));
+    }
+    st.chunk_done(pipe, b);
     if (!y_direct) {
+      StageTimer t(st.v[SMM_HOST_STAT_COPY_OUT_MS]);
       const int64_t r0 = c * chunk_rows, rows = std::min(chunk_rows, n_batch - r0);
       if ((int64_t)ldy == D) {
-        host_copy((char*)y_host + (size_t)r0 * yrow, pipe.hy[b], (size_t)rows * D * ysz);
+        int rc = host_copy((char*)y_host + (size_t)r0 * yrow, pipe.hy[b], (size_t)rows * D * ysz);
+        if (rc) return rc;
       } else {
         for (int64_t r = 0; r < rows; ++r)
           memcpy((char*)y_host + (size_t)(r0 + r) * yrow, (char*)pipe.hy[b] + (size_t)r * D * ysz,
@@ -1161,33 +1229,46 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
     if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (smm_debug_fail_at_chunk)");
     const char* xsrc = (const char*)x_host + (size_t)r0 * xrow;
     if (pack) {
-      host_pack(pipe.hx[b], xsrc, xsz, ldx, op->h_used, rows);
+      {
+        StageTimer t(st.v[SMM_HOST_STAT_STAGE_IN_MS]);
+        int rc = host_pack(pipe.hx[b], xsrc, xsz, ldx, op->h_used, rows);
+        if (rc) return rc;
+      }
+      SMM_HIP(hipEventRecord(pipe.ev[b][0], pipe.stream[b]));
       SMM_HIP(hipMemcpyAsync(pipe.dx[b], pipe.hx[b], (size_t)U * rows * xsz, hipMemcpyHostToDevice, pipe.stream[b]));
     } else if (!x_direct) {
-      if (ldx == S) {
-        host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
-      } else {
-        for (int64_t r = 0; r < rows; ++r)
-          memcpy((char*)pipe.hx[b] + (size_t)r * S * xsz, xsrc + (size_t)r * xrow, (size_t)S * xsz);
+      {
+        StageTimer t(st.v[SMM_HOST_STAT_STAGE_IN_MS]);
+        if (ldx == S) {
+          int rc = host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
+          if (rc) return rc;
+        } else {
+          for (int64_t r = 0; r < rows; ++r)
+            memcpy((char*)pipe.hx[b] + (size_t)r * S * xsz, xsrc + (size_t)r * xrow, (size_t)S * xsz);
+        }
       }
+      SMM_HIP(hipEventRecord(pipe.ev[b][0], pipe.stream[b]));
       SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, pipe.hx[b], (size_t)S * xsz, (size_t)S * xsz,
                                (size_t)rows, hipMemcpyHostToDevice, pipe.stream[b]));
     } else {
+      SMM_HIP(hipEventRecord(pipe.ev[b][0], pipe.stream[b]));
       SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, xsrc, xrow, (size_t)S * xsz, (size_t)rows,
                                hipMemcpyHostToDevice, pipe.stream[b]));
     }
+    SMM_HIP(hipEventRecord(pipe.ev[b][1], pipe.stream[b]));
     const int pw = op->native_plan();
     const smm_operator::TilePlan& pl = op->plan[pw];
     int rc = SMM_OK;
     if (pack)
-      rc = smm_apply_sb(op, pipe.dx[b], x_dtype, rows, pipe.dy[b], y_dtype, D, rows, remap_area_min,
-                        (flags & (SMM_APPLY_MASKED | SMM_APPLY_NO_FILL)) | SMM_APPLY_SB_PACKED, pipe.stream[b]);
+      rc = smm_apply_sb_impl(op, pipe.dx[b], x_dtype, rows, pipe.dy[b], y_dtype, D, rows, remap_area_min,
+                         (flags & (SMM_APPLY_MASKED | SMM_APPLY_NO_FILL)) | SMM_APPLY_SB_PACKED, pipe.stream[b]);
     else
       rc = run_apply(op->d_desc, nullptr, nullptr, S, op->csr.n_dst, pw, pl.valid, pl.preferred, (pl.reuse ? 1 : 0),
                      pl.max_chunks, op->csr.max_row_nnz, pipe.dx[b], x_dtype,
                      ldx_d, 0, 0, pipe.dy[b], y_dtype, D, 0, 0, rows, 1, 1, remap_area_min, flags,
                      pipe.stream[b]);
     if (rc) return rc;
+    SMM_HIP(hipEventRecord(pipe.ev[b][2], pipe.stream[b]));
     if (!y_direct) {
       SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)rows * D * ysz, hipMemcpyDeviceToHost,
                              pipe.stream[b]));
@@ -1195,6 +1276,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
       SMM_HIP(hipMemcpy2DAsync((char*)y_host + (size_t)r0 * yrow, yrow, pipe.dy[b], (size_t)D * ysz,
                                (size_t)D * ysz, (size_t)rows, hipMemcpyDeviceToHost, pipe.stream[b]));
     }
+    SMM_HIP(hipEventRecord(pipe.ev[b][3], pipe.stream[b]));
   }
   for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks; ++c) {
     int rc = drain(c);
@@ -1207,7 +1289,7 @@ int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t l
   return prc;
 }
 
-int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask) {
+static int smm_operator_mask_apply_impl(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask) {
   if (!op || !src_imask || !dst_imask) return fail(SMM_ERR_INVALID, "null argument");
   DeviceGuard guard(op->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the operator's device");
@@ -1253,7 +1335,7 @@ int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t
 
 // ---- groups
 
-int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
+static int smm_group_create_impl(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
   if (!out) return fail(SMM_ERR_INVALID, "null out handle");
   *out = nullptr;
   if (!ops || n_ops <= 0) return fail(SMM_ERR_INVALID, "a group needs at least one operator");
@@ -1263,8 +1345,9 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
         ops[i]->csr.n_dst != ops[0]->csr.n_dst)
       return fail(SMM_ERR_INVALID, "group members must share device and grid sizes");
   }
-  smm_group* g = new (std::nothrow) smm_group();
-  if (!g) return fail(SMM_ERR_ALLOC, "out of host memory");
+  std::unique_ptr<smm_group> owner(new (std::nothrow) smm_group());   // freed on every early return and on a throw
+  if (!owner) return fail(SMM_ERR_ALLOC, "out of host memory");
+  smm_group* g = owner.get();
   g->device = ops[0]->device;
   g->ops.assign(ops, ops + n_ops);
   g->tile_valid = true;
@@ -1272,18 +1355,12 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
   // any level has rows longer than 16 links), and the links' majority decides tile vs SELL
   for (int i = 0; i < n_ops; ++i) g->tile_which = std::max(g->tile_which, ops[i]->native_plan());
   DeviceGuard guard(g->device);
-  if (!guard.ok) {
-    delete g;
-    return fail(SMM_ERR_HIP, "cannot select device");
-  }
+  if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select device");
   int64_t nnz_all = 0, nnz_pref = 0;
   std::vector<LevelDesc> descs((size_t)n_ops);
   for (int i = 0; i < n_ops; ++i) {
     int prc = ensure_plan(ops[i], g->tile_which);
-    if (prc) {
-      delete g;
-      return prc;
-    }
+    if (prc) return prc;
     const smm_operator::TilePlan& pl = ops[i]->plan[g->tile_which];
     descs[(size_t)i] = ops[i]->desc(g->tile_which);
     g->tile_valid = g->tile_valid && pl.valid;
@@ -1295,12 +1372,9 @@ int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
   }
   g->tile_preferred = 2 * nnz_pref >= nnz_all;
   int rc = upload(&g->d_descs, descs);
-  if (rc) {
-    delete g;
-    return rc;
-  }
+  if (rc) return rc;
   for (int i = 0; i < n_ops; ++i) ops[i]->group_refs.fetch_add(1);
-  *out = g;
+  *out = owner.release();
   return SMM_OK;
 }
 
@@ -1381,7 +1455,7 @@ static int group_level_cfg(smm_group_t g, int64_t n_lev, const int32_t* level_in
 }
 }  // extern "C++"
 
-int smm_group_prepare(smm_group_t g, int64_t n_lev, const int32_t* level_index,
+static int smm_group_prepare_impl(smm_group_t g, int64_t n_lev, const int32_t* level_index,
                       const uint8_t* masked_levels) {
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   DeviceGuard guard(g->device);
@@ -1391,11 +1465,12 @@ int smm_group_prepare(smm_group_t g, int64_t n_lev, const int32_t* level_index,
   return group_level_cfg(g, n_lev, level_index, masked_levels, 0.0, 0u, &d_map, &d_masked);
 }
 
-int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer, int64_t xs_lev,
+static int smm_group_apply_impl(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer, int64_t xs_lev,
                     int64_t xs_inner, void* y, int y_dtype, int64_t ys_outer, int64_t ys_lev,
                     int64_t ys_inner, int64_t n_outer, int64_t n_lev, int64_t n_inner,
                     const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min,
                     unsigned flags, void* stream) {
+  if (int frc = check_flags(flags)) return frc;
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   DeviceGuard guard(g->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
@@ -1431,7 +1506,7 @@ static int check_sb_levels(smm_group_t g, int64_t n_lev, const int32_t* level_in
 }
 }  // extern "C++"
 
-int smm_group_prepare_sb(smm_group_t g) {
+static int smm_group_prepare_sb_impl(smm_group_t g) {
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   DeviceGuard guard(g->device);
   if (!guard.ok) return fail(SMM_ERR_HIP, "cannot select the group's device");
@@ -1450,10 +1525,11 @@ int smm_group_prepare_sb(smm_group_t g) {
 // BASELINE config 3 kept batch-fastest, same box: 9.51 ms against 10.24 ms for one launch per level dealt over a
 // pool of 8 streams (round 4's form, removed: profiles/r05_cfg3sb_grouped_vs_stream_pool.txt) and 14.4 ms for one
 // launch per level on one stream (still there: SMM_TUNE_SB_LEVEL_LAUNCHES, and for levels beyond the grid limit).
-int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev, int64_t ldx, void* y,
+static int smm_group_apply_sb_impl(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev, int64_t ldx, void* y,
                        int y_dtype, int64_t ys_lev, int64_t ys_batch, int64_t n_batch, int64_t n_lev,
                        const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min,
                        unsigned flags, void* stream) {
+  if (int frc = check_flags(flags)) return frc;
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   if (n_batch < 0 || n_lev < 0) return fail(SMM_ERR_INVALID, "negative batch size / level count");
   if (n_lev > 0 && !level_index) return fail(SMM_ERR_INVALID, "null level_index");
@@ -1546,9 +1622,10 @@ static void fill_launch_info(const LaunchInfo& li, int* kernel, int* j_per_block
 }
 }  // extern "C++"
 
-int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, unsigned flags, int* kernel,
+static int smm_operator_launch_info_impl(smm_operator_t op, int x_dtype, int64_t n_batch, unsigned flags, int* kernel,
                              int* j_per_block, int* rows_per_step, int* rows_per_block, int64_t* n_blocks,
                              int64_t* lds_bytes, int* big_operator) {
+  if (int frc = check_flags(flags)) return frc;
   if (!op) return fail(SMM_ERR_INVALID, "null operator");
   const int pw = op->native_plan();
   const smm_operator::TilePlan& pl = op->plan[pw];
@@ -1561,9 +1638,10 @@ int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, un
   return SMM_OK;
 }
 
-int smm_group_launch_info(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n_lev, int64_t n_inner,
+static int smm_group_launch_info_impl(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n_lev, int64_t n_inner,
                           unsigned flags, int* kernel, int* j_per_block, int* rows_per_step,
                           int* rows_per_block, int64_t* n_blocks, int64_t* lds_bytes, int* big_operator) {
+  if (int frc = check_flags(flags)) return frc;
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   const smm_operator* op0 = g->ops[0];
   LaunchInfo li;
@@ -1579,10 +1657,11 @@ int smm_group_launch_info(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n
 // Y host (n_outer, n_inner, n_lev, D) when transpose != 0 (regrid.py:420-427), else
 // (n_lev, n_outer, n_inner, D) (concat order, regrid.py:410).  Chunks of the outer axis
 // stream through the group's double-buffered H2D / kernel / D2H pipeline.
-int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y_host, int y_dtype,
+static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dtype, void* y_host, int y_dtype,
                          int64_t n_outer, int64_t n_lev, int64_t n_inner, int transpose,
                          const int32_t* level_index, const uint8_t* masked_levels,
                          double remap_area_min, unsigned flags, int64_t chunk_outer) {
+  if (int frc = check_flags(flags)) return frc;
   if (!g) return fail(SMM_ERR_INVALID, "null group");
   if (n_outer < 0 || n_lev < 0 || n_inner < 0) return fail(SMM_ERR_INVALID, "negative batch size");
   if ((x_dtype != SMM_F32 && x_dtype != SMM_F64) || (y_dtype != SMM_F32 && y_dtype != SMM_F64))
@@ -1646,18 +1725,27 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
                       y_direct ? 0 : (size_t)chunk_outer * y_outer));
 
   const int64_t n_chunks = (n_outer + chunk_outer - 1) / chunk_outer;
+  CallStats st;
   auto drain = [&](int64_t c) -> int {
     const int b = (int)(c & 1);
-    SMM_HIP(hipStreamSynchronize(pipe.stream[b]));
+    {
+      StageTimer t(st.v[SMM_HOST_STAT_WAIT_MS]);
+      SMM_HIP(hipStreamSynchronize(pipe.stream[b]));
+    }
+    st.chunk_done(pipe, b);
     if (!y_direct) {
+      StageTimer t(st.v[SMM_HOST_STAT_COPY_OUT_MS]);
       const int64_t o0 = c * chunk_outer, no = std::min(chunk_outer, n_outer - o0);
       if (transpose) {
-        host_copy((char*)y_host + (size_t)o0 * y_outer, pipe.hy[b], (size_t)no * y_outer);
+        int rc = host_copy((char*)y_host + (size_t)o0 * y_outer, pipe.hy[b], (size_t)no * y_outer);
+        if (rc) return rc;
       } else {  // device chunk is (n_lev, no, n_inner, D); host is (n_lev, n_outer, n_inner, D)
         const size_t blk = (size_t)no * n_inner * D * ysz;
-        for (int64_t l = 0; l < n_lev; ++l)
-          host_copy((char*)y_host + ((size_t)l * n_outer + (size_t)o0) * n_inner * D * ysz,
-                    (char*)pipe.hy[b] + (size_t)l * blk, blk);
+        for (int64_t l = 0; l < n_lev; ++l) {
+          int rc = host_copy((char*)y_host + ((size_t)l * n_outer + (size_t)o0) * n_inner * D * ysz,
+                             (char*)pipe.hy[b] + (size_t)l * blk, blk);
+          if (rc) return rc;
+        }
       }
     }
     return SMM_OK;
@@ -1685,13 +1773,19 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
     if (pack) {
       const int64_t bc = no * n_inner;   // batch entries per level in this chunk: b = (o - o0) * n_inner + i
       size_t off = 0;                    // bytes
-      for (int64_t l = 0; l < n_lev; ++l) {
-        smm_operator* op = g->ops[(size_t)level_index[l]];
-        host_pack((char*)pipe.hx[b] + off, xsrc + (size_t)l * n_inner * S * xsz, xsz, n_inner, rows_per_outer * S, S,
-                  op->h_used, bc);
-        off += (size_t)op->csr.n_used_src * bc * xsz;
+      {
+        StageTimer t(st.v[SMM_HOST_STAT_STAGE_IN_MS]);
+        for (int64_t l = 0; l < n_lev; ++l) {
+          smm_operator* op = g->ops[(size_t)level_index[l]];
+          int hrc = host_pack((char*)pipe.hx[b] + off, xsrc + (size_t)l * n_inner * S * xsz, xsz, n_inner,
+                              rows_per_outer * S, S, op->h_used, bc);
+          if (hrc) return hrc;
+          off += (size_t)op->csr.n_used_src * bc * xsz;
+        }
       }
+      SMM_HIP(hipEventRecord(pipe.ev[b][0], pipe.stream[b]));
       SMM_HIP(hipMemcpyAsync(pipe.dx[b], pipe.hx[b], off, hipMemcpyHostToDevice, pipe.stream[b]));
+      SMM_HIP(hipEventRecord(pipe.ev[b][1], pipe.stream[b]));
       off = 0;
       for (int64_t l = 0; l < n_lev && !rc; ++l) {
         const int w = level_index[l];
@@ -1706,16 +1800,21 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
     } else {
       const void* h2d_src = xsrc;
       if (!x_direct) {
-        host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
+        StageTimer t(st.v[SMM_HOST_STAT_STAGE_IN_MS]);
+        int hrc = host_copy(pipe.hx[b], xsrc, (size_t)rows * S * xsz);
+        if (hrc) return hrc;
         h2d_src = pipe.hx[b];
       }
+      SMM_HIP(hipEventRecord(pipe.ev[b][0], pipe.stream[b]));
       SMM_HIP(hipMemcpy2DAsync(pipe.dx[b], xrow_d, h2d_src, (size_t)S * xsz, (size_t)S * xsz, (size_t)rows,
                                hipMemcpyHostToDevice, pipe.stream[b]));
+      SMM_HIP(hipEventRecord(pipe.ev[b][1], pipe.stream[b]));
       rc = smm_group_apply(g, pipe.dx[b], x_dtype, rows_per_outer * ldx_d, n_inner * ldx_d, ldx_d,
                            pipe.dy[b], y_dtype, ys_o, ys_l, ys_i, no, n_lev, n_inner, level_index,
                            masked_levels, remap_area_min, flags, pipe.stream[b]);
     }
     if (rc) return rc;
+    SMM_HIP(hipEventRecord(pipe.ev[b][2], pipe.stream[b]));
     if (!y_direct) {
       SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)no * y_outer, hipMemcpyDeviceToHost,
                              pipe.stream[b]));
@@ -1729,6 +1828,7 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
                                (char*)pipe.dy[b] + (size_t)l * blk, blk, hipMemcpyDeviceToHost,
                                pipe.stream[b]));
     }
+    SMM_HIP(hipEventRecord(pipe.ev[b][3], pipe.stream[b]));
   }
   for (int64_t c = std::max<int64_t>(0, n_chunks - 2); c < n_chunks; ++c) {
     int rc = drain(c);
@@ -1739,6 +1839,80 @@ int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y
   const int prc = pipeline();
   if (prc) pipe.quiesce();
   return prc;
+}
+
+}  // extern "C"
+
+// ---- the guarded entry points: whatever an implementation above throws (std::bad_alloc from a plan vector, a
+// std::system_error) becomes a status here -- nothing crosses the extern "C" boundary (include/smmregrid_amd.h)
+extern "C" {
+
+int smm_operator_set_epilogue(smm_operator_t op, const int32_t* dst_imask, const double* dst_frac) {
+  return guarded([&] { return smm_operator_set_epilogue_impl(op, dst_imask, dst_frac); });
+}
+
+int smm_operator_mask_apply(smm_operator_t op, const int32_t* src_imask, int32_t* dst_imask) {
+  return guarded([&] { return smm_operator_mask_apply_impl(op, src_imask, dst_imask); });
+}
+
+int smm_operator_prepare_sb(smm_operator_t op) {
+  return guarded([&] { return smm_operator_prepare_sb_impl(op); });
+}
+
+int smm_operator_used_sources(smm_operator_t op, int32_t* used) {
+  return guarded([&] { return smm_operator_used_sources_impl(op, used); });
+}
+
+int smm_apply(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype, int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags, void* stream) {
+  return guarded([&] { return smm_apply_impl(op, x, x_dtype, ldx, y, y_dtype, ldy, n_batch, remap_area_min, flags, stream); });
+}
+
+int smm_apply_sb(smm_operator_t op, const void* x, int x_dtype, int64_t ldx, void* y, int y_dtype, int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags, void* stream) {
+  return guarded([&] { return smm_apply_sb_impl(op, x, x_dtype, ldx, y, y_dtype, ldy, n_batch, remap_area_min, flags, stream); });
+}
+
+int smm_apply_host(smm_operator_t op, const void* x_host, int x_dtype, int64_t ldx, void* y_host, int y_dtype, int64_t ldy, int64_t n_batch, double remap_area_min, unsigned flags, int64_t chunk_rows) {
+  return guarded([&] { return smm_apply_host_impl(op, x_host, x_dtype, ldx, y_host, y_dtype, ldy, n_batch, remap_area_min, flags, chunk_rows); });
+}
+
+int smm_group_create(const smm_operator_t* ops, int n_ops, smm_group_t* out) {
+  return guarded([&] { return smm_group_create_impl(ops, n_ops, out); });
+}
+
+int smm_group_prepare(smm_group_t g, int64_t n_lev, const int32_t* level_index, const uint8_t* masked_levels) {
+  return guarded([&] { return smm_group_prepare_impl(g, n_lev, level_index, masked_levels); });
+}
+
+int smm_group_apply(smm_group_t g, const void* x, int x_dtype, int64_t xs_outer, int64_t xs_lev, int64_t xs_inner, void* y, int y_dtype, int64_t ys_outer, int64_t ys_lev, int64_t ys_inner, int64_t n_outer, int64_t n_lev, int64_t n_inner, const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min, unsigned flags, void* stream) {
+  return guarded([&] { return smm_group_apply_impl(g, x, x_dtype, xs_outer, xs_lev, xs_inner, y, y_dtype, ys_outer, ys_lev, ys_inner, n_outer, n_lev, n_inner, level_index, masked_levels, remap_area_min, flags, stream); });
+}
+
+int smm_group_prepare_sb(smm_group_t g) {
+  return guarded([&] { return smm_group_prepare_sb_impl(g); });
+}
+
+int smm_group_apply_sb(smm_group_t g, const void* x, int x_dtype, int64_t xs_lev, int64_t ldx, void* y, int y_dtype, int64_t ys_lev, int64_t ys_batch, int64_t n_batch, int64_t n_lev, const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min, unsigned flags, void* stream) {
+  return guarded([&] { return smm_group_apply_sb_impl(g, x, x_dtype, xs_lev, ldx, y, y_dtype, ys_lev, ys_batch, n_batch, n_lev, level_index, masked_levels, remap_area_min, flags, stream); });
+}
+
+int smm_group_apply_host(smm_group_t g, const void* x_host, int x_dtype, void* y_host, int y_dtype, int64_t n_outer, int64_t n_lev, int64_t n_inner, int transpose, const int32_t* level_index, const uint8_t* masked_levels, double remap_area_min, unsigned flags, int64_t chunk_outer) {
+  return guarded([&] { return smm_group_apply_host_impl(g, x_host, x_dtype, y_host, y_dtype, n_outer, n_lev, n_inner, transpose, level_index, masked_levels, remap_area_min, flags, chunk_outer); });
+}
+
+int smm_operator_launch_info(smm_operator_t op, int x_dtype, int64_t n_batch, unsigned flags, int* kernel, int* j_per_block, int* rows_per_step, int* rows_per_block, int64_t* n_blocks, int64_t* lds_bytes, int* big_operator) {
+  return guarded([&] { return smm_operator_launch_info_impl(op, x_dtype, n_batch, flags, kernel, j_per_block, rows_per_step, rows_per_block, n_blocks, lds_bytes, big_operator); });
+}
+
+int smm_group_launch_info(smm_group_t g, int x_dtype, int64_t n_outer, int64_t n_lev, int64_t n_inner, unsigned flags, int* kernel, int* j_per_block, int* rows_per_step, int* rows_per_block, int64_t* n_blocks, int64_t* lds_bytes, int* big_operator) {
+  return guarded([&] { return smm_group_launch_info_impl(g, x_dtype, n_outer, n_lev, n_inner, flags, kernel, j_per_block, rows_per_step, rows_per_block, n_blocks, lds_bytes, big_operator); });
+}
+
+int smm_operator_plan_info(smm_operator_t op, int* kernel_kind, int64_t* lds_bytes, int64_t* staged_src_elems) {
+  return guarded([&] { return smm_operator_plan_info_impl(op, kernel_kind, lds_bytes, staged_src_elems); });
+}
+
+int smm_operator_export_csr(smm_operator_t op, int64_t* rowptr, int32_t* col, double* val) {
+  return guarded([&] { return smm_operator_export_csr_impl(op, rowptr, col, val); });
 }
 
 }  // extern "C"

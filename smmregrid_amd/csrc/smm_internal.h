@@ -39,12 +39,37 @@ struct HostSell {
 // (hardware threads, at most 16, shared between the builders running at that moment, and never more
 // than the work is worth); returns the previous setting.  The results do not depend on the count.
 int set_host_threads(int n);
+int fixed_host_threads();   // the count set by set_host_threads (0 = automatic)
 int host_threads(int64_t work_items, int64_t min_items_per_thread);
+// CPUs this process may really use: the scheduler affinity capped by the cgroup CPU quota (a 16-CPU share of a
+// 256-thread host has affinity 256 and a quota of 16); >= 1, read once.
+int usable_cpus();
 // Test hook of the builders' worker pools (tests/cpp/build_harness.cpp): no_threads = behave as if no thread could
 // be started (every task then runs on the caller); throw_in_task >= 0 = the task body started after that many
 // others throws std::bad_alloc (-1 = off).  Whatever a worker throws is rethrown on the calling thread after
 // every started thread has been joined.
 void debug_builder_faults(bool no_threads, int64_t throw_in_task);
+
+// ---- host side of the host-buffer pipelines (smm_hostpool.cpp).  None of these throws; the int results are
+// 0 = done, 1 = out of memory inside a task, 2 = any other failure inside a task.
+// One persistent worker pool per process: fn(ctx, i) for i in [0, n_tasks), claimed one by one by the calling
+// thread and up to max_threads - 1 workers (started on first need, kept).  A worker that cannot be started
+// costs parallelism only; jobs of concurrent callers take turns.
+int pool_run(int64_t n_tasks, int max_threads, void (*fn)(void*, int64_t), void* ctx) noexcept;
+int pool_workers();        // workers alive in this process (tests)
+int staging_threads();     // threads a staging stage uses: set_host_threads(n) if n > 0, else min(16, usable_cpus())
+// Test hooks of the pool (tests/cpp/build_harness.cpp): no_threads = behave as if no worker could be started;
+// throw_in_task >= 0 = the task body started after that many others throws std::bad_alloc (-1 = off).
+void debug_pool_faults(bool no_threads, int64_t throw_in_task);
+// parallel memcpy (pageable <-> pinned staging): one thread tops out far below PCIe
+int host_copy(void* dst, const void* src, size_t bytes) noexcept;
+// Pack of the host pipelines: out[u * rows + r] = X[entry r][used[u]] -- the used source cells of a chunk of batch
+// entries, batch-fastest, ready for smm_apply_sb (SMM_APPLY_SB_PACKED).  Batch entry r is the source row at
+// x + (r / n_inner) * stride_o + (r % n_inner) * stride_i (elements of xsz bytes): plain row blocks have
+// n_inner >= rows and stride_i = ldx; one level of an (outer, level, inner, S) field has stride_o = n_lev * n_inner * S,
+// stride_i = S.  streaming = write the packed block with non-temporal stores (a staging buffer only the DMA reads).
+int host_pack(void* out, const void* x, size_t xsz, int64_t n_inner, int64_t stride_o, int64_t stride_i,
+              const int32_t* used, int64_t U, int64_t rows, bool streaming) noexcept;
 
 // Returns false and fills err on invalid input.
 bool build_csr(int64_t n_src, int64_t n_dst, int64_t nnz, const int32_t* src1,

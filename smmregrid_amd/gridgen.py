@@ -923,10 +923,10 @@ def sampled_conservative_weights(src, dst, src_mask=None, norm="fracarea", sampl
     uk, inv = np.unique(key, return_inverse=True)                               # chunks may split a pixel's sub-pixels
     cnt = np.bincount(inv, weights=cnt)
     hp_idx, reg_idx = uk // n_reg, uk % n_reg
-    reg_global = abs((reg.lon_b[-1] - reg.lon_b[0]) - 360.0) < 1e-9 and reg.lat_b[0] <= -90.0 + 1e-9 and reg.lat_b[-1] >= 90.0 - 1e-9
-    if not hp_is_dst and reg_global:
-        # a lon/lat target cell too small to catch a sub-pixel centre (the last rows before a pole) takes the
-        # pixel that holds its own centre
+    if not hp_is_dst:
+        # a lon/lat target cell too small to catch a sub-pixel centre (the last rows before a pole; a fine regional
+        # grid under few `samples`) takes the pixel that holds its own centre -- HEALPix covers the sphere, so the
+        # centre of every cell of a regional grid lies in some pixel too
         empty = np.flatnonzero(np.bincount(reg_idx, minlength=n_reg) == 0)
         if empty.size:
             clon, clat = reg.centers()

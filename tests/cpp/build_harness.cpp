@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -261,6 +262,80 @@ int main(int argc, char** argv) {
     std::string e3;
     if (!smm::build_csr(n_src, n_dst, nnz, src.data(), dst.data(), w.data(), again, e3) || !same_csr(again)) ++fbad;
     printf("FAULTBAD %lld %lld\n", fbad, thrown);
+  }
+  // the host pipelines' staging stages on the persistent pool (smm_hostpool.cpp): the pack gives the same block with
+  // 1, 3 and 16 threads, plain and non-temporal stores, rows that do not fill a 16-row block; a worker that cannot
+  // be started costs parallelism only; a task that throws comes back as a status (1 = bad_alloc) -- never
+  // std::terminate -- and the pool is usable afterwards
+  {
+    long long qbad = 0, statuses = 0;
+    const int64_t S = 5003, rows = 83, n_inner = 5, stride_i = S, stride_o = 2 * n_inner * S;   // a level of an (o, 2, 5, S) field
+    const int64_t n_o = (rows + n_inner - 1) / n_inner;
+    std::vector<double> x((size_t)(n_o * stride_o));
+    for (size_t i = 0; i < x.size(); ++i) x[i] = 0.5 * (double)i;
+    std::vector<int32_t> used;
+    for (int32_t c = 3; c < S; c += 1 + (c % 7)) used.push_back(c);
+    const int64_t U = (int64_t)used.size();
+    auto entry = [&](int64_t r, int32_t c) { return x[(size_t)((r / n_inner) * stride_o + (r % n_inner) * stride_i + c)]; };
+    auto check = [&](const std::vector<double>& out) {
+      long long b2 = 0;
+      for (int64_t u = 0; u < U; ++u)
+        for (int64_t r = 0; r < rows; ++r) b2 += out[(size_t)(u * rows + r)] != entry(r, used[(size_t)u]);
+      return b2;
+    };
+    for (int threads : {1, 3, 16})
+      for (int streaming = 0; streaming < 2; ++streaming) {
+        smm::set_host_threads(threads);
+        std::vector<double> out((size_t)(U * rows), -1.0);
+        if (smm::host_pack(out.data(), x.data(), 8, n_inner, stride_o, stride_i, used.data(), U, rows, streaming != 0)) ++qbad;
+        qbad += check(out);
+      }
+    // f32, rows a multiple of 16 so that the streaming path is taken for every block
+    {
+      std::vector<float> xf(x.begin(), x.end()), outf((size_t)(U * 96), -1.f);
+      std::vector<float> xrows((size_t)(96 * S));
+      for (size_t i = 0; i < xrows.size(); ++i) xrows[i] = (float)(i % 100003);
+      smm::set_host_threads(4);
+      if (smm::host_pack(outf.data(), xrows.data(), 4, 96, 0, S, used.data(), U, 96, true)) ++qbad;
+      for (int64_t u = 0; u < U; ++u)
+        for (int64_t r = 0; r < 96; ++r) qbad += outf[(size_t)(u * 96 + r)] != xrows[(size_t)(r * S + used[(size_t)u])];
+    }
+    // big enough for the pool to be used: 1500 x 5003 doubles packed (> 4 MiB), and a 64-MiB copy
+    const int64_t big_rows = 1504;
+    std::vector<double> xb((size_t)(big_rows * S));
+    for (size_t i = 0; i < xb.size(); ++i) xb[i] = (double)(i % 1000003);
+    std::vector<double> outb((size_t)(U * big_rows));
+    auto pack_big = [&]() { return smm::host_pack(outb.data(), xb.data(), 8, big_rows, 0, S, used.data(), U, big_rows, true); };
+    auto big_ok = [&]() {
+      long long b2 = 0;
+      for (int64_t u = 0; u < U; u += 17)
+        for (int64_t r = 0; r < big_rows; r += 5) b2 += outb[(size_t)(u * big_rows + r)] != xb[(size_t)(r * S + used[(size_t)u])];
+      return b2;
+    };
+    smm::set_host_threads(6);
+    if (pack_big() || big_ok()) ++qbad;
+    const int workers_after_first = smm::pool_workers();
+    if (pack_big() || smm::pool_workers() != workers_after_first) ++qbad;       // persistent: no new threads per call
+    std::vector<char> ca((size_t)64 << 20), cb((size_t)64 << 20, 0);
+    for (size_t i = 0; i < ca.size(); i += 4099) ca[i] = (char)(i * 31);
+    if (smm::host_copy(cb.data(), ca.data(), ca.size()) || memcmp(ca.data(), cb.data(), ca.size()) != 0) ++qbad;
+    // no worker can be started: the caller does everything, same block
+    smm::debug_pool_faults(true, -1);
+    std::fill(outb.begin(), outb.end(), -1.0);
+    if (pack_big() || big_ok()) ++qbad;
+    // a task throws: status 1, no terminate, with and without workers; then a clean run
+    for (int no_threads = 0; no_threads < 2; ++no_threads)
+      for (int64_t at = 0; at < 12; ++at) {
+        smm::debug_pool_faults(no_threads != 0, at);
+        const int rc = pack_big();
+        if (rc == 1) ++statuses;
+        else if (rc != 0) ++qbad;
+      }
+    smm::debug_pool_faults(false, -1);
+    std::fill(outb.begin(), outb.end(), -1.0);
+    if (pack_big() || big_ok()) ++qbad;
+    smm::set_host_threads(argc > 1 ? atoi(argv[1]) : 0);
+    printf("POOLBAD %lld %lld %d %d\n", qbad, statuses, workers_after_first, smm::usable_cpus());
   }
   printf("SELLBAD %lld\n", bad);
   return 0;

@@ -105,3 +105,13 @@ def max_rel_spread(outputs):
         if ok.any():
             worst = max(worst, float(np.max(np.abs(y[ok] - base[ok]) / denom)))
     return worst
+
+
+def kernel_forms(*tile_knobs, sell_knobs=({"sell_batch_rows": 8}, {"sell_batch_rows": 2})):
+    """(apply flags, tuning knobs) pairs a parity loop walks: the library's own choice, the forced tile kernel plain
+    and under each of `tile_knobs` (dicts of smm_debug_set_tuning knobs), the forced SELL kernel plain and under
+    `sell_knobs`.  ABI v5 moved the launch-shape variants out of the apply flags (unknown flag bits are refused
+    since v6), so every form is reached through `_lib.tuning(**knobs)`."""
+    from smmregrid_amd import _lib
+    t, s = _lib.APPLY_KERNEL_TILE, _lib.APPLY_KERNEL_SELL
+    return [(0, {}), (t, {})] + [(t, dict(k)) for k in tile_knobs] + [(s, {})] + [(s, dict(k)) for k in sell_knobs]

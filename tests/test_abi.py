@@ -56,7 +56,7 @@ def test_tuning_knobs_match_the_header_and_are_not_apply_flags():
 
 def test_abi_version_and_error_string():
     lib = _lib.load()
-    assert lib.smm_abi_version() == 5
+    assert lib.smm_abi_version() == 6
     assert isinstance(lib.smm_last_error(), (bytes, type(None)))
 
 

@@ -1,5 +1,6 @@
-"""The host-side operator builder (csrc/smm_build.cpp) under AddressSanitizer + UBSan on the CPU:
-canonical CSR bit-exact against scipy, SELL-64 and tile-plan invariants, error paths."""
+"""The host-side operator builder (csrc/smm_build.cpp) and the host pipelines' staging pool (csrc/smm_hostpool.cpp)
+under AddressSanitizer + UBSan -- and once under ThreadSanitizer -- on the CPU: canonical CSR bit-exact against
+scipy, SELL-64 and tile-plan invariants, error paths, injected thread-start and task failures."""
 import os
 import subprocess
 
@@ -11,14 +12,15 @@ from tests.helpers import ragged_links, random_links
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "build_harness_asan")
+SOURCES = [os.path.join(ROOT, "tests", "cpp", "build_harness.cpp"),
+           os.path.join(ROOT, "smmregrid_amd", "csrc", "smm_build.cpp"),
+           os.path.join(ROOT, "smmregrid_amd", "csrc", "smm_hostpool.cpp")]
 
 
 @pytest.fixture(scope="module")
 def harness():
-    src = [os.path.join(ROOT, "tests", "cpp", "build_harness.cpp"),
-           os.path.join(ROOT, "smmregrid_amd", "csrc", "smm_build.cpp")]
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=address,undefined",
-                           "-fno-sanitize-recover=all", "-o", EXE] + src)
+                           "-fno-sanitize-recover=all", "-o", EXE] + SOURCES)
     yield EXE
     os.remove(EXE)
 
@@ -100,6 +102,32 @@ def test_builder_under_sanitizers(harness, rng, case, threads):
     assert "CHUNKBAD 0" in lines            # host pipelines size their chunks from X AND Y bytes (U << D)
     prune = [ln.split() for ln in lines if ln.startswith("PRUNEBAD")][0]
     assert prune[1] == "0" and int(prune[2]) == int((val == 0.0).sum())     # exact-zero links dropped, rest intact
+    check_pool_line(lines)
+
+
+def check_pool_line(lines):
+    """POOLBAD <mismatches> <statuses from injected task failures> <workers after the first big pack> <usable cpus>:
+    the staging pool packs the same block whatever the thread count / store kind, an injected bad_alloc in a task
+    comes back as status 1 (both with workers and with thread start refused) and never aborts, the workers
+    persist between calls (at most threads - 1 of them)."""
+    pool = [ln.split() for ln in lines if ln.startswith("POOLBAD")][0]
+    assert pool[1] == "0", pool
+    assert int(pool[2]) >= 2 and 0 <= int(pool[3]) <= 5 and int(pool[4]) >= 1
+
+
+def test_staging_pool_under_thread_sanitizer(rng, tmp_path):
+    """The same harness under -fsanitize=thread: the pool's job hand-over (generation counter, claim counter,
+    completion wait) and the builders' worker pools are race-free."""
+    exe = str(tmp_path / "build_harness_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread", "-fsanitize=thread", "-o", exe] + SOURCES)
+    n_src, n_dst = 900, 300
+    src, dst, w = random_links(rng, n_src, n_dst, 2500)
+    text = f"{n_src} {n_dst} {len(src)}\n" + "".join(f"{int(s)} {int(d)} {float(v)!r}\n" for s, d, v in zip(src, dst, w))
+    out = subprocess.run([exe, "3"], input=text, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "ThreadSanitizer" not in out.stderr
+    check_pool_line(out.stdout.splitlines())
 
 
 def test_builder_rejects_bad_addresses(harness):

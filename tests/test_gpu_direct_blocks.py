@@ -5,7 +5,7 @@ import pytest
 
 from oracle import oracle
 from smmregrid_amd import OperatorGroup, SparseOperator, _lib, gridgen, to_device
-from tests.helpers import assert_same, field
+from tests.helpers import assert_same, field, kernel_forms
 
 pytestmark = pytest.mark.gpu
 
@@ -90,6 +90,6 @@ def test_tightened_budget_demotes_moderately_wide_blocks(hip, rng, dtype):
     csr = op.export_csr()
     x = field(rng, 11, n_src, dtype=dtype, nan_frac=0.01)
     ref = oracle.apply_c(csr, x)
-    t = _lib.APPLY_KERNEL_TILE
-    for fl in (0, t, t | (12 << 16), t | (6 << 16), t | (3 << 20), _lib.APPLY_KERNEL_SELL):
-        assert_same(op.apply(to_device(x), flags=fl).to_host(), ref, exact=True)
+    for fl, knobs in kernel_forms({"tile_rows_per_step": 1}, {"xcd_run": -1}, {"xcd_run": 8}, {"tile_walk": 3}):
+        with _lib.tuning(**knobs):
+            assert_same(op.apply(to_device(x), flags=fl).to_host(), ref, exact=True)

@@ -5,7 +5,7 @@ import pytest
 
 from oracle import oracle
 from smmregrid_amd import OperatorGroup, SparseOperator, _lib, to_device
-from tests.helpers import assert_same, field, ragged_links, random_links
+from tests.helpers import assert_same, field, kernel_forms, ragged_links, random_links
 
 pytestmark = pytest.mark.gpu
 
@@ -104,10 +104,12 @@ def test_fuzz_long_rows(hip, seed):
     x = field(rng, int(rng.integers(1, 30)), n_src, dtype=dtype, nan_frac=0.03, inf_frac=0.005)
     masked = bool(seed % 3)
     ref = oracle.apply_c(csr, x, masked, imask, frac, 0.5)
-    t = _lib.APPLY_KERNEL_TILE
-    kernels = [0, _lib.APPLY_KERNEL_SELL] + ([t, t | (15 << 16), t | (3 << 20)] if op.plan_info()["tile_plan"] else [])
-    for fl in kernels:
-        assert_same(op.apply(to_device(x), masked=masked, remap_area_min=0.5, flags=fl).to_host(), ref, exact=True)
+    forms = kernel_forms({"tile_split_rows": 1}, {"tile_walk": 3}, {"tile_links": 1}, {"tile_x_loads": 2})
+    if not op.plan_info()["tile_plan"]:
+        forms = [f for f in forms if f[0] != _lib.APPLY_KERNEL_TILE]
+    for fl, knobs in forms:
+        with _lib.tuning(**knobs):
+            assert_same(op.apply(to_device(x), masked=masked, remap_area_min=0.5, flags=fl).to_host(), ref, exact=True)
     assert_same(op.apply_host(x, masked=masked, remap_area_min=0.5), ref, exact=True)
 
 

@@ -6,7 +6,7 @@ import pytest
 
 from oracle import oracle
 from smmregrid_amd import OperatorGroup, SparseOperator, _lib, gridgen, to_device
-from tests.helpers import assert_same, field
+from tests.helpers import assert_same, field, kernel_forms
 
 pytestmark = pytest.mark.gpu
 
@@ -30,9 +30,9 @@ def test_part_slice_blocks_match_the_oracle(hip, rng, sgrid, tgrid):
     for dtype in (np.float64, np.float32):
         x = field(rng, 13, op.n_src, dtype=dtype, nan_frac=0.01)
         ref = oracle.apply_c(csr, x, True, imask, frac, 0.5)
-        t = _lib.APPLY_KERNEL_TILE
-        for fl in (0, t, t | (6 << 16), t | (5 << 20), t | (15 << 16), _lib.APPLY_KERNEL_SELL):   # 15: rows not split over lanes
-            assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.5, flags=fl).to_host(), ref, exact=True)
+        for fl, knobs in kernel_forms({"xcd_run": -1}, {"tile_walk": 5}, {"tile_split_rows": 1}, {"tile_links": 1}):
+            with _lib.tuning(**knobs):
+                assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.5, flags=fl).to_host(), ref, exact=True)
     assert_same(op.apply_host(x, masked=True, remap_area_min=0.5), ref, exact=True)
 
 
@@ -82,9 +82,9 @@ def test_split_rows_of_ragged_length(hip, rng, stride, max_len, max_rows):
     for dtype in (np.float64, np.float32):
         x = field(rng, 9, n_src, dtype=dtype, nan_frac=0.02, inf_frac=0.002)
         ref = oracle.apply_c(csr, x, True, imask, frac, 0.4)
-        t = _lib.APPLY_KERNEL_TILE
-        for fl in (0, t, t | (15 << 16), t | (3 << 20), _lib.APPLY_KERNEL_SELL):
-            assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.4, flags=fl).to_host(), ref, exact=True)
+        for fl, knobs in kernel_forms({"tile_split_rows": 1}, {"tile_walk": 3}, {"tile_links": 1}):
+            with _lib.tuning(**knobs):
+                assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.4, flags=fl).to_host(), ref, exact=True)
 
 
 def test_split_kernel_with_direct_blocks(hip, rng):
@@ -113,6 +113,6 @@ def test_split_kernel_with_direct_blocks(hip, rng):
     for dtype in (np.float64, np.float32):
         x = field(rng, 7, n_src, dtype=dtype, nan_frac=0.02)
         ref = oracle.apply_c(csr, x, True, imask, frac, 0.4)
-        t = _lib.APPLY_KERNEL_TILE
-        for fl in (0, t, t | (15 << 16), _lib.APPLY_KERNEL_SELL):
-            assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.4, flags=fl).to_host(), ref, exact=True)
+        for fl, knobs in kernel_forms({"tile_split_rows": 1}, sell_knobs=()):
+            with _lib.tuning(**knobs):
+                assert_same(op.apply(to_device(x), masked=True, remap_area_min=0.4, flags=fl).to_host(), ref, exact=True)

@@ -1,0 +1,121 @@
+"""Round 6: the ABI refuses apply-flag bits it does not define; nothing a staging task throws crosses the C ABI; the
+host pipelines report where their time went; the pack's store kind and the staging thread count do not change a bit."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from smmregrid_amd import OperatorGroup, SparseOperator, _lib, gridgen, pinned_empty, to_device
+from smmregrid_amd.device import DeviceArray
+from tests.helpers import assert_same, field, random_links
+
+pytestmark = pytest.mark.gpu
+
+
+def _bilinear(src="r288x144", dst="r72x36"):
+    w = gridgen.bilinear_weights(src, dst)
+    op = SparseOperator(w.sizes["src_grid_size"], w.sizes["dst_grid_size"], w["src_address"].values,
+                        w["dst_address"].values, w["remap_matrix"].values, device=0)
+    return w, op
+
+
+def test_unknown_apply_flag_bits_are_refused(hip, rng):
+    """ABI v4 encoded kernel variants in bits 16..27 of `flags`; v5 moved them to smm_debug_set_tuning and v6 refuses
+    what is left over, in every entry that takes flags, so that a stale caller fails loudly instead of silently
+    running the default kernel."""
+    w, op = _bilinear()
+    x = field(rng, 40, op.n_src)
+    xd = to_device(x)
+    for bad in (1 << 16, 15 << 16, 3 << 20, 1 << 5, 1 << 31):
+        for call in (lambda: op.apply(xd, flags=bad),
+                     lambda: op.apply(xd, flags=bad | _lib.APPLY_KERNEL_TILE),
+                     lambda: op.apply_sb(to_device(np.ascontiguousarray(x.T)), flags=bad),
+                     lambda: op.apply_host(x, flags=bad),
+                     lambda: op.launch_info(40, flags=bad)):
+            with pytest.raises(_lib.SmmError) as e:
+                call()
+            assert e.value.code == _lib.SMM_ERR_INVALID and "unknown apply flag bits" in str(e.value)
+    grp = OperatorGroup([op])
+    with pytest.raises(_lib.SmmError) as e:
+        grp.apply(to_device(x.reshape(40, 1, 1, -1)), [0], flags=1 << 16)
+    assert e.value.code == _lib.SMM_ERR_INVALID
+    with pytest.raises(_lib.SmmError):
+        grp.apply_host(x.reshape(40, 1, 1, -1), [0], flags=1 << 20)
+    # every defined bit is still accepted
+    ok = op.apply(xd, flags=_lib.APPLY_KERNEL_SELL | _lib.APPLY_NO_FILL).to_host()
+    assert_same(ok, oracle.apply_c(op.export_csr(), x), exact=True)
+    grp.close()
+
+
+@pytest.mark.parametrize("mode", ["packed", "whole_rows"])
+def test_staging_task_failure_returns_a_status_and_drains(hip, rng, mode):
+    """A std::bad_alloc thrown inside a staging task (pack / copy-in on the pool's threads) comes back from
+    smm_apply_host as SMM_ERR_ALLOC -- no std::terminate inside extern "C" -- after the copies in flight into the
+    caller's Y have landed; with thread start refused the calling thread stages alone and the bits are the same; the
+    pipeline is usable afterwards."""
+    w, op = _bilinear("r1440x720", "r360x180")       # U = S / 4: the packing variant applies; 8.3 MB per row
+    S, D = op.n_src, op.n_dst
+    B, chunk = 192, 32
+    x = field(rng, B, S)
+    ref = oracle.apply_c(op.export_csr(), x)
+    fl = 0 if mode == "packed" else _lib.APPLY_HOST_NO_PACK
+    assert_same(op.apply_host(x, flags=fl, chunk_rows=chunk), ref, exact=True)
+    try:
+        _lib.call("smm_debug_staging_faults", 1, -1)                 # no worker thread can be started
+        assert_same(op.apply_host(x, flags=fl, chunk_rows=chunk), ref, exact=True)
+        codes = []
+        for no_threads in (0, 1):
+            for at in (0, 3, 40):
+                out = np.full((B, D), -1.0)
+                _lib.call("smm_debug_staging_faults", no_threads, at)
+                try:
+                    op.apply_host(x, out=out, flags=fl, chunk_rows=chunk)
+                    codes.append(0)                                    # the counter ran past every task of this call
+                    assert_same(out, ref, exact=True)
+                except _lib.SmmError as e:
+                    codes.append(e.code)
+                    assert e.code == _lib.SMM_ERR_ALLOC and "staging task" in str(e)
+                    rows = out[:, 0] != -1.0                           # delivered chunks are complete and right
+                    assert_same(out[rows], ref[rows], exact=True)
+        assert _lib.SMM_ERR_ALLOC in codes
+    finally:
+        _lib.call("smm_debug_staging_faults", 0, -1)
+    assert_same(op.apply_host(x, flags=fl, chunk_rows=chunk), ref, exact=True)
+
+
+def test_host_pipeline_stats_and_store_kinds(hip, rng):
+    """smm_debug_host_stats: one call = one `calls`, its chunks, wall time >= every host-side stage, event times of H2D /
+    kernel / D2H present; pinned input and output have no copy stages.  The pack gives the same bits with non-temporal
+    and plain stores, 1 and 8 staging threads."""
+    w, op = _bilinear("r1440x720", "r360x180")
+    S, D = op.n_src, op.n_dst
+    B = 256
+    x = field(rng, B, S)
+    ref = oracle.apply_c(op.export_csr(), x)
+    op.apply_host(x)                                                   # warm-up: staging buffers
+    _lib.host_stats(reset=True)
+    y = op.apply_host(x, chunk_rows=64)
+    st = _lib.host_stats(reset=True)
+    assert_same(y, ref, exact=True)
+    assert st["calls"] == 1 and st["chunks"] == 4 and st["threads"] >= 1
+    assert st["stage_in_ms"] > 0 and st["copy_out_ms"] > 0 and st["h2d_ms"] > 0 and st["kernel_ms"] > 0 and st["d2h_ms"] > 0
+    assert st["total_ms"] >= max(st["stage_in_ms"], st["copy_out_ms"], st["wait_ms"]) * 0.999
+    assert _lib.host_stats()["calls"] == 0                              # reset
+    xp, yp = pinned_empty((B, S), np.float64), pinned_empty((B, D), np.float64)
+    xp[...] = x
+    op.apply_host(xp, out=yp, flags=_lib.APPLY_HOST_NO_PACK, chunk_rows=64)
+    st = _lib.host_stats(reset=True)
+    assert_same(np.array(yp), ref, exact=True)
+    assert st["stage_in_ms"] == 0 and st["copy_out_ms"] == 0 and st["h2d_ms"] > 0 and st["chunks"] == 4
+    prev = ctypes.c_int(0)
+    for threads in (1, 8):
+        _lib.call("smm_set_host_threads", threads, ctypes.byref(prev))
+        try:
+            for stores in (0, 1):
+                with _lib.tuning(host_pack_stores=stores):
+                    assert_same(op.apply_host(x, chunk_rows=96), ref, exact=True)      # 96 + 96 + 64 rows
+                    assert_same(op.apply_host(x[:37]), ref[:37], exact=True)           # a short, odd chunk
+        finally:
+            _lib.call("smm_set_host_threads", prev.value, None)
+    assert _lib.host_stats()["threads"] in (1.0, 8.0)

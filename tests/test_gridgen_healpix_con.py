@@ -441,6 +441,27 @@ def test_regional_lonlat_grid_and_healpix_conservative():
     assert field.min() - 1e-9 <= y.min() and y.max() <= field.max() + 1e-9
 
 
+def test_fine_regional_target_under_few_samples_has_no_holes():
+    """cells of a fine REGIONAL lon/lat target that catch no sub-pixel centre (few `samples`) take the
+    pixel holding their own centre, as cells of a global target do: no NaN holes inside the covered area."""
+    lon, lat = np.arange(10.05, 14.0, 0.1), np.arange(40.05, 43.0, 0.1)     # 0.1-degree cells under 7-degree pixels
+    reg = gridgen.regular_grid_from_centers(lon, lat)
+    w = gridgen.sampled_conservative_weights("hp8", reg, samples=16)        # 16 sub-pixels per pixel: ~1.8 degrees each
+    per_cell = np.bincount(w["dst_address"].values - 1, minlength=reg.size)
+    assert per_cell.min() >= 1 and (w["dst_grid_frac"].values > 0).all()
+    rows = np.bincount(w["dst_address"].values - 1, weights=w["remap_matrix"].values[:, 0], minlength=reg.size)
+    assert np.allclose(rows, 1.0)
+    # the pixel a hole-filling link names is the one that holds the cell's centre
+    clon, clat = reg.centers()
+    nlon, nlat = gridgen.healpix_centers(8, nested=True)
+    ring2nest = np.argsort(gridgen.healpix_ring_index(8, nlon, nlat))
+    holder = ring2nest[gridgen.healpix_ring_index(8, clon, clat)]
+    single = np.flatnonzero(per_cell == 1)
+    order = np.argsort(w["dst_address"].values, kind="stable")
+    first_link = order[np.searchsorted(w["dst_address"].values[order], single + 1)]
+    assert np.array_equal(w["src_address"].values[first_link] - 1, holder[single])
+
+
 def test_curvilinear_centres_feed_nn_and_dis():
     """A NEMO-style field (2-D nav_lon / nav_lat on (y, x); the reference's so3d-nemo.nc / onlytos-ipsl.nc layout):
     the native generator takes the cell centres in storage order for `nn` and `dis`, reports (nx, ny) as

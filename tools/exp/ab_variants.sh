@@ -7,7 +7,7 @@ rm -rf $out; mkdir -p $out
 for rep in 1 2 3; do
   for v in $vars; do
     t=""; [ "$v" != 0 ] && t="--tune $v"
-    python bench.py --workload $wl $t --steps 20 --warmup 5 --no-cpu-baseline --others none --configs none "$@" > $out/v${v}_$rep.json 2> $out/v${v}_$rep.err
+    python bench.py --workload $wl $t --steps 20 --warmup 5 --no-cpu-baseline --others none --configs none --user-path none "$@" > $out/v${v}_$rep.json 2> $out/v${v}_$rep.err
   done
 done
 python - <<PY

@@ -165,16 +165,26 @@ int main(int argc, char** argv) {
   // placement sweep (argv[14] = largest offset in bytes): ONE allocation holds both buffers, the write buffer starts at
   // (end of the read buffer) + delta for a list of deltas -- does the rate follow the relative placement of the two streams?
   const uint64_t sweep = argc > 14 ? (uint64_t)atoll(argv[14]) : 0;
-  char *src = nullptr, *dst = nullptr;
+  char *src = nullptr, *dst = nullptr, *dst_base = nullptr;
   if (sweep) {
     CHECK(hipMalloc((void**)&src, src_bytes + dst_bytes + sweep + 4096));
     CHECK(hipMemset(src, 1, src_bytes + dst_bytes + sweep + 4096));
     dst = src + src_bytes;
   } else {
+    // placement study (round 6): argv[15] = bytes by which the write buffer's base is moved inside its own over-sized
+    // allocation (the library can do that for buffers it owns), argv[16] = bytes of a dummy allocation made BEFORE the two
+    // buffers (moves where hipMalloc puts them).  The line printed below carries both base pointers, their difference modulo
+    // 2 MiB / 64 MiB / 1 GiB and the allocation ranges, so that a fast placement can be told from a slow one.
+    const uint64_t dst_off = argc > 15 ? (uint64_t)atoll(argv[15]) : 0;
+    const uint64_t pre = argc > 16 ? (uint64_t)atoll(argv[16]) : 0;
+    char* dummy = nullptr;
+    if (pre) CHECK(hipMalloc((void**)&dummy, pre));
     CHECK(hipMalloc((void**)&src, src_bytes));
-    CHECK(hipMalloc((void**)&dst, dst_bytes));
+    CHECK(hipMalloc((void**)&dst, dst_bytes + dst_off));
     CHECK(hipMemset(src, 1, src_bytes));
-    CHECK(hipMemset(dst, 0, dst_bytes));
+    CHECK(hipMemset(dst, 0, dst_bytes + dst_off));
+    dst_base = dst;
+    dst += dst_off;
   }
   a.src = src;
   a.dst = dst;
@@ -218,6 +228,56 @@ int main(int argc, char** argv) {
     CHECK(hipFree(src));
     return 0;
   }
+  // placement study, second question (argv[17] = pairs): is the rate a property of the PROCESS or of the ALLOCATION?
+  // The first pair of buffers is kept and measured again after every further pair (allocated while all earlier ones
+  // are still held, so that each lands in other physical memory) has been measured.
+  const int more_pairs = argc > 17 ? atoi(argv[17]) : 0;
+  if (more_pairs > 0) {
+    const double bytes = (double)a.n_units * a.read_unit + (double)a.n_units * a.write_unit;
+    auto measure = [&](const char* s0, char* d0, float* per_rep) -> double {
+      a.src = s0;
+      a.dst = d0;
+      launch();
+      (void)hipDeviceSynchronize();
+      float sum3 = 0.f;
+      for (int r = 0; r < reps; ++r) {
+        (void)hipEventRecord(e0, nullptr);
+        launch();
+        (void)hipEventRecord(e1, nullptr);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (per_rep) per_rep[r] = (float)(bytes / ms / 1e6);
+        sum3 += ms;
+      }
+      return bytes / (sum3 / reps) / 1e6;
+    };
+    std::vector<float> per((size_t)reps);
+    printf("pair 0 (src %p dst %p): %.0f GB/s  reps:", (void*)src, (void*)dst, measure(src, dst, per.data()));
+    for (float v : per) printf(" %.0f", v);
+    printf("\n");
+    std::vector<char*> held;
+    for (int k = 1; k <= more_pairs; ++k) {
+      char *s2 = nullptr, *d2 = nullptr;
+      if (hipMalloc((void**)&s2, src_bytes) != hipSuccess || hipMalloc((void**)&d2, dst_bytes) != hipSuccess) {
+        printf("pair %d: out of device memory\n", k);
+        break;
+      }
+      (void)hipMemset(s2, 1, src_bytes);
+      (void)hipMemset(d2, 0, dst_bytes);
+      held.push_back(s2);
+      held.push_back(d2);
+      const double r2 = measure(s2, d2, nullptr);
+      const double r0 = measure(src, dst, nullptr);
+      // crossed: reads from the new pair's source, writes into the first pair's destination, and the other way round
+      const double rx = measure(s2, dst, nullptr), ry = measure(src, d2, nullptr);
+      printf("pair %d (src %p dst %p): %.0f GB/s   pair 0 again: %.0f   src%d->dst0: %.0f   src0->dst%d: %.0f\n", k, (void*)s2, (void*)d2, r2, r0, k, rx, k, ry);
+    }
+    for (char* h : held) (void)hipFree(h);
+    CHECK(hipFree(src));
+    CHECK(hipFree(dst_base));
+    return 0;
+  }
   float best = 1e30f, sum = 0.f;
   for (int r = 0; r < reps; ++r) {
     CHECK(hipEventRecord(e0, nullptr));
@@ -236,7 +296,21 @@ int main(int argc, char** argv) {
          a.read_run, a.read_unit, a.write_seg, a.write_unit, (unsigned long long)a.write_stride,
          (unsigned long long)a.read_pitch, a.rows_per_tile, (unsigned long long)a.slab_pitch, a.exact_rounds, a.barrier, (unsigned long long)a.n_units, wg_per_cu, sum / reps, best, rb / (sum / reps) / 1e6, wb / (sum / reps) / 1e6,
          (rb + wb) / (sum / reps) / 1e6, wb / (rb + wb + 1e-30));
+  {
+    void *sb = nullptr, *db = nullptr;
+    size_t ss = 0, ds = 0;
+    (void)hipMemGetAddressRange((hipDeviceptr_t*)&sb, &ss, (hipDeviceptr_t)src);
+    (void)hipMemGetAddressRange((hipDeviceptr_t*)&db, &ds, (hipDeviceptr_t)dst_base);
+    const uint64_t ps = (uint64_t)(uintptr_t)src, pd = (uint64_t)(uintptr_t)dst, diff = pd > ps ? pd - ps : ps - pd;
+    printf("placement {\"total_GBs\": %.1f, \"src\": \"0x%llx\", \"dst\": \"0x%llx\", \"dst_above_src\": %d, \"diff_mod_2M\": %llu, "
+           "\"diff_mod_64M\": %llu, \"diff_mod_1G\": %llu, \"src_mod_1G\": %llu, \"dst_mod_1G\": %llu, \"src_mod_2M\": %llu, \"dst_mod_2M\": %llu, "
+           "\"src_range\": [\"0x%llx\", %zu], \"dst_range\": [\"0x%llx\", %zu]}\n",
+           (rb + wb) / (sum / reps) / 1e6, (unsigned long long)ps, (unsigned long long)pd, (int)(pd > ps),
+           (unsigned long long)(diff % (2ull << 20)), (unsigned long long)(diff % (64ull << 20)), (unsigned long long)(diff % (1ull << 30)),
+           (unsigned long long)(ps % (1ull << 30)), (unsigned long long)(pd % (1ull << 30)), (unsigned long long)(ps % (2ull << 20)),
+           (unsigned long long)(pd % (2ull << 20)), (unsigned long long)(uintptr_t)sb, ss, (unsigned long long)(uintptr_t)db, ds);
+  }
   CHECK(hipFree(src));
-  CHECK(hipFree(dst));
+  CHECK(hipFree(dst_base));
   return 0;
 }

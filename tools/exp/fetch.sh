@@ -5,7 +5,7 @@ root=$PWD
 for v in $2; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pf_$v_$c
-    (cd /tmp && rocprofv3 --pmc $c --output-format csv -d /tmp/pf_${v}_$c -- python3 $root/bench.py --workload $1 --steps 3 --warmup 1 --no-cpu-baseline --others none --configs none $( [ "$v" != 0 ] && echo --tune $v ) $3 > /dev/null 2>&1)
+    (cd /tmp && rocprofv3 --pmc $c --output-format csv -d /tmp/pf_${v}_$c -- python3 $root/bench.py --workload $1 --steps 3 --warmup 1 --no-cpu-baseline --others none --configs none --user-path none $( [ "$v" != 0 ] && echo --tune $v ) $3 > /dev/null 2>&1)
     python3 - $v $c <<'PY'
 import csv,glob,sys,collections
 v,c=sys.argv[1:3]

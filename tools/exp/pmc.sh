@@ -8,7 +8,7 @@ i=0
 for set in "$@"; do
   i=$((i+1))
   rm -rf /tmp/pm_$i
-  (cd /tmp && rocprofv3 --pmc $set --output-format csv -d /tmp/pm_$i -- python3 $root/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --others none --configs none $SMM_BENCH_ARGS > /dev/null 2>&1) || { echo "set '$set' failed"; continue; }
+  (cd /tmp && rocprofv3 --pmc $set --output-format csv -d /tmp/pm_$i -- python3 $root/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --others none --configs none --user-path none $SMM_BENCH_ARGS > /dev/null 2>&1) || { echo "set '$set' failed"; continue; }
   python3 - $i <<'PY'
 import csv,glob,sys,collections
 i=sys.argv[1]

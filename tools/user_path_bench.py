@@ -47,18 +47,79 @@ def _median_ms(fn, reps, budget_s=None):
 
 # ------------------------------------------------------------------------------------------ host to host
 
-def host_to_host(device=0, rows=512, cpu_cells_per_s=None):
-    """smm_apply_host on config-2 rows held in host memory; returns the compact block of the bench line."""
+def _ceilings(rows_bytes=512 << 20):
+    """The two rates the host pipeline cannot beat, measured in the same run: pinned hipMemcpy H2D / D2H / both
+    directions at once (GB/s per direction), and the library's own multi-threaded host -> host copy into pinned
+    memory (GB/s of bytes copied; the memory system moves at least twice that: one read, one write)."""
+    import ctypes
+    from smmregrid_amd import _lib, pinned_empty
+    from smmregrid_amd.device import DeviceArray, Stream, synchronize
+    n = rows_bytes // 8
+    h1, h2 = pinned_empty((n,), np.float64), pinned_empty((n,), np.float64)
+    h1[...] = 1.0
+    h2[...] = 2.0
+    d1, d2 = DeviceArray((n,), np.float64), DeviceArray((n,), np.float64)
+    s1, s2 = Stream(), Stream()
+
+    def h2d():
+        d1.copy_from_host(h1, stream=s1)
+        s1.synchronize()
+
+    def d2h():
+        d2.to_host(out=h2, stream=s2)
+
+    def both():
+        d1.copy_from_host(h1, stream=s1)
+        _lib.call("smm_memcpy_d2h", h2.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d2.ptr), d2.nbytes, s2.handle)
+        s1.synchronize()
+        s2.synchronize()
+
+    out = {}
+    for name, fn in (("h2d", h2d), ("d2h", d2h), ("both", both)):
+        fn()
+        _, ms_min, _ = _median_ms(fn, 5)
+        out[f"pcie_{name}_GBs"] = rows_bytes / (ms_min * 1e-3) / 1e9
+    synchronize()
+    page = np.full(n, 3.0)
+
+    def hcopy():
+        _lib.call("smm_host_memcpy", h1.ctypes.data_as(ctypes.c_void_p), page.ctypes.data_as(ctypes.c_void_p), page.nbytes)
+
+    hcopy()
+    _, ms_min, _ = _median_ms(hcopy, 7)
+    out["host_copy_GBs"] = rows_bytes / (ms_min * 1e-3) / 1e9
+    d1.free()
+    d2.free()
+    return out
+
+
+def host_to_host(device=0, rows=512, cpu_cells_per_s=None, reps=9):
+    """smm_apply_host on config-2 rows held in host memory; returns the compact block of the bench line: per mode the
+    median and best of `reps` calls, where the time went (smm_debug_host_stats: pack / copy-in, H2D, kernel, D2H,
+    copy-out, wait), and the fraction of the two measured ceilings -- PCIe and host memory -- the mode runs at."""
     from smmregrid_amd import SparseOperator, _lib, gridgen, pinned_empty
     w = gridgen.bilinear_weights("r1440x721", "r360x180")
     S, D = w.sizes["src_grid_size"], w.sizes["dst_grid_size"]
     op = SparseOperator(S, D, w["src_address"].values, w["dst_address"].values, w["remap_matrix"].values, device=device)
     op.set_epilogue(w["dst_grid_imask"].values, w["dst_grid_frac"].values)
     U = op.n_used_src
+    used_lines = int(np.unique(op.used_sources() // 8).size)          # 64-B lines of a source row the pack reads
     rng = np.random.default_rng(20260723)
     row = 250.0 + 30.0 * rng.standard_normal(S)
-    out = {"workload": f"cfg2 rows in host memory, {rows} x {S} f64 -> {rows} x {D} f64", "rows": int(rows),
-           "pcie_bytes_per_row": {"packed": int((U + D) * 8), "whole_rows": int((S + D) * 8)}}
+    ceil = _ceilings()
+    out = {"workload": f"cfg2 rows in host memory, {rows} x {S} f64 -> {rows} x {D} f64", "rows": int(rows), "reps": int(reps),
+           "pcie_bytes_per_row": {"packed": int((U + D) * 8), "whole_rows": int((S + D) * 8)},
+           "ceilings": {k: round(v, 1) for k, v in ceil.items()}, "staging_threads": None}
+    # host-memory bytes one row costs (reads + writes that reach DRAM; a plain store into a line not in cache reads it
+    # first, a non-temporal one does not): pack = touched source lines + the packed block, the DMA engine's read of the
+    # staging block and write of Y, and -- for pageable buffers -- the copies between the caller's arrays and staging
+    nt = 1
+    host_bytes = {
+        ("pageable", "packed"): used_lines * 64 + U * 8 * nt + U * 8 + D * 8 + 3 * D * 8,
+        ("pinned", "packed"): used_lines * 64 + U * 8 * nt + U * 8 + D * 8,
+        ("pageable", "whole_rows"): 3 * S * 8 + S * 8 + D * 8 + 3 * D * 8,
+        ("pinned", "whole_rows"): S * 8 + D * 8,
+    }
     first = None
     for kind in ("pageable", "pinned"):
         alloc = (lambda s, d: np.empty(s, d)) if kind == "pageable" else pinned_empty
@@ -68,13 +129,24 @@ def host_to_host(device=0, rows=512, cpu_cells_per_s=None):
         y = alloc((rows, D), np.float64)
         for mode, fl in (("packed", 0), ("whole_rows", _lib.APPLY_HOST_NO_PACK)):
             op.apply_host(x, out=y, remap_area_min=0.5, flags=fl)           # warm-up: staging buffers, page faults
-            ms, ms_min, n = _median_ms(lambda: op.apply_host(x, out=y, remap_area_min=0.5, flags=fl), 3)
-            out[f"{kind}_{mode}"] = {"cells_per_s": rows * D / (ms * 1e-3), "host_GBs": (x.nbytes + y.nbytes) / (ms * 1e-3) / 1e9,
-                                     "ms": ms}
+            _lib.host_stats(reset=True)
+            ms, ms_min, n = _median_ms(lambda: op.apply_host(x, out=y, remap_area_min=0.5, flags=fl), reps)
+            st = _lib.host_stats(reset=True)
+            calls = max(st["calls"], 1.0)
+            e = {"cells_per_s": rows * D / (ms * 1e-3), "cells_per_s_best": rows * D / (ms_min * 1e-3), "ms": ms, "ms_min": ms_min,
+                 "calls": n, "host_GBs": (x.nbytes + y.nbytes) / (ms * 1e-3) / 1e9,
+                 "stage_ms": {k[:-3]: round(st[k] / calls, 2) for k in ("stage_in_ms", "h2d_ms", "kernel_ms", "d2h_ms",
+                                                                        "copy_out_ms", "wait_ms", "total_ms")}}
+            # X over PCIe against the one-direction H2D rate (Y, a fifth to a sixteenth of the bytes, travels the other way)
+            x_b = (out["pcie_bytes_per_row"][mode] - D * 8) * rows
+            e["pcie_frac"] = (x_b / (ms * 1e-3) / 1e9) / ceil["pcie_h2d_GBs"]
+            e["host_mem_frac"] = (host_bytes[(kind, mode)] * rows / (ms * 1e-3) / 1e9) / (2.0 * ceil["host_copy_GBs"])
+            out[f"{kind}_{mode}"] = e
+            out["staging_threads"] = int(st["threads"])
             if first is None:
                 first = y[rows // 2].copy(), x[rows // 2].copy()
             else:                                                           # every mode gives the same bits
-                out[f"{kind}_{mode}"]["same_bits"] = bool(np.array_equal(y[rows // 2], first[0], equal_nan=True))
+                e["same_bits"] = bool(np.array_equal(y[rows // 2], first[0], equal_nan=True))
         del x, y
     # one row of the result against the oracle (its own CSR from the links)
     from oracle import oracle
@@ -83,8 +155,18 @@ def host_to_host(device=0, rows=512, cpu_cells_per_s=None):
     out["spot_check"] = bool(np.array_equal(ref, first[0], equal_nan=True))
     if cpu_cells_per_s:
         out["cpu_cells_per_s"] = float(cpu_cells_per_s)      # the same product on the host's cores (cpu_baseline)
+    out["bound"] = _what_bounds(out)
     op.close()
     return out
+
+
+def _what_bounds(out):
+    """One short sentence per mode family from the fractions above (kept under 100 characters for the bench line)."""
+    def worst(e):
+        return "host memory" if e["host_mem_frac"] >= e["pcie_frac"] else "PCIe"
+    p, wr = out["pageable_packed"], out["pinned_whole_rows"]
+    return (f"packed: {worst(p)} ({p['host_mem_frac']:.2f} of host copy rate, {p['pcie_frac']:.2f} of PCIe); "
+            f"pinned whole rows: {worst(wr)} ({wr['pcie_frac']:.2f} of PCIe)")[:99]
 
 
 # ------------------------------------------------------------------------------------------ reference-sized
@@ -204,5 +286,12 @@ def reference_sized(device=0, reps=25, budget_s=40.0, only=None):
 
 
 if __name__ == "__main__":
+    # python tools/user_path_bench.py [rows] [--only-h2h] [knob=value ...]   (knobs: smm_debug_set_tuning names, A/B runs)
     n_rows = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
-    print(json.dumps({"reference_sized": reference_sized(), "host_to_host": host_to_host(rows=n_rows)}))
+    from smmregrid_amd import _lib
+    for kv in [a for a in sys.argv[1:] if "=" in a]:
+        _lib.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
+    res = {"host_to_host": host_to_host(rows=n_rows)}
+    if "--only-h2h" not in sys.argv:
+        res["reference_sized"] = reference_sized()
+    print(json.dumps(res))
