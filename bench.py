@@ -1017,12 +1017,16 @@ def final_line(out, details):
     for k in ("kernel_ms_min_rank", "kernel_ms_max_rank"):
         if k in full and line.get("n_gpus", 1) > 1:
             roof[k] = full[k]
+    checks = [e.pop("spot_check") for blk in nested.values() for e in blk.values() if isinstance(e, dict) and "spot_check" in e]
+    if checks:
+        roof["spot_checks_bit_equal"] = f"{sum(bool(c) for c in checks)} of {len(checks)}"   # every timed output against the oracle
     roof.update(nested)
     if "roofline" in line:
         line["roofline"] = roof
     cpu = line.get("cpu_baseline")
     if cpu:
-        cpu.pop("legs", None)
+        for k in ("legs", "threads", "rows_sampled", "passes", "seconds"):     # `sample` says the same; the legs are in `details`
+            cpu.pop(k, None)
         cpu["sample"] = short(cpu["sample"], 60)
     cfg = line.get("config") or {}
     cfg.pop("plan", None)
@@ -1053,22 +1057,27 @@ def final_line(out, details):
     ref = details.get("reference_sized")
     if ref:
         keys = ("in", "init_ms", "regrid_ms", "cpu_scipy_ms", "cpu_c1_ms", "bit_equal")
-        line["reference_sized"] = {n: ({k: e[k] for k in keys if k in e} if "regrid_ms" in e else
-                                       {"error": short(e.get("error") or e.get("skipped"), 60)}) for n, e in ref.items()}
-        line["reference_sized"]["unit"] = "ms per regrid() host->host; cpu: 1-core oracle"
+        line["reference_sized"] = {"cols": "shape, init ms, regrid() ms host->host, 1-core scipy ms, 1-core C ms, bit_equal"}
+        for n, e in ref.items():
+            line["reference_sized"][n] = ([e.get(k) for k in keys] if "regrid_ms" in e else
+                                          {"error": short(e.get("error") or e.get("skipped"), 60)})
     h2h = details.get("host_to_host")
     if h2h:
         # per mode: median and best cells/s of `reps` calls, the fraction of the measured PCIe (H2D) and host-memory
         # (2 x the staging pool's copy rate) ceilings it runs at, and the stage split of one call in ms
         blk = {"rows": h2h.get("rows"), "reps": h2h.get("reps"),
-               "unit": "cells/s; st = ms/call: stage-in, h2d, kernel, d2h, copy-out, wait, total", "ceil_GBs": h2h.get("ceilings")}
+               "cols": "Mcells/s median, best; frac of PCIe h2d, of host-mem ceiling; ms/call: in, h2d, kern, d2h, out, wait, total"}
+        ceil = h2h.get("ceilings") or {}
+        blk["ceil_GBs"] = {k.replace("pcie_", "").replace("_GBs", ""): v for k, v in ceil.items()}
         for k, e in h2h.items():
             if isinstance(e, dict) and "cells_per_s" in e:
                 st = e.get("stage_ms") or {}
-                blk[k] = {"v": float(f"{e['cells_per_s']:.4g}"), "best": float(f"{e.get('cells_per_s_best', 0):.4g}"),
-                          "pcie": round(e.get("pcie_frac", 0), 2), "mem": round(e.get("host_mem_frac", 0), 2),
-                          "st": [round(st.get(n, 0), 1) for n in ("stage_in", "h2d", "kernel", "d2h", "copy_out", "wait", "total")]}
-        for k in ("staging_threads", "cpu_cells_per_s", "spot_check", "bound", "error"):
+                blk[k] = [round(e["cells_per_s"] / 1e6), round(e.get("cells_per_s_best", 0) / 1e6),
+                          round(e.get("pcie_frac", 0), 2), round(e.get("host_mem_frac", 0), 2)] + \
+                         [round(st.get(n, 0), 1) for n in ("stage_in", "h2d", "kernel", "d2h", "copy_out", "wait", "total")]
+        if h2h.get("cpu_cells_per_s"):
+            blk["cpu_Mcells_per_s"] = round(h2h["cpu_cells_per_s"] / 1e6)
+        for k in ("staging_threads", "spot_check", "bound", "error"):
             if k in h2h:
                 blk[k] = h2h[k]
         line["host_to_host"] = blk

@@ -380,7 +380,6 @@ enum {
   SMM_TUNE_SB_LOADS,            /* batch-fastest kernel: loads per batch of the link walk (4, 8)               */
   SMM_TUNE_SB_LEVEL_LAUNCHES,   /* smm_group_apply_sb: 1 = one launch per data level instead of one grouped launch */
   SMM_TUNE_SB_LDS_PAD,          /* batch-fastest kernels: extra LDS bytes per wave, capping the waves per CU    */
-  SMM_TUNE_SB_PAIR_TILES,       /* batch-fastest kernels: tiles per band of two destination-grid rows whose tiles are interleaved (0 = off) */
   SMM_TUNE_HOST_PACK_STORES,    /* host pipelines: 1 = the pack writes its staging block with plain (not non-temporal) stores */
   SMM_TUNE_COUNT
 };

@@ -76,7 +76,6 @@ struct SbArgs {
   int masked;
   int xcd_remap;
   int b_fastest;           // > 0: width (destination tiles) of the strips the tiles are ordered in
-  int pair_tiles;          // > 0: destination tiles per band of two destination-grid rows (tiles of row j and j + 1 interleaved)
 };
 
 // Arguments of the batch-fastest kernel over a whole level group in ONE launch (smm_group_apply_sb).  The levels'
@@ -103,7 +102,6 @@ struct SbGroupArgs {
   double area_min;
   int xcd_remap, b_fastest;
   int n_lev;
-  int pair_tiles;            // see SbArgs
   SbLevelPtrs lev[kSbGroupLevels];
 };
 static_assert(sizeof(SbGroupArgs) <= 4096, "kernel arguments are limited to 4 KiB");
@@ -1021,7 +1019,6 @@ struct SbTile {   // what does not depend on the level
   uint32_t n_blocks;   // blocks of this operator's grid (for the XCD remap)
   double area_min;
   int masked, xcd_remap, b_fastest;
-  int pair_tiles;
 };
 
 template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB, typename M>
@@ -1060,16 +1057,9 @@ __device__ __forceinline__ void sb_tile_body(const M& m, const SbTile& a, uint32
     dt = bid - bt32 * (uint32_t)a.n_dtiles;
     bt = bt32;
   }
-  if (a.pair_tiles > 1) {
-    // Bands of T tiles = two rows of the destination grid (lon fastest): inside a band the tiles of the lower row are
-    // interleaved with those of the upper row, so that consecutive workgroups -- one XCD run -- own latitude neighbours,
-    // whose links share the source cells along their common edge.  A permutation of dt inside whole bands.
-    const uint32_t T = (uint32_t)a.pair_tiles, d32 = (uint32_t)dt, band = d32 / T, p = d32 - band * T;
-    if ((band + 1) * T <= (uint32_t)a.n_dtiles) {
-      const uint32_t h = T / 2;
-      dt = (int64_t)band * T + ((p & 1u) ? (p >> 1) : h + (p >> 1));
-    }
-  }
+  // (Round 6: dealing the tiles of two neighbouring rows of the destination grid to consecutive workgroups -- so that
+  // one XCD's L2 sees both users of the source cells along their common edge -- bought 0.5 - 4.6 % on config 3 kept
+  // batch-fastest, below the 5 % bar: profiles/r06_cfg3sb_lat_pair_order.txt; not kept.)
   const int64_t d0 = dt * TD;
   const int rows = (int)(a.n_dst - d0 < TD ? a.n_dst - d0 : TD);
   const int64_t b0 = bt * BT;
@@ -1226,7 +1216,7 @@ template <typename XT, typename YT, int TD, int U, bool FILL, bool YSB = false>
 __global__ __launch_bounds__(64) void smm_apply_sb_kernel(SbArgs a) {
   const SbMatrix<const int64_t*, const int32_t*, const double*, const uint8_t*> m{a.rowptr, a.col, a.val, a.imask, a.frac};
   const SbTile t{a.x, a.y, a.ldx, a.ldy, a.n_batch, a.n_dst, a.n_dtiles, a.n_btiles, (uint32_t)a.n_blocks,
-                 a.area_min, a.masked, a.xcd_remap, a.b_fastest, a.pair_tiles};
+                 a.area_min, a.masked, a.xcd_remap, a.b_fastest};
   sb_tile_body<XT, YT, TD, U, FILL, YSB>(m, t, blockIdx.x);
 }
 
@@ -1246,7 +1236,7 @@ __global__ __launch_bounds__(64) void smm_group_apply_sb_kernel(SbGroupArgs a) {
   // the operator's arrays are immutable while a kernel runs: constant address space keeps their loads scalar
   const SbMatrix<k_i64, k_i32, k_f64, k_u8> m{(k_i64)L.rowptr, (k_i32)L.col, (k_f64)L.val, (k_u8)L.imask, (k_f64)L.frac};
   const SbTile t{(const XT*)a.x + (int64_t)lvl * a.xs_lev, (YT*)a.y + (int64_t)lvl * a.ys_lev, a.ldx, a.ldy, a.n_batch,
-                 a.n_dst, a.n_dtiles, a.n_btiles, per, a.area_min, L.imask != nullptr, a.xcd_remap, a.b_fastest, a.pair_tiles};
+                 a.n_dst, a.n_dtiles, a.n_btiles, per, a.area_min, L.imask != nullptr, a.xcd_remap, a.b_fastest};
   sb_tile_body<XT, YT, TD, U, FILL, YSB>(m, t, bid);
 }
 

@@ -271,7 +271,6 @@ int launch_sb(const SbArgs& a, bool fill, unsigned flags, hipStream_t s) {
   // 8, 16 tiles within 3 % of it).  SMM_TUNE_SB_STRIP: -1 = whole-grid order, n = strips of n tiles.
   const int strip = smm::tuning(SMM_TUNE_SB_STRIP);
   args.b_fastest = strip < 0 ? 0 : (strip > 0 ? strip : 2);
-  args.pair_tiles = std::max(0, smm::tuning(SMM_TUNE_SB_PAIR_TILES));   // experiment knob (round 6): see sb_tile_body
   const bool ysb = (flags & SMM_APPLY_SB_Y_SB) != 0;   // result kept batch-fastest: Y (D, ldy >= B)
   auto go = [&](auto u_tag, auto fill_tag) {
     constexpr int UU = decltype(u_tag)::value;
@@ -307,7 +306,6 @@ int launch_sb_group(const SbGroupArgs& a, bool fill, unsigned flags, hipStream_t
   args.xcd_remap = xcd_run_length();
   const int strip = smm::tuning(SMM_TUNE_SB_STRIP);
   args.b_fastest = strip < 0 ? 0 : (strip > 0 ? strip : 2);
-  args.pair_tiles = std::max(0, smm::tuning(SMM_TUNE_SB_PAIR_TILES));   // experiment knob (round 6): see sb_tile_body
   const bool ysb = (flags & SMM_APPLY_SB_Y_SB) != 0;
   auto go = [&](auto u_tag, auto fill_tag) {
     constexpr int UU = decltype(u_tag)::value;

@@ -156,7 +156,8 @@ def test_secondary_entries_keep_their_units():
     out = {"roofline": {"kernel_ms": 2.75, "frac": 0.42, "traffic": 17.05e9, "algorithmic_bytes": 9.33e9},
            "spot_check": {"bit_equal_to_oracle": True}, "config": {"workload": "x" * 300, "plan": {"a": 1}}}
     cfg3 = {"value": 6e10, "unit": "cells/s", "roofline": {"kernel_ms": 11.4, "frac": 0.47, "traffic": 68.8e9, "algorithmic_bytes": 43.0e9,
-                                                             "layout_floor_ratio": 1.31, "refetch_ratio": 1.221}}
+                                                             "layout_floor_ratio": 1.31, "refetch_ratio": 1.221},
+            "spot_check": {"bit_equal_to_oracle": True}}
     details = {"others": {"cfg2sb": entry, "cfg3": cfg3, "cfg3c": {"error": "boom"}},
                "baseline_configs": {"cfg4": {"value": 3.4e11, "kernel_ms": 39.6, "frac": 0.5172, "workload": "w", "steps": 3,
                                              "algorithmic_bytes": 163.68e9,
@@ -171,27 +172,28 @@ def test_secondary_entries_keep_their_units():
                                                   "stage_ms": {"stage_in": 15.76, "h2d": 23.22, "kernel": 0.29, "d2h": 4.78,
                                                                "copy_out": 0.0, "wait": 9.67, "total": 29.69}},
                                 "pcie_bytes_per_row": {"packed": 2592000, "whole_rows": 8824320}, "spot_check": True,
-                                "staging_threads": 16, "bound": "packed: PCIe"}}
+                                "staging_threads": 16, "bound": "packed: PCIe", "cpu_cells_per_s": 8.5e8}}
     line = bench.final_line(out, details)
     r = line["roofline"]
     # the record keeps the first two dozen scalars of a nested block and the tail of the output: scalars first,
     # nested summaries last, the user-path and per-config blocks at the end of the line; the per-workload fractions are
-    # not repeated as scalars
+    # not repeated as scalars and the line stays well inside its 4-kB budget
     keys = list(r)
     assert keys.index("batch_fastest_frac") < keys.index("layouts") < keys.index("configs") == len(keys) - 1
     assert not [k for k in keys if k.startswith("cfg")] and all(not isinstance(r[k], dict) for k in keys[:-2])
+    assert len(json.dumps(line)) < 3500
     assert list(line)[-3:] == ["reference_sized", "baseline_configs", "host_to_host"]
-    assert line["reference_sized"]["2t_era5"] == {"in": "12x73x144", "init_ms": 3.2, "regrid_ms": 0.41, "cpu_scipy_ms": 5.5,
-                                                  "cpu_c1_ms": 2.2, "bit_equal": True}
+    assert line["reference_sized"]["2t_era5"] == ["12x73x144", 3.2, 0.41, 5.5, 2.2, True] and "regrid() ms" in line["reference_sized"]["cols"]
     assert len(line["reference_sized"]["tas_ecearth"]["error"]) <= 60
     h = line["host_to_host"]
-    assert h["pinned_packed"] == {"v": 9.877e8, "best": 1.012e9, "pcie": 0.73, "mem": 0.81,
-                                  "st": [15.8, 23.2, 0.3, 4.8, 0.0, 9.7, 29.7]}
-    assert h["spot_check"] is True and h["ceil_GBs"]["pcie_h2d_GBs"] == 57.5 and h["staging_threads"] == 16 and h["reps"] == 9
+    assert h["pinned_packed"] == [988, 1012, 0.73, 0.81, 15.8, 23.2, 0.3, 4.8, 0.0, 9.7, 29.7] and "Mcells/s median, best" in h["cols"]
+    assert h["spot_check"] is True and h["ceil_GBs"] == {"h2d": 57.5, "host_copy": 110.4} and h["staging_threads"] == 16
+    assert h["reps"] == 9 and h["cpu_Mcells_per_s"] == 850
     c4 = line["baseline_configs"]["cfg4"]
     assert c4["frac"] == 0.5172 and c4["alg_GB"] == 163.68
     assert c4["f32_out"] == {"ms": 28.123, "frac": 0.4827, "alg_GB": 108.6, "spot_check": True}
     assert r["configs"]["cfg3"] == {"ms": 11.4, "frac": 0.47, "traffic_ratio": 1.6, "floor": 1.31, "refetch": 1.221}
+    assert r["spot_checks_bit_equal"] == "3 of 3" and "spot_check" not in r["layouts"]["batch_fastest"]
     assert r["layouts"]["batch_fastest"]["frac"] == 0.68 and r["batch_fastest_frac"] == 0.68
     assert r["layouts"]["native"]["traffic_ratio"] == 1.827 and r["configs"]["cfg3c"] == {"error": "boom"}
     assert len(line["config"]["workload"]) <= 100 and "plan" not in line["config"]

@@ -166,6 +166,7 @@ int main(int argc, char** argv) {
   // (end of the read buffer) + delta for a list of deltas -- does the rate follow the relative placement of the two streams?
   const uint64_t sweep = argc > 14 ? (uint64_t)atoll(argv[14]) : 0;
   char *src = nullptr, *dst = nullptr, *dst_base = nullptr;
+  bool vmm_used = false;   // buffers from the virtual-memory API are left to process exit
   if (sweep) {
     CHECK(hipMalloc((void**)&src, src_bytes + dst_bytes + sweep + 4096));
     CHECK(hipMemset(src, 1, src_bytes + dst_bytes + sweep + 4096));
@@ -179,8 +180,44 @@ int main(int argc, char** argv) {
     const uint64_t pre = argc > 16 ? (uint64_t)atoll(argv[16]) : 0;
     char* dummy = nullptr;
     if (pre) CHECK(hipMalloc((void**)&dummy, pre));
-    CHECK(hipMalloc((void**)&src, src_bytes));
-    CHECK(hipMalloc((void**)&dst, dst_bytes + dst_off));
+    // argv[18] = alignment (bytes) of a virtual-memory-API allocation for the write buffer instead of hipMalloc
+    // (hipMemCreate + hipMemAddressReserve(alignment) + hipMemMap): does a virtual address aligned to 64 MiB / 1 GiB
+    // let the driver map larger fragments?  argv[19] != 0: the read buffer the same way.
+    const uint64_t vmm_align = argc > 18 ? (uint64_t)atoll(argv[18]) : 0;
+    const int vmm_src = argc > 19 ? atoi(argv[19]) : 0;
+    auto vmm_alloc = [&](char** out, uint64_t bytes) -> int {
+      hipMemAllocationProp prop = {};
+      prop.type = hipMemAllocationTypePinned;
+      prop.location.type = hipMemLocationTypeDevice;
+      prop.location.id = 0;
+      size_t gran = 0;
+      CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+      const uint64_t unit = vmm_align > gran ? vmm_align : gran;
+      const uint64_t size = (bytes + unit - 1) / unit * unit;
+      hipMemGenericAllocationHandle_t h;
+      CHECK(hipMemCreate(&h, size, &prop, 0));
+      void* p = nullptr;
+      CHECK(hipMemAddressReserve(&p, size, vmm_align, nullptr, 0));
+      CHECK(hipMemMap(p, size, 0, h, 0));
+      hipMemAccessDesc ad = {};
+      ad.location = prop.location;
+      ad.flags = hipMemAccessFlagsProtReadWrite;
+      CHECK(hipMemSetAccess(p, size, &ad, 1));
+      *out = (char*)p;
+      fprintf(stderr, "vmm: %llu bytes at %p (granularity %zu, alignment %llu)\n", (unsigned long long)size, p, gran, (unsigned long long)vmm_align);
+      return 0;
+    };
+    if (vmm_align && vmm_src) {
+      if (vmm_alloc(&src, src_bytes)) return 1;
+    } else {
+      CHECK(hipMalloc((void**)&src, src_bytes));
+    }
+    if (vmm_align) {
+      if (vmm_alloc(&dst, dst_bytes + dst_off)) return 1;
+      vmm_used = true;
+    } else {
+      CHECK(hipMalloc((void**)&dst, dst_bytes + dst_off));
+    }
     CHECK(hipMemset(src, 1, src_bytes));
     CHECK(hipMemset(dst, 0, dst_bytes + dst_off));
     dst_base = dst;
@@ -310,7 +347,9 @@ int main(int argc, char** argv) {
            (unsigned long long)(ps % (1ull << 30)), (unsigned long long)(pd % (1ull << 30)), (unsigned long long)(ps % (2ull << 20)),
            (unsigned long long)(pd % (2ull << 20)), (unsigned long long)(uintptr_t)sb, ss, (unsigned long long)(uintptr_t)db, ds);
   }
-  CHECK(hipFree(src));
-  CHECK(hipFree(dst_base));
+  if (!vmm_used) {
+    CHECK(hipFree(src));
+    CHECK(hipFree(dst_base));
+  }
   return 0;
 }

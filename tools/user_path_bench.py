@@ -161,12 +161,10 @@ def host_to_host(device=0, rows=512, cpu_cells_per_s=None, reps=9):
 
 
 def _what_bounds(out):
-    """One short sentence per mode family from the fractions above (kept under 100 characters for the bench line)."""
+    """The binding ceiling per mode family, from the fractions above (a short string for the bench line)."""
     def worst(e):
         return "host memory" if e["host_mem_frac"] >= e["pcie_frac"] else "PCIe"
-    p, wr = out["pageable_packed"], out["pinned_whole_rows"]
-    return (f"packed: {worst(p)} ({p['host_mem_frac']:.2f} of host copy rate, {p['pcie_frac']:.2f} of PCIe); "
-            f"pinned whole rows: {worst(wr)} ({wr['pcie_frac']:.2f} of PCIe)")[:99]
+    return f"packed: {worst(out['pageable_packed'])}; whole rows: {worst(out['pinned_whole_rows'])}"
 
 
 # ------------------------------------------------------------------------------------------ reference-sized
