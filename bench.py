@@ -1207,6 +1207,7 @@ def main():
         rdv = HostRendezvous(rank, world)
         n_ranks = len({int(p) for p in rdv.allgather(str(rank).encode())})   # ranks that really joined
 
+    rehearsal = None
     if args.dry_run:
         prob = DryProblem(args.workload, rank)
         y = np.zeros(prob.y_shape)
@@ -1223,6 +1224,10 @@ def main():
                 raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({n_dev} visible): one rank per GPU "
                                  "(SMM_BENCH_SHARE_GPUS=1 lets ranks share devices for a rehearsal)")
             local_rank %= n_dev              # rehearsal on a smaller box: ranks share devices, RCCL will refuse
+        if world > n_dev and os.environ.get("SMM_BENCH_SHARE_GPUS"):
+            rehearsal = f"{world} ranks share {n_dev} device(s)"
+            if os.environ.get("SMM_RCCL_LIB"):
+                rehearsal += f"; collectives through {os.path.basename(os.environ['SMM_RCCL_LIB'])}"
         set_device(local_rank)
         cls = ProblemLevels if WORKLOADS[args.workload][0] == "con3d" else Problem2D
         prob = cls(args.workload, local_rank, rank, batch=args.batch)
@@ -1248,6 +1253,9 @@ def main():
                "layout": "native (B, S)" if getattr(prob, "layout", "bs") == "bs" else "batch-fastest",
                "resident_in_hbm": True, "create_ms": getattr(prob, "create_ms", None)}
         cfg.update(prob.meta)
+        if rehearsal:
+            # not a multi-GPU measurement: the ranks ran on fewer devices than ranks (tests / a rehearsal of the N > 1 path)
+            cfg["rehearsal"] = short(rehearsal + ": no scaling or xGMI meaning", 96)
         details["plan"] = cfg.get("plan")
         out = {
             "metric": "regridded cells/sec (dst_pts x time x lev)",

@@ -136,3 +136,35 @@ def test_process_wide_setters_need_no_device():
     _lib.call("smm_debug_set_grid_limit", 0)
     with pytest.raises(_lib.SmmError):
         _lib.call("smm_debug_set_grid_limit", -3)
+
+
+def test_host_memcpy_on_the_staging_pool_survives_a_fork():
+    """smm_host_memcpy (no GPU involved): the parallel copy of the host pipelines' staging pool.  The pool is per
+    process -- a child of fork() has none of the parent's worker threads and must start its own instead of waiting
+    for threads that do not exist; both processes exit cleanly (the workers are joined at exit)."""
+    import numpy as np
+    lib = _lib.load()
+    prev = ctypes.c_int(0)
+    assert lib.smm_set_host_threads(4, ctypes.byref(prev)) == 0
+    try:
+        src = np.arange(12 << 20, dtype=np.float64)          # 96 MiB: above the single-thread threshold
+        dst = np.zeros_like(src)
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        assert lib.smm_host_memcpy(ptr(dst), ptr(src), src.nbytes) == 0 and np.array_equal(dst, src)
+        assert lib.smm_host_memcpy(ptr(dst), None, 8) == _lib.SMM_ERR_INVALID
+        assert lib.smm_host_memcpy(None, None, 0) == 0
+        pid = os.fork()
+        if pid == 0:                                         # the child: a pool of its own
+            code = 1
+            try:
+                dst[:] = 0.0
+                ok = lib.smm_host_memcpy(ptr(dst), ptr(src), src.nbytes) == 0 and np.array_equal(dst, src)
+                code = 0 if ok else 2
+            finally:
+                os._exit(code)
+        _, status = os.waitpid(pid, 0)
+        assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+        dst[:] = 0.0                                         # the parent's pool is untouched by the fork
+        assert lib.smm_host_memcpy(ptr(dst), ptr(src), src.nbytes) == 0 and np.array_equal(dst, src)
+    finally:
+        lib.smm_set_host_threads(prev.value, None)

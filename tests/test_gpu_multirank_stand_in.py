@@ -102,6 +102,7 @@ def test_bench_two_ranks_with_gather_through_the_stand_in(hip, fake_rccl):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "2 ranks share 1 device" in line["config"]["rehearsal"] and "fake_rccl" in line["config"]["rehearsal"]
     g = line["with_gather"]
     assert "error" not in g, g
     assert g["ranks"] == 2 and g["tiles"] == 5 and g["value"] > 0 and g["ms_per_step"] > 0

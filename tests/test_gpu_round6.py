@@ -119,3 +119,43 @@ def test_host_pipeline_stats_and_store_kinds(hip, rng):
         finally:
             _lib.call("smm_set_host_threads", prev.value, None)
     assert _lib.host_stats()["threads"] in (1.0, 8.0)
+
+
+def test_concurrent_host_pipelines_share_the_staging_pool(hip, rng):
+    """The reference's dask scheduler calls apply_weights from several threads (regrid.py:29-30): four threads run
+    smm_apply_host on two operators at once (calls on one operator take turns, the staging jobs of different
+    operators take turns on the one pool) while a fifth thread builds operators (the builders' own worker threads).
+    Every result is bit-equal to the oracle."""
+    import threading
+    ops = [_bilinear("r1440x720", "r360x180")[1], _bilinear("r720x360", "r180x90")[1]]
+    xs = [field(rng, 160, op.n_src) for op in ops]
+    refs = [oracle.apply_c(op.export_csr(), x) for op, x in zip(ops, xs)]
+    errors = []
+
+    def apply_loop(k, reps):
+        try:
+            for r in range(reps):
+                y = ops[k].apply_host(xs[k], flags=_lib.APPLY_HOST_NO_PACK if (r + k) % 2 else 0, chunk_rows=48)
+                if not np.array_equal(y, refs[k], equal_nan=True):
+                    errors.append(f"operator {k}, call {r}: result differs from the oracle")
+        except Exception as exc:          # noqa: BLE001 -- reported through `errors`
+            errors.append(repr(exc))
+
+    def create_loop():
+        try:
+            for _ in range(3):
+                w, op = _bilinear("r720x360", "r90x45")
+                x = field(rng, 3, op.n_src)
+                if not np.array_equal(op.apply(to_device(x)).to_host(), oracle.apply_c(op.export_csr(), x), equal_nan=True):
+                    errors.append("operator created under load differs")
+                op.close()
+        except Exception as exc:          # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=apply_loop, args=(k % 2, 4)) for k in range(4)] + [threading.Thread(target=create_loop)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not any(t.is_alive() for t in threads), "a host pipeline call did not return"
+    assert errors == [], errors[:3]
