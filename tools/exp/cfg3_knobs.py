@@ -20,6 +20,10 @@ prob = bench.ProblemLevels("cfg3", 0, 0)
 y = DeviceArray(prob.y_shape, np.float64)
 variants = [{}, {"tile_x_loads": 1}, {"tile_x_loads": 2}, {"xcd_run": 6}, {"xcd_run": 12}, {"xcd_run": 64}, {"xcd_run": 128},
             {"xcd_run": -1}, {"tile_walk": 120}, {"tile_walk": 32}, {"tile_walk": 16}, {"tile_links": 1}]
+if len(sys.argv) > 2 and sys.argv[2] == "occupancy":
+    # experiment build only (smm_launch.hpp adds the sb_lds_pad knob to the tile kernel's dynamic LDS): fewer workgroups per CU
+    variants = [{}] + [{"sb_lds_pad": pad} for pad in (2048, 4096, 6144, 8192, 12288, 18432, 26624, 40960)] + \
+               [{"sb_lds_pad": 12288, "xcd_run": 64}, {"sb_lds_pad": 18432, "xcd_run": 64}]
 res = {json.dumps(v): [] for v in variants}
 for rep in range(reps):
     for v in variants:
