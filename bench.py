@@ -850,6 +850,7 @@ def layout_summary(entry):
         out["floor"] = round(r["layout_floor_ratio"], 3)
         if r.get("refetch_ratio"):
             out["refetch"] = round(r["refetch_ratio"], 3)
+            out.pop("traffic_ratio", None)            # = floor x refetch: the compact line carries the two factors
     if "spot_check" in entry:
         out["spot_check"] = bool(entry["spot_check"].get("bit_equal_to_oracle"))
     return out
@@ -974,8 +975,7 @@ def compact(obj, digits=6):
 
 
 ROOFLINE_SCALARS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes",
-                    "traffic_ratio", "traffic_fresh", "line_granular_frac", "layout_floor_ratio", "refetch_ratio", "traffic_GBs",
-                    "stream_copy_GBs")
+                    "traffic_ratio", "traffic_fresh", "layout_floor_ratio", "refetch_ratio", "stream_copy_GBs")
 
 
 def final_line(out, details):
@@ -1007,10 +1007,13 @@ def final_line(out, details):
         nested["layouts"] = {"native": native, "batch_fastest": sb}
         if "cfg2sbk" in others:
             nested["layouts"]["batch_fastest_y_kept"] = layout_summary(others.get("cfg2sbk"))
-        # the same figures once more as plain scalars (a record that keeps only scalars still shows them)
+        # the same figures once more as plain scalars (a record that keeps only scalars still shows them); the traffic ratios
+        # of the two layouts live in the scalars only (`traffic_ratio`, `batch_fastest_traffic_ratio`)
         for key in ("frac", "ms", "traffic_ratio"):
             if key in sb:
                 roof[f"batch_fastest_{key}"] = sb[key]
+        for e in nested["layouts"].values():
+            e.pop("traffic_ratio", None)
         # (the per-workload fractions live in `roofline.configs` and `baseline_configs` only: round 5 repeated them as
         # scalars here and the line came within 0.4 kB of its budget)
         nested["configs"] = {n: layout_summary(e) for n, e in others.items() if not n.startswith("cfg2sb")}
@@ -1025,7 +1028,7 @@ def final_line(out, details):
         line["roofline"] = roof
     cpu = line.get("cpu_baseline")
     if cpu:
-        for k in ("legs", "threads", "rows_sampled", "passes", "seconds"):     # `sample` says the same; the legs are in `details`
+        for k in ("legs", "threads", "rows_sampled", "passes", "seconds", "usable_cores"):   # `sample` / `cores` say the same; the legs are in `details`
             cpu.pop(k, None)
         cpu["sample"] = short(cpu["sample"], 60)
     cfg = line.get("config") or {}
@@ -1040,7 +1043,7 @@ def final_line(out, details):
     line.pop("baseline_configs", None)
     for name, blk in (details.get("baseline_configs") or {}).items():
         keep = {k: v for k, v in blk.items() if k not in ("workload", "steps", "warmup", "unit", "dtype", "algorithmic_bytes",
-                                                          "setup_and_run_s")}
+                                                          "setup_and_run_s", "create_ms")}
         if keep.get("n_gpus") == 1:          # one rank: the spread over ranks and the host-side step time say nothing new
             for k in ("kernel_ms_min", "kernel_ms_max", "ms_per_step"):
                 keep.pop(k, None)
@@ -1066,7 +1069,7 @@ def final_line(out, details):
         # per mode: median and best cells/s of `reps` calls, the fraction of the measured PCIe (H2D) and host-memory
         # (2 x the staging pool's copy rate) ceilings it runs at, and the stage split of one call in ms
         blk = {"rows": h2h.get("rows"), "reps": h2h.get("reps"),
-               "cols": "Mcells/s median, best; frac of PCIe h2d, of host-mem ceiling; ms/call: in, h2d, kern, d2h, out, wait, total"}
+               "cols": "Mcells/s median, best; frac of PCIe, of host-mem ceiling; ms: in, h2d, kern, d2h, out, wait, total"}
         ceil = h2h.get("ceilings") or {}
         blk["ceil_GBs"] = {k.replace("pcie_", "").replace("_GBs", ""): v for k, v in ceil.items()}
         for k, e in h2h.items():
@@ -1292,7 +1295,7 @@ def main():
     def emit(code=0):
         """Rank 0: the bulky details first (a line that does not start with '{'), the compact line last."""
         if rank == 0:
-            out["wall_s"] = time.perf_counter() - t_start
+            out["wall_s"] = round(time.perf_counter() - t_start, 1)
             print("details: " + json.dumps(details), flush=True)
             print(json.dumps(final_line(out, details)), flush=True)
         if code:

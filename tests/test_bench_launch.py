@@ -192,10 +192,11 @@ def test_secondary_entries_keep_their_units():
     c4 = line["baseline_configs"]["cfg4"]
     assert c4["frac"] == 0.5172 and c4["alg_GB"] == 163.68
     assert c4["f32_out"] == {"ms": 28.123, "frac": 0.4827, "alg_GB": 108.6, "spot_check": True}
-    assert r["configs"]["cfg3"] == {"ms": 11.4, "frac": 0.47, "traffic_ratio": 1.6, "floor": 1.31, "refetch": 1.221}
+    assert r["configs"]["cfg3"] == {"ms": 11.4, "frac": 0.47, "floor": 1.31, "refetch": 1.221}
     assert r["spot_checks_bit_equal"] == "3 of 3" and "spot_check" not in r["layouts"]["batch_fastest"]
     assert r["layouts"]["batch_fastest"]["frac"] == 0.68 and r["batch_fastest_frac"] == 0.68
-    assert r["layouts"]["native"]["traffic_ratio"] == 1.827 and r["configs"]["cfg3c"] == {"error": "boom"}
+    assert r["traffic_ratio"] == 1.827 and r["batch_fastest_traffic_ratio"] == 1.002 and "traffic_ratio" not in r["layouts"]["native"]
+    assert r["configs"]["cfg3c"] == {"error": "boom"}
     assert len(line["config"]["workload"]) <= 100 and "plan" not in line["config"]
 
 

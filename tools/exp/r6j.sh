@@ -1,0 +1,8 @@
+# round 6, GPU call j (clean tree): the driver's command plain and under the kernel trace, with the refreshed profiles/traffic.json.
+mkdir -p gpurun_out/r6j && cd /root/repo
+export TMPDIR=/tmp
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r6j/r06_driver_cmd_bench.json 2> gpurun_out/r6j/bench.err; echo "bench rc=$?"
+rm -rf /tmp/prof_driver
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_driver/kt -- python3 /root/repo/bench.py --gpus 1 --steps 20 --warmup 5 > /root/repo/gpurun_out/r6j/r06_driver_cmd_bench_under_rocprof.json 2> /root/repo/gpurun_out/r6j/rocprof.err); echo "rocprof rc=$?"
+cp $(ls /tmp/prof_driver/kt/*/*_kernel_stats.csv | head -1) gpurun_out/r6j/r06_driver_cmd_kernel_stats.csv
+tail -n 1 gpurun_out/r6j/r06_driver_cmd_bench.json | cut -c1-1500
