@@ -217,12 +217,15 @@ def test_a_failing_rank_fails_the_run():
 
 def test_under_torch_distributed_run():
     """The driver's other launch form: one rank per GPU started by torch.distributed.run."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--dry-run",
-               "--steps", "2", "--warmup", "1", "--gather", "none"], timeout=300)
+    for attempt in range(2):        # the probed port (and port + 23 of the rendezvous) can be taken between probe and bind: one retry
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--dry-run",
+                   "--steps", "2", "--warmup", "1", "--gather", "none"], timeout=300)
+        if out.returncode == 0 or "Address already in use" not in out.stderr:
+            break
     assert out.returncode == 0, out.stderr[-3000:]
     line = json_line(out)
     assert line["n_gpus"] == 2 and line["config"]["launched_by"] == "external launcher"
