@@ -59,7 +59,7 @@ def main():
                         device=0)
     csr = oracle.coo_to_csr_c(n_src, n_dst, w["src_address"].values, w["dst_address"].values,
                               w["remap_matrix"].values)
-    n_rows = 10                                      # 2 ranks: 5 + 5; 3 ranks: 4 + 4 + 2 (a short last shard)
+    n_rows = 10                                      # 2 ranks: 5 + 5; 3 ranks: 4 + 4 + 2; 4 ranks: 3 + 3 + 3 + 1 (a short last shard)
     x = 250.0 + 30.0 * rng.standard_normal((n_rows, n_src))
     x[3, :40] = np.nan
     ref = oracle.apply_c(csr, x)

@@ -44,9 +44,9 @@ def _env(fake, **extra):
     return env
 
 
-@pytest.mark.parametrize("world,slot_bytes", [(2, None), (3, None), (2, "4096")])
+@pytest.mark.parametrize("world,slot_bytes", [(2, None), (3, None), (4, None), (2, "4096")])
 def test_gather_allgather_and_the_tiled_ring_on_device_memory(hip, fake_rccl, tmp_path, world, slot_bytes):
-    """2 and 3 rank processes on device 0: Comm.gather (root = last rank) / allgather in f64 and f32,
+    """2, 3 and 4 rank processes on device 0: Comm.gather (root = last rank) / allgather in f64 and f32,
     regrid_sharded root / all / none with a short last shard, TiledRingGather with 4 tiles of 2, 2, 2, 1 rows over
     2 slots for 2 steps -- root's assembled Y bit-equal to oracle.apply_c per rank and tile, `gathered_bytes` as
     tests/test_distributed_cpu.py computes it.  The third case shrinks the stand-in's staging slot to 4 KiB so
