@@ -612,13 +612,17 @@ def stream_copy_gbs(nbytes=2 << 30, reps=5):
     return gbs
 
 
+HOST_ONLY_SOURCES = ("smm_hostpool.cpp", "smm_comm.cpp")   # staging pool, RCCL binding: cannot change a kernel's traffic
+
+
 def kernel_source_sha():
-    """sha256 over the device-side sources: ties a replayed PMC figure to the code that produced it."""
+    """sha256 over the sources that decide what a kernel moves -- the kernels, their launchers and the plan builder; ties a
+    replayed PMC figure to the code that produced it."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "smmregrid_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hpp", ".hip", ".cpp", ".h")):
+        if name.endswith((".hpp", ".hip", ".cpp", ".h")) and name not in HOST_ONLY_SOURCES:
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     return h.hexdigest()[:16]

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <string>
 
 #include "../../include/smmregrid_amd.h"
@@ -124,7 +125,8 @@ int smm_comm_create(const void* id, int n_ranks, int rank, smm_comm_t* out) {
   if (!r.ok) return smm::fail_msg(SMM_ERR_UNSUPPORTED, r.err);
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
-  smm_comm* c = new smm_comm();
+  smm_comm* c = new (std::nothrow) smm_comm();
+  if (!c) return smm::fail_msg(SMM_ERR_ALLOC, "out of host memory");
   c->n_ranks = n_ranks;
   c->rank = rank;
   int rc = check(r.CommInitRank(&c->comm, n_ranks, uid, rank), "ncclCommInitRank");

@@ -154,14 +154,15 @@ class Pool {
       std::unique_lock<std::mutex> one_job(job_mu_);     // jobs of concurrent callers take turns (each lasts ms)
       {
         std::unique_lock<std::mutex> lk(mu_);
-        while ((int)workers_.size() < want && !g_pool_no_threads.load(std::memory_order_relaxed)) {
+        while (!stop_ && (int)workers_.size() < want && !g_pool_no_threads.load(std::memory_order_relaxed)) {
           try {
             workers_.emplace_back(&Pool::worker, this, (int)workers_.size(), gen_);
           } catch (...) {   // EAGAIN / out of memory: go on with the workers there are
             break;
           }
         }
-        job.helpers = g_pool_no_threads.load(std::memory_order_relaxed) ? 0 : std::min(want, (int)workers_.size());
+        // after shutdown() (process exit has begun; a straggling thread may still call in) the caller works alone
+        job.helpers = (stop_ || g_pool_no_threads.load(std::memory_order_relaxed)) ? 0 : std::min(want, (int)workers_.size());
         if (job.helpers > 0) {
           job_ = &job;
           busy_ = job.helpers;
