@@ -126,6 +126,8 @@ def parse_args():
                          "config-2 rows (block `host_to_host`) and Regridder.regrid on the reference's own fields with the CPU "
                          "oracle beside them (block `reference_sized`)")
     ap.add_argument("--host-rows", type=int, default=512, help="batch rows of the host_to_host block")
+    ap.add_argument("--host-level-steps", type=int, default=24,
+                    help="time steps of the config-3 field held in host memory (75 levels each; 24 = 21 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -837,7 +839,53 @@ def run_others(args, names, local_rank, flags, t_start):
         except Exception as exc:   # one secondary workload must not lose the headline
             out[name] = {"error": repr(exc)}
     if "levels" in shared:
+        if args.user_path != "none" and time.perf_counter() - t_start <= args.others_budget:
+            try:       # the same 75 operators from HOST memory (smm_group_apply_host): never `value`, PCIe-inclusive
+                out["cfg3_host"] = levels_host_to_host(shared["levels"], args.host_level_steps)
+            except Exception as exc:   # must not lose the line
+                out["cfg3_host"] = {"error": short(repr(exc), 90)}
         shared["levels"].free()
+    return out
+
+
+def levels_host_to_host(prob, n_t, reps=3):
+    """BASELINE config 3's operators on a field held in HOST memory, (n_t, 75, 1, S) f64 with NaN on land per level, through
+    smm_group_apply_host: level-major packing of the used cells (the default) against whole rows, median of `reps` calls, the
+    stage split of smm_debug_host_stats, one (time step, level) row checked against the oracle."""
+    from oracle import oracle
+    from smmregrid_amd import _lib
+    x = np.ascontiguousarray(np.broadcast_to(prob.slab[None, :, None, :], (n_t, prob.n_lev, 1, prob.n_src)))
+    x[:, :, 0, ::131] += np.arange(n_t, dtype=np.float64)[:, None, None]          # time steps differ (NaN stays NaN)
+    used = sum(op.n_used_src for op in prob.ops)
+    out = {"workload": f"cfg3 operators, {n_t} x {prob.n_lev} x {prob.n_src} f64 in host memory", "time_steps": int(n_t),
+           "input_GB": round(x.nbytes / 1e9, 2), "pcie_GB": {"packed": round((used + prob.n_lev * prob.n_dst) * 8 * n_t / 1e9, 2),
+                                                              "whole_rows": round((x.nbytes + n_t * prob.n_lev * prob.n_dst * 8) / 1e9, 2)}}
+    ys = {}
+    for mode, fl in (("packed", 0), ("whole_rows", _lib.APPLY_HOST_NO_PACK)):
+        call = lambda: prob.group.apply_host(x, prob.level_index, prob.masked_levels, masked=True, remap_area_min=0.5, flags=fl)
+        ys[mode] = call()                                                           # warm-up: staging buffers
+        _lib.host_stats(reset=True)
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            call()
+            times.append(time.perf_counter() - t0)
+        st = _lib.host_stats(reset=True)
+        sec = float(np.median(times))
+        out[mode] = {"seconds": sec, "cells_per_s": n_t * prob.n_lev * prob.n_dst / sec, "host_GBs": x.nbytes / sec / 1e9,
+                     "chunks": int(st["chunks"] / max(st["calls"], 1)),
+                     "stage_ms": {k[:-3]: round(st[k] / max(st["calls"], 1), 1) for k in
+                                  ("stage_in_ms", "h2d_ms", "kernel_ms", "d2h_ms", "copy_out_ms", "wait_ms", "total_ms")}}
+    out["same_bits"] = bool(np.array_equal(ys["packed"], ys["whole_rows"], equal_nan=True))
+    t, lv = n_t // 2, prob.n_lev // 2
+    w3 = prob.weights
+    n = int(w3["link_length"].values[lv])
+    rm = w3["remap_matrix"].values[lv, :n]
+    csr = oracle.coo_to_csr_c(prob.n_src, prob.n_dst, w3["src_address"].values[lv, :n], w3["dst_address"].values[lv, :n],
+                              rm[:, 0] if rm.ndim == 2 else rm)
+    ref = oracle.apply_c(csr, x[t, lv], bool(prob.masked_levels[lv]), prob.dst_imask[lv], w3["dst_grid_frac"].values[lv], 0.5)[0]
+    got = ys["packed"][t, 0, lv]
+    out["spot_check"] = bool(np.array_equal(got, ref, equal_nan=True))
     return out
 
 
@@ -1020,7 +1068,7 @@ def final_line(out, details):
             e.pop("traffic_ratio", None)
         # (the per-workload fractions live in `roofline.configs` and `baseline_configs` only: round 5 repeated them as
         # scalars here and the line came within 0.4 kB of its budget)
-        nested["configs"] = {n: layout_summary(e) for n, e in others.items() if not n.startswith("cfg2sb")}
+        nested["configs"] = {n: layout_summary(e) for n, e in others.items() if not n.startswith("cfg2sb") and n != "cfg3_host"}
     for k in ("kernel_ms_min_rank", "kernel_ms_max_rank"):
         if k in full and line.get("n_gpus", 1) > 1:
             roof[k] = full[k]
@@ -1073,7 +1121,7 @@ def final_line(out, details):
         # per mode: median and best cells/s of `reps` calls, the fraction of the measured PCIe (H2D) and host-memory
         # (2 x the staging pool's copy rate) ceilings it runs at, and the stage split of one call in ms
         blk = {"rows": h2h.get("rows"), "reps": h2h.get("reps"),
-               "cols": "Mcells/s median, best; frac of PCIe, of host-mem ceiling; ms: in, h2d, kern, d2h, out, wait, total"}
+               "cols": "Mcells/s median, best; frac of PCIe, of host-mem rate; ms: in,h2d,kern,d2h,out,wait,total"}
         ceil = h2h.get("ceilings") or {}
         blk["ceil_GBs"] = {k.replace("pcie_", "").replace("_GBs", ""): v for k, v in ceil.items()}
         for k, e in h2h.items():
@@ -1082,6 +1130,14 @@ def final_line(out, details):
                 blk[k] = [round(e["cells_per_s"] / 1e6), round(e.get("cells_per_s_best", 0) / 1e6),
                           round(e.get("pcie_frac", 0), 2), round(e.get("host_mem_frac", 0), 2)] + \
                          [round(st.get(n, 0), 1) for n in ("stage_in", "h2d", "kernel", "d2h", "copy_out", "wait", "total")]
+        c3 = others.get("cfg3_host") or {}
+        if "packed" in c3:      # config 3's 75 operators from host memory: Mcells/s and seconds, packed (level-major) / whole rows
+            blk["cfg3_levels"] = {"steps": c3["time_steps"], "in_GB": c3["input_GB"],
+                                  "packed": [round(c3["packed"]["cells_per_s"] / 1e6), round(c3["packed"]["seconds"], 3)],
+                                  "whole_rows": [round(c3["whole_rows"]["cells_per_s"] / 1e6), round(c3["whole_rows"]["seconds"], 3)],
+                                  "ok": bool(c3.get("same_bits") and c3.get("spot_check"))}
+        elif "error" in c3:
+            blk["cfg3_levels"] = {"error": c3["error"]}
         if h2h.get("cpu_cells_per_s"):
             blk["cpu_Mcells_per_s"] = round(h2h["cpu_cells_per_s"] / 1e6)
         for k in ("staging_threads", "spot_check", "bound", "error"):

@@ -33,7 +33,7 @@ APPLY_KERNEL_TILE = 1 << 9
 # smm_debug_set_tuning knobs (tests, tools, benchmarks; the results do not depend on them)
 TUNE_KNOBS = ("sell_batch_rows", "tile_walk", "tile_staging", "tile_rows_per_step", "tile_x_loads",
               "tile_split_rows", "tile_links", "xcd_run", "sb_strip", "sb_loads", "sb_level_launches", "sb_lds_pad",
-              "host_pack_stores")
+              "host_pack_stores", "host_chunk_kb")
 TUNE = {name: i for i, name in enumerate(TUNE_KNOBS)}
 STAGING_REGISTERS, STAGING_DMA = 1, 2
 

@@ -1689,10 +1689,12 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
       return fail(SMM_ERR_INVALID, "level_index[" + std::to_string(l) + "] outside the group");
     used_total += g->ops[(size_t)level_index[l]]->csr.n_used_src;
   }
-  // A chunk carries every selected level, so it needs >= 32 batch entries per level to feed the
-  // batch-fastest kernel and the pack loops; when 32 entries of all levels do not fit 1 GiB of staging
-  // (config 3: 39 M used cells per time step) the whole-row pipeline stays (measured there: packing with
-  // one time step per chunk ran 4x slower than whole rows).
+  // Chunks of the pipeline.  Whole rows: blocks of the outer axis with every level.  Packed: a chunk needs >= 32 batch
+  // entries per level to feed the batch-fastest kernel and the pack loops; when that many entries of ALL selected levels
+  // fit the staging budget a chunk is again a block of the outer axis (host_chunk_units); when they do not (config 3: 39 M
+  // used cells per time step, 10 GB for 32 steps) the chunks become LEVEL-MAJOR: a few consecutive data levels x as many
+  // outer indices as one level's used cells allow (round 6; before, such a field went whole rows over PCIe: config 3 ships
+  // 106 GB that way and 37 GB packed).  One time step per chunk with all levels (round 3) ran 4x slower than whole rows.
   const int64_t min_outer = (32 + n_inner - 1) / n_inner;
   const bool may_pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
                         used_total > 0 && used_total * 2 <= n_lev * S;
@@ -1705,8 +1707,57 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
   const smm::HostChunk hc = smm::host_chunk_units(n_outer, x_outer_d, y_outer,
                                                   may_pack ? (size_t)used_total * n_inner * xsz : 0, min_outer, 1,
                                                   chunk_outer, free_b);
-  const bool pack = hc.pack;
-  chunk_outer = hc.units;
+  struct GChunk {
+    int64_t o0, no, l0, nl;
+    size_t x_bytes;   // packed X bytes of the chunk (pack mode)
+  };
+  std::vector<GChunk> chunks;
+  const int64_t budget_kb = smm::tuning(SMM_TUNE_HOST_CHUNK_KB);   // tests: > 0 forces level-major chunks of that staging budget
+  bool pack = hc.pack && budget_kb <= 0;
+  if (pack || !may_pack || chunk_outer > 0) {
+    for (int64_t o0 = 0; o0 < n_outer; o0 += hc.units)
+      chunks.push_back({o0, std::min<int64_t>(hc.units, n_outer - o0), 0, n_lev, 0});
+  }
+  if (!pack && may_pack && chunk_outer <= 0 && n_outer >= min_outer) {
+    // level-major: the staging budget per chunk (SMM_TUNE_HOST_CHUNK_KB lowers it so that tests reach every branch)
+    const size_t target = budget_kb > 0 ? (size_t)budget_kb << 10 : (size_t)256 << 20, cap = 4 * target;
+    int64_t max_used = 0;
+    for (int64_t l = 0; l < n_lev; ++l) max_used = std::max(max_used, g->ops[(size_t)level_index[l]]->csr.n_used_src);
+    const size_t per_outer = (size_t)std::max<int64_t>(max_used, 1) * n_inner * xsz;   // the widest level, one outer index
+    int64_t bo = (int64_t)(cap / per_outer);
+    if (free_b > 0) bo = std::min<int64_t>(bo, (int64_t)(free_b / 8 / (per_outer + (size_t)n_inner * D * ysz)));
+    bo = std::min(bo, n_outer);
+    if (bo >= min_outer) {
+      pack = true;
+      chunks.clear();
+      for (int64_t o0 = 0; o0 < n_outer; o0 += bo) {
+        const int64_t no = std::min(bo, n_outer - o0);
+        for (int64_t l0 = 0; l0 < n_lev;) {
+          int64_t nl = 0;
+          size_t bytes = 0;
+          do {
+            bytes += (size_t)g->ops[(size_t)level_index[l0 + nl]]->csr.n_used_src * no * n_inner * xsz;
+            ++nl;
+          } while (l0 + nl < n_lev &&
+                   bytes + (size_t)g->ops[(size_t)level_index[l0 + nl]]->csr.n_used_src * no * n_inner * xsz <= target);
+          chunks.push_back({o0, no, l0, nl, bytes});
+          l0 += nl;
+        }
+      }
+    }
+  }
+  if (chunks.empty())   // packing not possible after all: whole rows
+    for (int64_t o0 = 0; o0 < n_outer; o0 += hc.units)
+      chunks.push_back({o0, std::min<int64_t>(hc.units, n_outer - o0), 0, n_lev, 0});
+  size_t max_x = 0, max_y = 0, max_rows = 0;
+  for (GChunk& c : chunks) {
+    if (pack && c.x_bytes == 0)
+      for (int64_t l = c.l0; l < c.l0 + c.nl; ++l)
+        c.x_bytes += (size_t)g->ops[(size_t)level_index[l]]->csr.n_used_src * c.no * n_inner * xsz;
+    max_x = std::max(max_x, pack ? c.x_bytes : (size_t)c.no * x_outer_d);
+    max_y = std::max(max_y, (size_t)c.no * n_inner * c.nl * D * ysz);
+    max_rows = std::max(max_rows, (size_t)c.no * rows_per_outer);
+  }
   if (pack) {
     // every selected level is checked before the first launch (as smm_group_apply does): a level that
     // lacks dst_imask / dst_frac must not surface after earlier levels have written part of Y
@@ -1719,13 +1770,44 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
 
   std::lock_guard<std::mutex> pipe_lock(g->pipe_mu);
   HostPipe& pipe = g->pipe;
-  const size_t x_chunk_d = pack ? (size_t)chunk_outer * n_inner * used_total * xsz : (size_t)chunk_outer * x_outer_d;
-  SMM_HIP(pipe.ensure(x_chunk_d, (size_t)chunk_outer * y_outer,
-                      x_direct ? 0 : (pack ? x_chunk_d : (size_t)chunk_outer * rows_per_outer * S * xsz),
-                      y_direct ? 0 : (size_t)chunk_outer * y_outer));
+  SMM_HIP(pipe.ensure(max_x, max_y, x_direct ? 0 : (pack ? max_x : max_rows * S * xsz), y_direct ? 0 : max_y));
 
-  const int64_t n_chunks = (n_outer + chunk_outer - 1) / chunk_outer;
+  const int64_t n_chunks = (int64_t)chunks.size();
   CallStats st;
+  // Y of a chunk on the device: (no, n_inner, nl, D) when transpose, else (nl, no, n_inner, D); on the host the chunk is
+  // the level range [l0, l0 + nl) of rows [o0, o0 + no): `rows` runs of nl * D values at a pitch of n_lev * D (transpose),
+  // nl runs of no * n_inner * D values (else).  whole = the chunk holds every level: one contiguous block when transpose.
+  auto y_to_host = [&](const GChunk& c, const char* src, bool async, hipStream_t stream) -> int {
+    const int64_t bc = c.no * n_inner;
+    if (transpose) {
+      char* dst = (char*)y_host + ((size_t)c.o0 * n_inner * n_lev + (size_t)c.l0) * D * ysz;
+      const size_t width = (size_t)c.nl * D * ysz, pitch = (size_t)n_lev * D * ysz;
+      if (async) {
+        if (c.nl == n_lev)
+          SMM_HIP(hipMemcpyAsync(dst, src, (size_t)bc * width, hipMemcpyDeviceToHost, stream));
+        else
+          SMM_HIP(hipMemcpy2DAsync(dst, pitch, src, width, width, (size_t)bc, hipMemcpyDeviceToHost, stream));
+      } else if (c.nl == n_lev) {
+        int rc = host_copy(dst, src, (size_t)bc * width);
+        if (rc) return rc;
+      } else {
+        int rc = stage_status(smm::host_copy_2d(dst, pitch, src, width, width, bc), "host copy");
+        if (rc) return rc;
+      }
+    } else {  // device chunk is (nl, no, n_inner, D); host is (n_lev, n_outer, n_inner, D)
+      const size_t blk = (size_t)bc * D * ysz;
+      for (int64_t ll = 0; ll < c.nl; ++ll) {
+        char* dst = (char*)y_host + (((size_t)(c.l0 + ll)) * n_outer + (size_t)c.o0) * n_inner * D * ysz;
+        if (async) {
+          SMM_HIP(hipMemcpyAsync(dst, src + (size_t)ll * blk, blk, hipMemcpyDeviceToHost, stream));
+        } else {
+          int rc = host_copy(dst, src + (size_t)ll * blk, blk);
+          if (rc) return rc;
+        }
+      }
+    }
+    return SMM_OK;
+  };
   auto drain = [&](int64_t c) -> int {
     const int b = (int)(c & 1);
     {
@@ -1735,18 +1817,8 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
     st.chunk_done(pipe, b);
     if (!y_direct) {
       StageTimer t(st.v[SMM_HOST_STAT_COPY_OUT_MS]);
-      const int64_t o0 = c * chunk_outer, no = std::min(chunk_outer, n_outer - o0);
-      if (transpose) {
-        int rc = host_copy((char*)y_host + (size_t)o0 * y_outer, pipe.hy[b], (size_t)no * y_outer);
-        if (rc) return rc;
-      } else {  // device chunk is (n_lev, no, n_inner, D); host is (n_lev, n_outer, n_inner, D)
-        const size_t blk = (size_t)no * n_inner * D * ysz;
-        for (int64_t l = 0; l < n_lev; ++l) {
-          int rc = host_copy((char*)y_host + ((size_t)l * n_outer + (size_t)o0) * n_inner * D * ysz,
-                             (char*)pipe.hy[b] + (size_t)l * blk, blk);
-          if (rc) return rc;
-        }
-      }
+      int rc = y_to_host(chunks[(size_t)c], (const char*)pipe.hy[b], false, nullptr);
+      if (rc) return rc;
     }
     return SMM_OK;
   };
@@ -1755,27 +1827,21 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
   auto pipeline = [&]() -> int {   // see smm_apply_host: errors drain both streams before returning
   for (int64_t c = 0; c < n_chunks; ++c) {
     const int b = (int)(c & 1);
-    const int64_t o0 = c * chunk_outer, no = std::min(chunk_outer, n_outer - o0);
-    const int64_t rows = no * rows_per_outer;
+    const GChunk& ck = chunks[(size_t)c];
+    const int64_t o0 = ck.o0, no = ck.no;
     if (c >= 2) {
       int rc = drain(c - 2);
       if (rc) return rc;
     }
     if (c == fail_at) return fail(SMM_ERR_HIP, "injected failure (smm_debug_fail_at_chunk)");
     const char* xsrc = (const char*)x_host + (size_t)o0 * rows_per_outer * S * xsz;
-    int64_t ys_o, ys_l, ys_i;
-    if (transpose) {
-      ys_o = n_inner * n_lev * D, ys_l = D, ys_i = n_lev * D;
-    } else {
-      ys_o = n_inner * D, ys_l = no * n_inner * D, ys_i = D;
-    }
     int rc = SMM_OK;
     if (pack) {
       const int64_t bc = no * n_inner;   // batch entries per level in this chunk: b = (o - o0) * n_inner + i
       size_t off = 0;                    // bytes
       {
         StageTimer t(st.v[SMM_HOST_STAT_STAGE_IN_MS]);
-        for (int64_t l = 0; l < n_lev; ++l) {
+        for (int64_t l = ck.l0; l < ck.l0 + ck.nl; ++l) {
           smm_operator* op = g->ops[(size_t)level_index[l]];
           int hrc = host_pack((char*)pipe.hx[b] + off, xsrc + (size_t)l * n_inner * S * xsz, xsz, n_inner,
                               rows_per_outer * S, S, op->h_used, bc);
@@ -1787,17 +1853,25 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
       SMM_HIP(hipMemcpyAsync(pipe.dx[b], pipe.hx[b], off, hipMemcpyHostToDevice, pipe.stream[b]));
       SMM_HIP(hipEventRecord(pipe.ev[b][1], pipe.stream[b]));
       off = 0;
-      for (int64_t l = 0; l < n_lev && !rc; ++l) {
-        const int w = level_index[l];
+      for (int64_t ll = 0; ll < ck.nl && !rc; ++ll) {
+        const int w = level_index[ck.l0 + ll];
         smm_operator* op = g->ops[(size_t)w];
         unsigned fl = (flags & SMM_APPLY_NO_FILL) | SMM_APPLY_SB_PACKED;
         if ((flags & SMM_APPLY_MASKED) && (!masked_levels || masked_levels[w])) fl |= SMM_APPLY_MASKED;
-        // Y of the chunk: entry (b, l, d) at b * ys_i' + l * ys_l + d, with b running over (o, i)
-        rc = smm_apply_sb(op, (char*)pipe.dx[b] + off, x_dtype, bc, (char*)pipe.dy[b] + (size_t)l * ys_l * ysz, y_dtype,
-                          transpose ? n_lev * D : D, bc, remap_area_min, fl, pipe.stream[b]);
+        // Y of the chunk: entry (b, ll, d) at (b * nl + ll) * D + d when transpose, at (ll * bc + b) * D + d else
+        rc = smm_apply_sb(op, (char*)pipe.dx[b] + off, x_dtype, bc,
+                          (char*)pipe.dy[b] + (size_t)ll * (transpose ? D : bc * D) * ysz, y_dtype,
+                          transpose ? ck.nl * D : D, bc, remap_area_min, fl, pipe.stream[b]);
         off += (size_t)op->csr.n_used_src * bc * xsz;
       }
     } else {
+      const int64_t rows = no * rows_per_outer;
+      int64_t ys_o, ys_l, ys_i;
+      if (transpose) {
+        ys_o = n_inner * n_lev * D, ys_l = D, ys_i = n_lev * D;
+      } else {
+        ys_o = n_inner * D, ys_l = no * n_inner * D, ys_i = D;
+      }
       const void* h2d_src = xsrc;
       if (!x_direct) {
         StageTimer t(st.v[SMM_HOST_STAT_STAGE_IN_MS]);
@@ -1816,17 +1890,11 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
     if (rc) return rc;
     SMM_HIP(hipEventRecord(pipe.ev[b][2], pipe.stream[b]));
     if (!y_direct) {
-      SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)no * y_outer, hipMemcpyDeviceToHost,
+      SMM_HIP(hipMemcpyAsync(pipe.hy[b], pipe.dy[b], (size_t)no * n_inner * ck.nl * D * ysz, hipMemcpyDeviceToHost,
                              pipe.stream[b]));
-    } else if (transpose) {
-      SMM_HIP(hipMemcpyAsync((char*)y_host + (size_t)o0 * y_outer, pipe.dy[b], (size_t)no * y_outer,
-                             hipMemcpyDeviceToHost, pipe.stream[b]));
     } else {
-      const size_t blk = (size_t)no * n_inner * D * ysz;
-      for (int64_t l = 0; l < n_lev; ++l)
-        SMM_HIP(hipMemcpyAsync((char*)y_host + ((size_t)l * n_outer + (size_t)o0) * n_inner * D * ysz,
-                               (char*)pipe.dy[b] + (size_t)l * blk, blk, hipMemcpyDeviceToHost,
-                               pipe.stream[b]));
+      int yrc = y_to_host(ck, (const char*)pipe.dy[b], true, pipe.stream[b]);
+      if (yrc) return yrc;
     }
     SMM_HIP(hipEventRecord(pipe.ev[b][3], pipe.stream[b]));
   }

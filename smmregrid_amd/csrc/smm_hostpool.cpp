@@ -315,6 +315,29 @@ int host_copy(void* dst, const void* src, size_t bytes) noexcept {
 }
 
 namespace {
+struct Copy2dJob {
+  char* dst;
+  const char* src;
+  size_t dpitch, spitch, width;
+  int64_t height, per;
+};
+}  // namespace
+
+int host_copy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int64_t height) noexcept {
+  if (height <= 0 || width == 0) return 0;
+  const size_t total = width * (size_t)height;
+  int nt = (int)std::min<size_t>((size_t)std::min(8, staging_threads()), std::max<size_t>(1, total / (4u << 20)));
+  nt = (int)std::min<int64_t>(nt, height);
+  Copy2dJob job{(char*)dst, (const char*)src, dpitch, spitch, width, height, 1};
+  job.per = std::max<int64_t>(1, height / ((int64_t)std::max(nt, 1) * 4));
+  return pool_run((height + job.per - 1) / job.per, nt, [](void* c, int64_t i) {
+    const Copy2dJob& j = *(const Copy2dJob*)c;
+    const int64_t r0 = i * j.per, r1 = std::min(j.height, r0 + j.per);
+    for (int64_t r = r0; r < r1; ++r) memcpy(j.dst + (size_t)r * j.dpitch, j.src + (size_t)r * j.spitch, j.width);
+  }, &job);
+}
+
+namespace {
 
 // 16 batch entries of one used cell are 128 B (f64) / 64 B (f32) of the packed block: whole cache lines of a buffer
 // nothing reads before the DMA engine does.  Written with non-temporal stores they do not pull the line in first

@@ -63,6 +63,8 @@ int staging_threads();     // threads a staging stage uses: set_host_threads(n) 
 void debug_pool_faults(bool no_threads, int64_t throw_in_task);
 // parallel memcpy (pageable <-> pinned staging): one thread tops out far below PCIe
 int host_copy(void* dst, const void* src, size_t bytes) noexcept;
+// the same for `height` rows of `width` bytes at row pitches dpitch / spitch (the level range of a chunk inside Y)
+int host_copy_2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int64_t height) noexcept;
 // Pack of the host pipelines: out[u * rows + r] = X[entry r][used[u]] -- the used source cells of a chunk of batch
 // entries, batch-fastest, ready for smm_apply_sb (SMM_APPLY_SB_PACKED).  Batch entry r is the source row at
 // x + (r / n_inner) * stride_o + (r % n_inner) * stride_i (elements of xsz bytes): plain row blocks have

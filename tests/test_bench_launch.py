@@ -158,7 +158,10 @@ def test_secondary_entries_keep_their_units():
     cfg3 = {"value": 6e10, "unit": "cells/s", "roofline": {"kernel_ms": 11.4, "frac": 0.47, "traffic": 68.8e9, "algorithmic_bytes": 43.0e9,
                                                              "layout_floor_ratio": 1.31, "refetch_ratio": 1.221},
             "spot_check": {"bit_equal_to_oracle": True}}
-    details = {"others": {"cfg2sb": entry, "cfg3": cfg3, "cfg3c": {"error": "boom"}},
+    c3h = {"time_steps": 24, "input_GB": 21.2, "same_bits": True, "spot_check": True,
+           "packed": {"seconds": 0.1912345, "cells_per_s": 6.1e8, "host_GBs": 110.0, "chunks": 56, "stage_ms": {}},
+           "whole_rows": {"seconds": 0.412, "cells_per_s": 2.83e8, "host_GBs": 51.0, "chunks": 24, "stage_ms": {}}}
+    details = {"others": {"cfg2sb": entry, "cfg3": cfg3, "cfg3c": {"error": "boom"}, "cfg3_host": c3h},
                "baseline_configs": {"cfg4": {"value": 3.4e11, "kernel_ms": 39.6, "frac": 0.5172, "workload": "w", "steps": 3,
                                              "algorithmic_bytes": 163.68e9,
                                              "f32_out": {"kernel_ms": 28.123456, "algorithmic_bytes": 108.6e9, "frac": 0.48271,
@@ -189,6 +192,8 @@ def test_secondary_entries_keep_their_units():
     assert h["pinned_packed"] == [988, 1012, 0.73, 0.81, 15.8, 23.2, 0.3, 4.8, 0.0, 9.7, 29.7] and "Mcells/s median, best" in h["cols"]
     assert h["spot_check"] is True and h["ceil_GBs"] == {"h2d": 57.5, "host_copy": 110.4} and h["staging_threads"] == 16
     assert h["reps"] == 9 and h["cpu_Mcells_per_s"] == 850
+    assert h["cfg3_levels"] == {"steps": 24, "in_GB": 21.2, "packed": [610, 0.191], "whole_rows": [283, 0.412], "ok": True}
+    assert "cfg3_host" not in r["configs"]
     c4 = line["baseline_configs"]["cfg4"]
     assert c4["frac"] == 0.5172 and c4["alg_GB"] == 163.68
     assert c4["f32_out"] == {"ms": 28.123, "frac": 0.4827, "alg_GB": 108.6, "spot_check": True}

@@ -159,3 +159,59 @@ def test_concurrent_host_pipelines_share_the_staging_pool(hip, rng):
         t.join(300)
     assert not any(t.is_alive() for t in threads), "a host pipeline call did not return"
     assert errors == [], errors[:3]
+
+
+@pytest.mark.parametrize("transpose", [True, False])
+@pytest.mark.parametrize("n_inner,dtype", [(1, np.float64), (2, np.float32)])
+def test_level_major_packed_chunks_of_the_group_pipeline(hip, rng, transpose, n_inner, dtype):
+    """smm_group_apply_host, round 6: when 32 batch entries of ALL selected levels do not fit the staging budget (config 3:
+    10 GB), the packed chunks become level-major -- a few consecutive data levels x a block of the outer axis, Y copied
+    back as the level range of those rows.  SMM_TUNE_HOST_CHUNK_KB forces that form at test sizes: several levels per
+    chunk, one level per chunk, several blocks of the outer axis with a short last one; pageable and pinned Y; both Y
+    layouts; a level subset in another order.  Every result bit-equal to the oracle and to the whole-row pipeline."""
+    from smmregrid_amd.weights import compute_weights_matrix3d
+    nx, ny, n_lev = 96, 48, 6
+    src = gridgen.regular_grid(nx, ny)
+    masks = gridgen.synthetic_ocean_masks(nx, ny, n_lev, top=0.45, bottom=0.06)
+    w3 = gridgen.ConservativeLevels(src, "r24x12").stack(masks, np.arange(n_lev, dtype=np.float64))
+    ops = compute_weights_matrix3d(w3, "lev", device=0)
+    S, D = ops[0].n_src, ops[0].n_dst
+    imask = np.stack([op.mask_apply(masks[i]) for i, op in enumerate(ops)])
+    frac = w3["dst_grid_frac"].values
+    for i, op in enumerate(ops):
+        op.set_epilogue(imask[i], frac[i])
+    assert sum(op.n_used_src for op in ops) * 2 <= n_lev * S          # the packing variant applies
+    grp = OperatorGroup(ops)
+    csrs = [op.export_csr() for op in ops]
+    masked_levels = (~(imask == 1).all(axis=1)).astype(np.uint8)
+    for level_index in (np.arange(n_lev, dtype=np.int32), np.array([4, 1, 2], dtype=np.int32)):
+        nl = level_index.size
+        n_outer = 150
+        x = (10.0 + 5.0 * rng.standard_normal((n_outer, nl, n_inner, S))).astype(dtype)
+        for k, l in enumerate(level_index):
+            x[:, k][:, :, masks[l] == 0] = np.nan
+        ref = oracle.apply_levels(csrs, x, 1, level_index, masked_levels.astype(bool), imask, frac, 0.5, transpose)
+        whole = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.5, transpose=transpose,
+                               flags=_lib.APPLY_HOST_NO_PACK)
+        assert_same(whole, ref, exact=True)
+        for kb in (0, 4096, 640, 160):              # default rule; a few levels per chunk ... one level and a block of 38 rows per chunk
+            with _lib.tuning(host_chunk_kb=kb):
+                _lib.host_stats(reset=True)
+                y = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.5, transpose=transpose)
+                st = _lib.host_stats(reset=True)
+            assert_same(y, ref, exact=True)
+            if kb == 160:
+                assert st["chunks"] >= 4 * nl             # level-major AND four blocks of the outer axis (38, 38, 38, 36 rows)
+    # pinned Y: the level range of a chunk goes back by a pitched D2H copy
+    level_index = np.arange(n_lev, dtype=np.int32)
+    x = (10.0 + 5.0 * rng.standard_normal((64, n_lev, n_inner, S))).astype(dtype)
+    ref = oracle.apply_levels(csrs, x, 1, level_index, masked_levels.astype(bool), imask, frac, 0.5, transpose)
+    shape = (64, n_inner, n_lev, D) if transpose else (n_lev, 64, n_inner, D)
+    out = pinned_empty(shape, np.float64)
+    lev, ml = grp._level_args(level_index, masked_levels, n_lev)
+    with _lib.tuning(host_chunk_kb=320):
+        _lib.call("smm_group_apply_host", grp.handle, x.ctypes.data_as(ctypes.c_void_p), 1 if dtype == np.float64 else 0,
+                  out.ctypes.data_as(ctypes.c_void_p), 1, 64, n_lev, n_inner, int(transpose),
+                  lev.ctypes.data_as(ctypes.c_void_p), ml.ctypes.data_as(ctypes.c_void_p), 0.5, _lib.APPLY_MASKED, 0)
+    assert_same(np.array(out), ref, exact=True)
+    grp.close()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host-to-host rate of smm_group_apply_host on config-3 shaped fields (75 masked ocean levels,
-1442x1021 -> r360x180 conservative): per-level packing of the used cells against whole rows."""
+1442x1021 -> r360x180 conservative): level-major packing of the used cells (round 6) against whole rows, with the
+stage split of smm_debug_host_stats.   python tools/host_pipeline_bench_levels.py [time steps, default 16]"""
 import json
 import os
 import sys
@@ -33,10 +34,13 @@ out = {"time_steps": n_t, "levels": n_lev, "input_GB": x.nbytes / 1e9,
 ref = None
 for mode, fl in (("packed", 0), ("whole_rows", _lib.APPLY_HOST_NO_PACK)):
     y = grp.apply_host(x, lev, ml, masked=True, remap_area_min=0.5, flags=fl)      # warm-up
+    _lib.host_stats(reset=True)
     t0 = time.perf_counter()
     y = grp.apply_host(x, lev, ml, masked=True, remap_area_min=0.5, flags=fl)
     dt = time.perf_counter() - t0
+    st = _lib.host_stats(reset=True)
     out[mode] = {"seconds": dt, "cells_per_s": n_t * n_lev * 64800 / dt, "host_GBs": x.nbytes / dt / 1e9}
+    out[mode]["stages"] = {k: round(v, 1) for k, v in st.items()}
     if ref is None:
         ref = y
     else:
