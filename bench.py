@@ -126,8 +126,8 @@ def parse_args():
                          "config-2 rows (block `host_to_host`) and Regridder.regrid on the reference's own fields with the CPU "
                          "oracle beside them (block `reference_sized`)")
     ap.add_argument("--host-rows", type=int, default=512, help="batch rows of the host_to_host block")
-    ap.add_argument("--host-level-steps", type=int, default=24,
-                    help="time steps of the config-3 field held in host memory (75 levels each; 24 = 21 GB)")
+    ap.add_argument("--host-level-steps", type=int, default=40,
+                    help="time steps of the config-3 field held in host memory (75 levels each; 40 = 35 GB; packing needs >= 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -1080,7 +1080,7 @@ def final_line(out, details):
         line["roofline"] = roof
     cpu = line.get("cpu_baseline")
     if cpu:
-        for k in ("legs", "threads", "rows_sampled", "passes", "seconds", "usable_cores"):   # `sample` / `cores` say the same; the legs are in `details`
+        for k in ("legs", "threads", "rows_sampled", "passes", "seconds", "usable_cores", "impl"):   # `sample` / `cores` / `kind` say it; the legs are in `details`
             cpu.pop(k, None)
         cpu["sample"] = short(cpu["sample"], 60)
     cfg = line.get("config") or {}
@@ -1112,7 +1112,7 @@ def final_line(out, details):
     ref = details.get("reference_sized")
     if ref:
         keys = ("in", "init_ms", "regrid_ms", "cpu_scipy_ms", "cpu_c1_ms", "bit_equal")
-        line["reference_sized"] = {"cols": "shape, init ms, regrid() ms host->host, 1-core scipy ms, 1-core C ms, bit_equal"}
+        line["reference_sized"] = {"cols": "shape; ms: init, regrid() host->host, 1-core scipy, 1-core C; bit_equal"}
         for n, e in ref.items():
             line["reference_sized"][n] = ([e.get(k) for k in keys] if "regrid_ms" in e else
                                           {"error": short(e.get("error") or e.get("skipped"), 60)})
@@ -1121,7 +1121,7 @@ def final_line(out, details):
         # per mode: median and best cells/s of `reps` calls, the fraction of the measured PCIe (H2D) and host-memory
         # (2 x the staging pool's copy rate) ceilings it runs at, and the stage split of one call in ms
         blk = {"rows": h2h.get("rows"), "reps": h2h.get("reps"),
-               "cols": "Mcells/s median, best; frac of PCIe, of host-mem rate; ms: in,h2d,kern,d2h,out,wait,total"}
+               "cols": "Mcells/s med, best; frac PCIe, host-mem; ms: in,h2d,kern,d2h,out,wait,total"}
         ceil = h2h.get("ceilings") or {}
         blk["ceil_GBs"] = {k.replace("pcie_", "").replace("_GBs", ""): v for k, v in ceil.items()}
         for k, e in h2h.items():

@@ -2,7 +2,7 @@
 # (bench line, kernel trace, PMC passes per workload), then the driver's command plain and under the kernel trace with the fresh traffic.json.
 mkdir -p gpurun_out/r6n && cd /root/repo
 export TMPDIR=/tmp
-python -m pytest tests/test_gpu_multirank_stand_in.py tests/test_gpu_round6.py -x -q > gpurun_out/r6n/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r6n/tests.log
+python -m pytest tests -m gpu -x -q > gpurun_out/r6n/tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r6n/tests.log
 SMM_GIT_HEAD=$(cat .git_head 2>/dev/null || echo unknown) bash tools/collect_profiles.sh r06 "cfg2 cfg2sb cfg2sbk cfg3 cfg3c cfg3sb cfg4s cfg5tile" pmc > gpurun_out/r6n/collect.log 2>&1; echo "collect rc=$?"; tail -3 gpurun_out/r6n/collect.log
 cp gpurun_out/profiles_new/traffic.json profiles/traffic.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/profiles_new/r06_driver_cmd_bench.json 2> gpurun_out/r6n/bench.err; echo "bench rc=$?"
