@@ -1037,6 +1037,12 @@ def final_line(out, details):
     `roofline` therefore lists its scalars first (the headline's, then every other workload's fraction) and its
     nested `layouts` / `configs` last, and the line ends with `reference_sized`, `baseline_configs`, `host_to_host`."""
     line = dict(out)
+    if isinstance(line.get("value"), float):
+        line["value"] = float(round(line["value"]))            # cells/s to the cell: the digits behind the point are noise
+    if isinstance(line.get("ms_per_step"), float):
+        line["ms_per_step"] = round(line["ms_per_step"], 6)
+    if isinstance(line.get("spot_check"), dict):
+        line["spot_check"] = {k: v for k, v in line["spot_check"].items() if k != "batch_row"}
     others = details.get("others") or {}
     full = line.get("roofline") or {}
     if full.get("traffic") and full.get("algorithmic_bytes"):
