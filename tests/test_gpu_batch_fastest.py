@@ -149,8 +149,9 @@ def test_host_pipeline_packs_the_used_cells(hip, rng, dtype):
     yp = pinned_empty((B, op.n_dst), np.float64)
     op.apply_host(xp, out=yp, masked=True, remap_area_min=0.5)
     assert_same(np.array(yp), ref, exact=True)
-    # fewer than 32 rows: whole rows as before
-    assert_same(op.apply_host(x[:20], masked=True, remap_area_min=0.5), ref[:20], exact=True)
+    # short batches: packed from 8 rows on (round 6; 32 before), whole rows below
+    for rows in (20, 9, 8, 7, 1):
+        assert_same(op.apply_host(x[:rows], masked=True, remap_area_min=0.5), ref[:rows], exact=True)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -202,6 +202,17 @@ def test_level_major_packed_chunks_of_the_group_pipeline(hip, rng, transpose, n_
             assert_same(y, ref, exact=True)
             if kb == 160:
                 assert st["chunks"] >= 4 * nl             # level-major AND four blocks of the outer axis (38, 38, 38, 36 rows)
+    # a short batch (10 entries: below the 32 a block of all levels needs, above the 8 level-major chunks take) is packed too
+    level_index = np.arange(n_lev, dtype=np.int32)
+    x = (10.0 + 5.0 * rng.standard_normal((10, n_lev, n_inner, S))).astype(dtype)
+    for l in range(n_lev):
+        x[:, l][:, :, masks[l] == 0] = np.nan
+    ref = oracle.apply_levels(csrs, x, 1, level_index, masked_levels.astype(bool), imask, frac, 0.5, transpose)
+    _lib.host_stats(reset=True)
+    y = grp.apply_host(x, level_index, masked_levels, masked=True, remap_area_min=0.5, transpose=transpose)
+    st = _lib.host_stats(reset=True)
+    assert_same(y, ref, exact=True)
+    assert st["h2d_ms"] > 0 and st["stage_in_ms"] > 0
     # pinned Y: the level range of a chunk goes back by a pitched D2H copy
     level_index = np.arange(n_lev, dtype=np.int32)
     x = (10.0 + 5.0 * rng.standard_normal((64, n_lev, n_inner, S))).astype(dtype)
