@@ -263,7 +263,7 @@ int smm_apply_sb(smm_operator_t op,
  * transfers of one chunk overlap the kernel of the other.  Synchronous: Y is
  * complete on return.  chunk_rows <= 0 picks ~256 MiB of X per chunk.
  * This path is PCIe-bound (about 100x below the device-resident rate).  When the operator uses at most
- * half of its source cells (bilinear / nearest downsampling) and the batch has >= 8 rows, the staging
+ * four fifths of its source cells (bilinear / nearest downsampling, a masked ocean level) and the batch has >= 8 rows, the staging
  * copy packs only the used cells of a chunk, batch-fastest, and the chunk runs through the kernel of
  * smm_apply_sb: a quarter of the PCIe bytes for config 2, the same bits (SMM_APPLY_HOST_NO_PACK or a
  * forced kernel flag turns it off).
@@ -317,7 +317,7 @@ int smm_group_apply_sb(smm_group_t g,
  * Host-buffer variant (the fields Regridder.regrid3d receives): X host C-contiguous
  * (n_outer, n_lev, n_inner, S); Y host (n_outer, n_inner, n_lev, D) when transpose != 0
  * (regrid.py:420-427) else (n_lev, n_outer, n_inner, D) (regrid.py:410).  Chunks flow through the same
- * double-buffered pipeline as smm_apply_host.  Synchronous.  When the selected levels use at most half of their
+ * double-buffered pipeline as smm_apply_host.  Synchronous.  When the selected levels use at most four fifths of their
  * source cells in total (masked ocean levels thin out with depth) and the batch has >= 8 entries, only the used
  * cells travel over PCIe, packed batch-fastest per level: a chunk is a block of the outer axis with every level when
  * the batch has >= 32 entries and 32 of all levels fit the staging budget, else a few consecutive data levels x a block

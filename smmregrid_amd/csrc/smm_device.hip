@@ -1159,12 +1159,12 @@ static int smm_apply_host_impl(smm_operator_t op, const void* x_host, int x_dtyp
   // source: +17 % fetched bytes when its rows are packed back to back)
   const size_t xrow_d = (((size_t)S * xsz + 127) / 128) * 128;
   const int64_t ldx_d = (int64_t)(xrow_d / xsz);
-  // Operators that use at most half of their source cells (bilinear / nearest downsampling: config 2
+  // Operators that use at most four fifths of their source cells (round 6: half before; bilinear / nearest downsampling: config 2
   // uses a quarter) do not ship the whole field over PCIe: the staging copy packs the used cells of a
   // chunk batch-fastest (host_pack) and the chunk runs through the batch-fastest kernel.  Same bits.
   const int64_t U = op->csr.n_used_src;
   const bool may_pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
-                        U > 0 && U * 2 <= S;
+                        U > 0 && U * 5 <= S * 4;
   // Chunk size from the X AND Y bytes of a row (an operator with few used cells and a large target
   // is bound by its Y staging), clamped to a quarter of the free device memory: smm_internal.h
   size_t free_b = 0, total_b = 0;
@@ -1678,7 +1678,7 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
   const int64_t rows_per_outer = n_lev * n_inner;
   const size_t x_outer_d = (size_t)rows_per_outer * xrow_d;   // device bytes per outer index
   const size_t y_outer = (size_t)rows_per_outer * D * ysz;    // Y bytes per outer index
-  // Packing variant (see smm_apply_host): when the selected levels use at most half of their source
+  // Packing variant (see smm_apply_host): when the selected levels use at most four fifths of their source
   // cells in total -- masked ocean levels thin out with depth -- each level's used cells of a chunk are
   // packed batch-fastest, one (U_l, batch) block per data level, and every level runs through the
   // batch-fastest kernel on its block.
@@ -1697,7 +1697,7 @@ static int smm_group_apply_host_impl(smm_group_t g, const void* x_host, int x_dt
   // 106 GB that way and 37 GB packed).  One time step per chunk with all levels (round 3) ran 4x slower than whole rows.
   const int64_t min_outer = (32 + n_inner - 1) / n_inner;
   const bool may_pack = !(flags & (SMM_APPLY_HOST_NO_PACK | SMM_APPLY_KERNEL_SELL | SMM_APPLY_KERNEL_TILE)) &&
-                        used_total > 0 && used_total * 2 <= n_lev * S;
+                        used_total > 0 && used_total * 5 <= n_lev * S * 4;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
     (void)hipGetLastError();
