@@ -854,6 +854,7 @@ def levels_host_to_host(prob, n_t, reps=3):
     stage split of smm_debug_host_stats, one (time step, level) row checked against the oracle."""
     from oracle import oracle
     from smmregrid_amd import _lib
+    from smmregrid_amd.device import result_cache
     x = np.ascontiguousarray(np.broadcast_to(prob.slab[None, :, None, :], (n_t, prob.n_lev, 1, prob.n_src)))
     x[:, :, 0, ::131] += np.arange(n_t, dtype=np.float64)[:, None, None]          # time steps differ (NaN stays NaN)
     used = sum(op.n_used_src for op in prob.ops)
@@ -864,6 +865,7 @@ def levels_host_to_host(prob, n_t, reps=3):
     for mode, fl in (("packed", 0), ("whole_rows", _lib.APPLY_HOST_NO_PACK)):
         call = lambda: prob.group.apply_host(x, prob.level_index, prob.masked_levels, masked=True, remap_area_min=0.5, flags=fl)
         ys[mode] = call()                                                           # warm-up: staging buffers
+        result_cache.wait()       # ... and the page-locked result block prepared in the background (steady state of a loop)
         _lib.host_stats(reset=True)
         times = []
         for _ in range(reps):

@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray, dtype_code, _stream_handle, current_device
+from .device import DeviceArray, dtype_code, result_cache, _stream_handle, current_device
 
 
 def _cptr(a):
@@ -252,7 +252,7 @@ class SparseOperator:
             x = np.ascontiguousarray(x)
         n_batch = x.shape[0]
         if out is None:
-            out = np.empty((n_batch, self.n_dst), dtype=out_dtype)
+            out = result_cache.empty((n_batch, self.n_dst), out_dtype)      # page-locked and recycled when large
         if out.shape != (n_batch, self.n_dst) or not out.flags.c_contiguous:
             raise ValueError(f"out must be a C-contiguous ({n_batch}, {self.n_dst}) array")
         fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
@@ -400,7 +400,7 @@ class OperatorGroup:
         n_outer, n_lev, n_inner, _ = x.shape
         lev, ml = self._level_args(level_index, masked_levels, n_lev)
         shape = (n_outer, n_inner, n_lev, self.n_dst) if transpose else (n_lev, n_outer, n_inner, self.n_dst)
-        out = np.empty(shape, dtype=out_dtype)
+        out = result_cache.empty(shape, out_dtype)
         fl = int(flags) | (_lib.APPLY_MASKED if masked else 0)
         _lib.call("smm_group_apply_host", self.handle, _cptr(x), dtype_code(x.dtype), _cptr(out),
                   dtype_code(out.dtype), n_outer, n_lev, n_inner, int(bool(transpose)), _cptr(lev),

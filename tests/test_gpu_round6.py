@@ -95,7 +95,7 @@ def test_host_pipeline_stats_and_store_kinds(hip, rng):
     ref = oracle.apply_c(op.export_csr(), x)
     op.apply_host(x)                                                   # warm-up: staging buffers
     _lib.host_stats(reset=True)
-    y = op.apply_host(x, chunk_rows=64)
+    y = op.apply_host(x, out=np.empty((B, D)), chunk_rows=64)        # an ordinary (pageable) result array: a copy-out stage
     st = _lib.host_stats(reset=True)
     assert_same(y, ref, exact=True)
     assert st["calls"] == 1 and st["chunks"] == 4 and st["threads"] >= 1
@@ -226,3 +226,53 @@ def test_level_major_packed_chunks_of_the_group_pipeline(hip, rng, transpose, n_
                   lev.ctypes.data_as(ctypes.c_void_p), ml.ctypes.data_as(ctypes.c_void_p), 0.5, _lib.APPLY_MASKED, 0)
     assert_same(np.array(out), ref, exact=True)
     grp.close()
+
+
+def test_results_come_in_recycled_page_locked_buffers(hip, rng):
+    """apply_host returns a fresh array per call (as the reference's regrid does).  The first large result is an ordinary array
+    (hipHostMalloc never runs on the caller's path) while a page-locked block of its size is prepared in the background; later
+    results take recycled page-locked blocks -- written by the DMA engine directly, no first-touch page faults, no copy-out
+    stage.  Results a caller still holds are never touched by later calls; small results are ordinary arrays;
+    SMM_RESULT_CACHE=0 switches it off."""
+    import gc
+    import os
+    from smmregrid_amd.device import result_cache
+    w, op = _bilinear("r1440x720", "r360x180")
+    x = field(rng, 256, op.n_src)                                  # Y: 256 x 64 800 x 8 B = 133 MB
+    ref = oracle.apply_c(op.export_csr(), x)
+    result_cache.clear()
+    gc.collect()
+    live0, hits0 = result_cache.live, result_cache.hits
+    y0 = op.apply_host(x)                                          # no block yet: an ordinary array, a block is being prepared
+    assert y0.flags.owndata
+    assert_same(y0, ref, exact=True)
+    result_cache.wait()
+    assert result_cache.cached >= y0.nbytes and result_cache.live == live0
+    _lib.host_stats(reset=True)
+    y1 = op.apply_host(x)
+    st = _lib.host_stats(reset=True)
+    assert_same(y1, ref, exact=True)
+    assert st["copy_out_ms"] == 0 and result_cache.hits == hits0 + 1            # written by the DMA engine: no staging copy
+    assert result_cache.live == live0 + y1.nbytes and not y1.flags.owndata and y1.flags.writeable
+    y2 = op.apply_host(x * 2.0)                                   # y1 is still held: its block is not reused, y1 untouched
+    assert_same(y1, ref, exact=True)
+    assert_same(y2, oracle.apply_c(op.export_csr(), x * 2.0), exact=True)
+    keep = y1[3].copy()
+    del y1
+    gc.collect()
+    result_cache.wait()
+    assert result_cache.cached >= y2.nbytes                        # the block went back to the cache ...
+    hits = result_cache.hits
+    y3 = op.apply_host(x)
+    assert result_cache.hits == hits + 1 and not y3.flags.owndata                          # ... and serves the next result
+    assert np.array_equal(y3[3], keep, equal_nan=True)
+    assert_same(y3, ref, exact=True)
+    assert op.apply_host(x[:4]).flags.owndata                     # 2 MB: an ordinary array
+    os.environ["SMM_RESULT_CACHE"] = "0"
+    try:
+        assert op.apply_host(x).flags.owndata
+    finally:
+        del os.environ["SMM_RESULT_CACHE"]
+    del y0, y2, y3
+    gc.collect()
+    result_cache.clear()
