@@ -317,7 +317,7 @@ class _ResultCache:
         self.cached = 0           # bytes waiting in `free`
         self.live = 0             # bytes of blocks backing arrays that are still alive
         self.pending = {}         # nbytes -> thread preparing a block of that size
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()      # re-entrant: a finaliser may fire inside a locked region of the same thread
         self.hits = self.misses = 0
 
     def _add(self, block):
@@ -350,7 +350,7 @@ class _ResultCache:
     def wait(self, timeout=30.0):
         """Block until the background preparations in flight are done (tests, benchmarks of the steady state)."""
         with self.lock:
-            threads = list(self.pending.values())
+            threads = [th for th in self.pending.values() if th is not None]
         for th in threads:
             th.join(timeout)
 
@@ -365,27 +365,32 @@ class _ResultCache:
         nbytes = n * dtype.itemsize
         if nbytes < self.min_bytes or os.environ.get("SMM_RESULT_CACHE") == "0":
             return np.empty(shape, dtype)
-        block = None
-        with self.lock:
+        block, spawn = None, False
+        with self.lock:       # short, allocation-free where it can be: a finaliser (`_release`) may run whenever memory is allocated
             if self.live + nbytes <= self.max_live:
-                for i, (size, b) in enumerate(self.free):
-                    if size >= nbytes and size <= 2 * nbytes + (1 << 20):     # a fitting block, not a much larger one
-                        block = b
-                        del self.free[i]
-                        self.cached -= size
-                        self.live += size
-                        self.hits += 1
+                for entry in self.free:
+                    if nbytes <= entry[0] <= 2 * nbytes + (1 << 20):          # a fitting block, not a much larger one
+                        block = entry[1]
                         break
-                if block is None:
+                if block is not None:
+                    self.free.remove(entry)
+                    self.cached -= block.nbytes
+                    self.live += block.nbytes
+                    self.hits += 1
+                else:
                     self.misses += 1
                     if nbytes not in self.pending and self.cached + nbytes <= self.max_cached:
-                        try:
-                            dev = current_device()
-                        except Exception:
-                            dev = None
-                        th = threading.Thread(target=self._prepare, args=(nbytes, dev), daemon=True)
-                        self.pending[nbytes] = th
-                        th.start()
+                        self.pending[nbytes] = None                            # reserved; the thread is made outside the lock
+                        spawn = True
+        if spawn:
+            try:
+                dev = current_device()
+            except Exception:
+                dev = None
+            th = threading.Thread(target=self._prepare, args=(nbytes, dev), daemon=True)
+            with self.lock:
+                self.pending[nbytes] = th
+            th.start()
         if block is None:
             return np.empty(shape, dtype)
         buf = (ctypes.c_char * max(block.nbytes, 1)).from_address(block.ptr)
