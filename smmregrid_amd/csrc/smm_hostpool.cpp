@@ -17,6 +17,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <mutex>
@@ -102,6 +103,53 @@ int compute_usable_cpus() {
   }
   if (quota > 0) affinity = std::max(1, std::min(affinity, (int)(quota + 0.5)));
   return affinity;
+}
+
+// CPU sets of the NUMA nodes this process may run on (each intersected with the process's affinity mask; nodes without an
+// allowed CPU are left out).  Worker k of the staging pool confines itself to node k % n: the pinned staging buffers live on the
+// GPU's node and the caller's arrays wherever they were first touched, so the pack's threads should sit on BOTH -- left to the
+// scheduler they sometimes all land on the node far from the pinned memory and the pack runs at half speed (profiles/
+// r06_host_to_host.txt: 25.7 against 10.6 - 13.4 ms per 512 rows with the threads on the far node / the near node / both).
+std::vector<cpu_set_t> numa_node_sets() {
+  std::vector<cpu_set_t> nodes;
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return nodes;
+  for (int node = 0; node < 64; ++node) {
+    char path[96];
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f) {
+      if (node > 8) break;   // node numbers may have holes, but not long ones
+      continue;
+    }
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!got) continue;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n_in = 0;
+    for (char* p = line; *p;) {                         // "0-63,128-191"
+      char* end = nullptr;
+      long a = strtol(p, &end, 10);
+      if (end == p) break;
+      long b = a;
+      if (*end == '-') {
+        p = end + 1;
+        b = strtol(p, &end, 10);
+      }
+      for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+        if (c >= 0 && CPU_ISSET((int)c, &allowed)) {
+          CPU_SET((int)c, &set);
+          ++n_in;
+        }
+      p = (*end == ',') ? end + 1 : end;
+      if (*end != ',' ) break;
+    }
+    if (n_in > 0) nodes.push_back(set);
+  }
+  return nodes;
 }
 
 std::atomic<bool> g_pool_no_threads{false};
@@ -200,6 +248,14 @@ class Pool {
 
  private:
   void worker(int index, uint64_t seen) noexcept {
+    try {
+      static const std::vector<cpu_set_t> nodes = numa_node_sets();
+      if (nodes.size() > 1) {
+        const cpu_set_t& mine = nodes[(size_t)index % nodes.size()];
+        (void)sched_setaffinity(0, sizeof(mine), &mine);   // a refusal changes nothing: the thread stays where it may run
+      }
+    } catch (...) {
+    }
     std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
       cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
