@@ -108,3 +108,25 @@ def test_bench_two_ranks_with_gather_through_the_stand_in(hip, fake_rccl):
     assert g["ranks"] == 2 and g["tiles"] == 5 and g["value"] > 0 and g["ms_per_step"] > 0
     assert g["gathered_bytes_per_step"] == 96 * 64800 * 8         # (world - 1) shards of 96 x 64 800 doubles
     assert line["spot_check"]["bit_equal_to_oracle"] is True
+
+
+def test_bench_two_ranks_run_the_baseline_configs_with_their_gathers(hip, fake_rccl):
+    """The rest of the N > 1 bench that had never executed on a GPU: after the headline (config 2 at full size on both
+    ranks, its compute + gather loop) every rank runs its share of BASELINE configs 4 and 5 -- here 8 rows each
+    (--config-batch) -- with the HBM guard decided by all ranks together, the per-rank kernel times collected over the
+    rendezvous and the compute + tiled-gather loop of `baseline_config_block`, all through the stand-in library."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gather", "root", "--steps", "2",
+                          "--warmup", "1", "--config-batch", "8", "--config-steps", "2", "--config-warmup", "1",
+                          "--config-gather-steps", "1", "--gather-tiles", "3"], cwd=ROOT,
+                         env=_env(fake_rccl, SMM_BENCH_SHARE_GPUS="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "error" not in line["with_gather"] and line["with_gather"]["ranks"] == 2
+    assert line["with_gather"]["gathered_bytes_per_step"] == 3600 * 64800 * 8
+    for name, d_cells, y_item in (("cfg4", 12 * 1024 * 1024, 8), ("cfg5", 720 * 360, 8)):
+        blk = line["baseline_configs"][name]
+        assert blk["n_gpus"] == 2 and blk["rows_per_gpu"] == 8 and blk["spot_check"] is True and blk["value"] > 0
+        assert 0 < blk["kernel_ms_min"] <= blk["kernel_ms_max"]
+        g = blk["with_gather"]
+        assert "error" not in g, g
+        assert g["ranks"] == 2 and g["gathered_bytes_per_step"] == 8 * d_cells * y_item and g["tiles"] == 3
